@@ -1,0 +1,207 @@
+"""Generate golden fixtures from the REFERENCE itself (run only in the build container).
+
+    python tests/golden/make_golden.py            # needs /root/reference (read-only)
+
+Imports /root/reference/vae_nets.py + vae_parameters.py (importable, CPU), loads
+the generator-defined weights (critic-vae_amd/synth.py) through load_state_dict, runs the
+reference's own forward / vae_loss / backward (and torch.optim.Adam for the trajectory case),
+cross-checks oracle/cvae_oracle.py against it, and writes small .npz fixtures next to this
+file.  Fixtures hold data only (inputs are regenerated from the seeds stored inside).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+import vae_nets            # noqa: E402  (the reference)
+import vae_parameters      # noqa: E402
+
+import critic_vae_amd as cva                    # noqa: E402
+from critic_vae_amd import synth                # noqa: E402
+from oracle import cvae_oracle as orc           # noqa: E402
+
+N_SAMPLES = 64
+
+
+def load_reference(params_np):
+    v = vae_nets.VariationalAutoencoder()
+    enc = {k[len("encoder."):]: torch.from_numpy(a.copy()) for k, a in params_np.items()
+           if k.startswith("encoder.")}
+    dec = {k[len("decoder."):]: torch.from_numpy(a.copy()) for k, a in params_np.items()
+           if k.startswith("decoder.")}
+    missing = v.encoder.load_state_dict(enc, strict=False)
+    assert not missing.unexpected_keys and all("running" in k or "num_batches" in k
+                                               for k in missing.missing_keys), missing
+    v.decoder.load_state_dict(dec, strict=True)
+    return v
+
+
+def ref_named_params(v):
+    out = {}
+    for k, p in v.encoder.named_parameters():
+        out["encoder." + k] = p
+    for k, p in v.decoder.named_parameters():
+        out["decoder." + k] = p
+    return out
+
+
+def run_reference_step(v, x, pred, eps):
+    """The reference's own forward (vae_nets.py:14-19) with randn_like pinned to eps."""
+    orig = torch.randn_like
+    torch.randn_like = lambda t, *a, **k: eps.clone()
+    try:
+        out = v(x, pred)
+    finally:
+        torch.randn_like = orig
+    losses = v.vae_loss(*out)
+    losses["total_loss"].backward()
+    return out, losses
+
+
+def ref_levels(v, recon, x):
+    """Per-level (ssim, cs) from the reference's MSSIM.ssim (vae_nets.py:181-215)."""
+    import torch.nn.functional as F
+    sims, css = [], []
+    a, b = recon.detach(), x
+    for _ in range(5):
+        s, c = v.mssim_loss.ssim(a, b, 11, 3, True)
+        sims.append(float(s)); css.append(float(c))
+        a, b = F.avg_pool2d(a, (2, 2)), F.avg_pool2d(b, (2, 2))
+    return np.array(sims, np.float32), np.array(css, np.float32)
+
+
+def sample_idx(name, n):
+    k = min(N_SAMPLES, n)
+    u = synth.uniform(99, "idx/" + name, (k,))
+    return np.minimum((u.astype(np.float64) * n).astype(np.int64), n - 1)
+
+
+def step_case(tag, batch, wseed=0, dseed=1234, step=0):
+    params_np = synth.make_params(wseed)
+    x_np, pred_np, eps_np = synth.make_batch(dseed, step, batch)
+    x, pred, eps = map(torch.from_numpy, (x_np, pred_np, eps_np))
+
+    v = load_reference(params_np)
+    out, losses = run_reference_step(v, x, pred, eps)
+    _, mu, logvar, recon = out
+    sims, css = ref_levels(v, recon, x)
+
+    # oracle on the same inputs
+    op = orc.to_torch(params_np, requires_grad=True)
+    bn = orc.new_bn_state(op)
+    o = orc.train_step(op, x, pred, eps, bn_state=bn)
+
+    fx = {"batch": batch, "wseed": wseed, "dseed": dseed, "step": step, "width": 64,
+          "mu": mu.detach().numpy(), "logvar": logvar.detach().numpy(),
+          "recon_sample": recon.detach().numpy().reshape(-1)[::16].copy(),
+          "recon_stats": np.array([recon.min().item(), recon.max().item(),
+                                   recon.double().sum().item()], np.float64),
+          "ssim_levels": sims, "cs_levels": css,
+          "losses": np.array([losses["total_loss"].item(), losses["recon_loss"].item(),
+                              losses["KLD"].item()], np.float32)}
+    if batch <= 2:
+        fx["recon"] = recon.detach().numpy()
+
+    worst = 0.0
+    rp = ref_named_params(v)
+    for name, p in rp.items():
+        g = p.grad.detach().numpy().reshape(-1)
+        go = op[name].grad.numpy().reshape(-1)
+        scale = max(np.abs(g).max(), 1e-30)
+        worst = max(worst, float(np.abs(g - go).max() / scale))
+        idx = sample_idx(name, g.size)
+        fx["grad_norm/" + name] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        fx["grad_sum/" + name] = np.float64(g.astype(np.float64).sum())
+        fx["grad_max/" + name] = np.float32(np.abs(g).max())
+        fx["grad_idx/" + name] = idx
+        fx["grad_val/" + name] = g[idx].copy()
+    for i, (_, bi, _) in enumerate(orc.ENC_BLOCKS):
+        bnm = v.encoder.model[bi]
+        fx[f"bn_running_mean/{bi}"] = bnm.running_mean.numpy().copy()
+        fx[f"bn_running_var/{bi}"] = bnm.running_var.numpy().copy()
+        assert torch.allclose(bnm.running_mean, bn[f"encoder.model.{bi}.running_mean"], atol=1e-6)
+        assert torch.allclose(bnm.running_var, bn[f"encoder.model.{bi}.running_var"], atol=1e-6)
+
+    d = {"mu": (mu - o["mu"]).abs().max().item(),
+         "logvar": (logvar - o["logvar"]).abs().max().item(),
+         "recon": (recon - o["recon"]).abs().max().item(),
+         "loss": abs(losses["total_loss"].item() - o["total_loss"].item()),
+         "grad_rel": worst}
+    print(f"[{tag}] reference loss {fx['losses']}  oracle-vs-reference max diffs {d}")
+    assert all(np.isfinite(fx["losses"])), "pick a finite seed"
+    assert max(d["mu"], d["logvar"], d["recon"], d["loss"]) < 1e-6 and worst < 1e-5, d
+    np.savez_compressed(os.path.join(HERE, f"step_{tag}.npz"), **fx)
+
+
+def trajectory_case(n_frames=1024, batch=32, wseed=0, dseed=1234):
+    """BASELINE.json config 1: one epoch of the vae.py:33-66 loop on synthetic frames (fixed
+    order, explicit eps), torch.optim.Adam(lr=5e-5) — reference modules + torch's own Adam."""
+    params_np = synth.make_params(wseed)
+    v = load_reference(params_np)
+    opt = torch.optim.Adam(list(v.parameters()), lr=vae_parameters.lr)
+    traj = []
+    for s in range(n_frames // batch):
+        x_np, pred_np, eps_np = synth.make_batch(dseed, s, batch)
+        x, pred, eps = map(torch.from_numpy, (x_np, pred_np, eps_np))
+        opt.zero_grad()
+        _, losses = run_reference_step(v, x, pred, eps)
+        opt.step()
+        traj.append([losses["total_loss"].item(), losses["recon_loss"].item(), losses["KLD"].item()])
+    traj = np.array(traj, np.float32)
+    print("[trajectory] first", traj[0], "last", traj[-1], "finite", np.isfinite(traj).all())
+    assert np.isfinite(traj).all()
+    fc = v.encoder.fc_mu.weight.detach().numpy().reshape(-1)
+    np.savez_compressed(os.path.join(HERE, "trajectory_b32.npz"), traj=traj, batch=batch,
+                        n_frames=n_frames, wseed=wseed, dseed=dseed,
+                        fc_mu_weight_head=fc[:256].copy())
+
+
+def msssim_cases():
+    """Op-level MS-SSIM pins, incl. the negative-cs -> NaN behaviour."""
+    m = vae_nets.MSSIM()
+    fx = {}
+    for tag, lo in (("pos", 0.0), ("neg", -1.0), ("nan", None)):
+        b = torch.from_numpy(synth.uniform(5, f"ms/{tag}/b", (4, 3, 64, 64)))
+        if lo is None:      # anti-correlated images: sigma12 < 0 -> cs < 0 -> fractional power -> NaN
+            a = 0.5 - b + 0.01 * torch.from_numpy(synth.uniform(5, f"ms/{tag}/a", (4, 3, 64, 64)))
+        else:
+            a = torch.from_numpy(synth.uniform(5, f"ms/{tag}/a", (4, 3, 64, 64), lo, 1.0))
+        a = a.clone().requires_grad_(True)
+        loss = m(a, b)
+        lo_, s_, c_ = orc.msssim(a.detach(), b)
+        sims, css = [], []
+        import torch.nn.functional as F
+        aa, bb = a.detach(), b
+        for _ in range(5):
+            s, c = m.ssim(aa, bb, 11, 3, True)
+            sims.append(float(s)); css.append(float(c))
+            aa, bb = F.avg_pool2d(aa, (2, 2)), F.avg_pool2d(bb, (2, 2))
+        fx[f"{tag}/loss"] = np.float32(loss.item())
+        fx[f"{tag}/ssim"] = np.array(sims, np.float32)
+        fx[f"{tag}/cs"] = np.array(css, np.float32)
+        assert np.allclose(s_.numpy(), sims, atol=1e-7) and np.allclose(c_.numpy(), css, atol=1e-7)
+        assert (np.isnan(loss.item()) and np.isnan(lo_.item())) or abs(loss.item() - lo_.item()) < 1e-7
+        if np.isfinite(loss.item()):
+            loss.backward()
+            g = a.grad.numpy()
+            fx[f"{tag}/grad_sample"] = g.reshape(-1)[::64].copy()
+            fx[f"{tag}/grad_absmax"] = np.float32(np.abs(g).max())
+        print(f"[msssim/{tag}] loss {loss.item()} cs {css}")
+    fx["window_1d"] = m.gaussian_window(11, 1.5).numpy()
+    np.savez_compressed(os.path.join(HERE, "msssim_ops.npz"), **fx)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    step_case("b2", 2)
+    step_case("b32", 32)
+    msssim_cases()
+    trajectory_case()
+    print("goldens written to", HERE)

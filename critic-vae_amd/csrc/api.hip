@@ -1,0 +1,323 @@
+// api.hip — the C-ABI of include/cvae.h: handle, flat parameter layout, workspace carve and the
+// forward / loss / backward / optimizer orchestration.  Host code only; every launch is
+// asynchronous on the caller's stream, nothing here allocates or synchronises.
+#include "common.h"
+#include "../../include/cvae.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+void cvae_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct ParamEntry { std::string name; int64_t offset, numel; };
+
+struct WsLayout {
+    int64_t y[4], a[4], coef[4], bnpart[4];
+    int64_t zcat, h, o[4];
+    int64_t dout4, d_o[4], d_h, d_zcat, d_a[4], d_y[4];
+    int64_t ms, scratch, total;
+};
+
+struct cvae_handle_s {
+    cvae_config cfg;
+    std::vector<ParamEntry> params;
+    int64_t param_total;
+    int K;                       // bottleneck
+    // parameter indices
+    int enc_w[4], enc_b[4], enc_g[4], enc_be[4], fc_w, fc_b, dec_w[5], dec_b[5], di_w, di_b;
+};
+
+static int layer_h(const cvae_handle_s* h, int layer) { return kLayers[layer].h * (h->cfg.width / 64); }
+
+static WsLayout carve(const cvae_handle_s* h, int B) {
+    WsLayout w{};
+    const int W = h->cfg.width;
+    int64_t off = 0;
+    auto take = [&](int64_t n) { int64_t o = off; off += align_up(n, 64); return o; };
+    for (int l = 0; l < 4; ++l) {
+        const int64_t H = layer_h(h, l), C = kLayers[l].cout;
+        w.y[l] = take(B * H * H * C);
+        w.a[l] = take(B * (H / 2) * (H / 2) * C);
+        w.coef[l] = take(C * 4);
+        w.bnpart[l] = take((int64_t)2 * bn_num_tiles(l, W, B) * C);
+        w.d_y[l] = take(B * H * H * C);
+        w.d_a[l] = take(B * (H / 2) * (H / 2) * C);
+    }
+    w.zcat = take((int64_t)B * 33);
+    w.d_zcat = take((int64_t)B * 33);
+    w.h = take((int64_t)B * h->K);
+    w.d_h = take((int64_t)B * h->K);
+    for (int i = 0; i < 4; ++i) {
+        const int64_t H = layer_h(h, 4 + i), C = kLayers[4 + i].cout;
+        w.o[i] = take(B * H * H * C);
+        w.d_o[i] = take(B * H * H * C);
+    }
+    w.dout4 = take((int64_t)B * 3 * W * W);
+    w.ms = take(msssim_ws_floats(W, B));
+    int64_t sc = 0;
+    auto mx = [&](int64_t v) { if (v > sc) sc = v; };
+    for (int l = 1; l <= 7; ++l) mx(wgrad_ws_floats(l, W, B));
+    mx(e1_wgrad_ws_floats(W, B));
+    mx(d4_bwd_ws_floats(W, B));
+    for (int l = 0; l < 4; ++l) mx(bn_bwd_ws_floats(l, W, B));
+    mx(fc_ws_floats(W, B));
+    mx(colsum_ws_floats(0, 256));
+    w.scratch = take(sc);
+    w.total = off;
+    return w;
+}
+
+static void add_param(cvae_handle_s* h, int* idx, const char* name, int64_t numel) {
+    *idx = (int)h->params.size();
+    h->params.push_back(ParamEntry{name, h->param_total, numel});
+    h->param_total += align_up(numel, 64);
+}
+
+extern "C" {
+
+const char* cvae_version(void) { return "critic-vae_amd 0.1 (gfx950, fp32 MFMA)"; }
+const char* cvae_last_error(void) { return g_err; }
+
+int cvae_create(const cvae_config* cfg, cvae_handle* out) {
+    if (!cfg || !out) { cvae_set_error("cvae_create: null argument"); return CVAE_EINVAL; }
+    if (cfg->width != 64) { cvae_set_error("cvae_create: width %d not supported yet (64 only)", cfg->width); return CVAE_EUNSUPPORTED; }
+    cvae_handle_s* h = new cvae_handle_s();
+    h->cfg = *cfg;
+    h->param_total = 0;
+    h->K = 256 * (cfg->width / 16) * (cfg->width / 16);
+    char nm[64];
+    for (int l = 0; l < 4; ++l) {
+        snprintf(nm, sizeof nm, "enc%d.w", l); add_param(h, &h->enc_w[l], nm, (int64_t)25 * kLayers[l].cin * kLayers[l].cout);
+        snprintf(nm, sizeof nm, "enc%d.b", l); add_param(h, &h->enc_b[l], nm, kLayers[l].cout);
+        snprintf(nm, sizeof nm, "enc%d.gamma", l); add_param(h, &h->enc_g[l], nm, kLayers[l].cout);
+        snprintf(nm, sizeof nm, "enc%d.beta", l); add_param(h, &h->enc_be[l], nm, kLayers[l].cout);
+    }
+    add_param(h, &h->fc_w, "fc.w", (int64_t)h->K * 64);
+    add_param(h, &h->fc_b, "fc.b", 64);
+    for (int i = 0; i < 5; ++i) {
+        snprintf(nm, sizeof nm, "dec%d.w", i); add_param(h, &h->dec_w[i], nm, (int64_t)25 * kLayers[4 + i].cin * kLayers[4 + i].cout);
+        snprintf(nm, sizeof nm, "dec%d.b", i); add_param(h, &h->dec_b[i], nm, kLayers[4 + i].cout);
+    }
+    add_param(h, &h->di_w, "decin.w", (int64_t)33 * h->K);
+    add_param(h, &h->di_b, "decin.b", h->K);
+    *out = h;
+    return CVAE_OK;
+}
+
+void cvae_destroy(cvae_handle h) { delete h; }
+
+int64_t cvae_param_total(cvae_handle h) { return h->param_total; }
+int32_t cvae_param_count(cvae_handle h) { return (int32_t)h->params.size(); }
+const char* cvae_param_name(cvae_handle h, int32_t i) { return h->params[i].name.c_str(); }
+int64_t cvae_param_offset(cvae_handle h, int32_t i) { return h->params[i].offset; }
+int64_t cvae_param_numel(cvae_handle h, int32_t i) { return h->params[i].numel; }
+int64_t cvae_workspace_bytes(cvae_handle h, int32_t batch) { return carve(h, batch).total * 4; }
+int64_t cvae_bn_state_floats(cvae_handle) { return 2 * 480; }
+
+// float offset of a named saved tensor inside the workspace (tests / debugging); -1 if unknown
+int64_t cvae_ws_offset(cvae_handle h, int32_t batch, const char* name) {
+    const WsLayout w = carve(h, batch);
+    char nm[32];
+    for (int l = 0; l < 4; ++l) {
+        snprintf(nm, sizeof nm, "y%d", l); if (!strcmp(name, nm)) return w.y[l];
+        snprintf(nm, sizeof nm, "a%d", l); if (!strcmp(name, nm)) return w.a[l];
+        snprintf(nm, sizeof nm, "d_y%d", l); if (!strcmp(name, nm)) return w.d_y[l];
+        snprintf(nm, sizeof nm, "d_a%d", l); if (!strcmp(name, nm)) return w.d_a[l];
+        snprintf(nm, sizeof nm, "coef%d", l); if (!strcmp(name, nm)) return w.coef[l];
+        snprintf(nm, sizeof nm, "o%d", l); if (!strcmp(name, nm)) return w.o[l];
+        snprintf(nm, sizeof nm, "d_o%d", l); if (!strcmp(name, nm)) return w.d_o[l];
+    }
+    if (!strcmp(name, "zcat")) return w.zcat;
+    if (!strcmp(name, "d_zcat")) return w.d_zcat;
+    if (!strcmp(name, "h")) return w.h;
+    if (!strcmp(name, "d_h")) return w.d_h;
+    if (!strcmp(name, "dout4")) return w.dout4;
+    if (!strcmp(name, "scratch")) return w.scratch;
+    return -1;
+}
+
+static const int kBnOff[4] = {0, 32, 96, 224};
+int cvae_decode(cvae_handle h, int32_t B, const float* zcat, const float* params, float* recon, void* wsv, void* stream);
+
+#define P_(idx) (params + h->params[(idx)].offset)
+#define G_(idx) (grads + h->params[(idx)].offset)
+#define RC(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+static int check(cvae_handle h, int32_t batch, const void* ws) {
+    if (!h) { cvae_set_error("null handle"); return CVAE_EINVAL; }
+    if (batch < 1 || batch > h->cfg.max_batch) { cvae_set_error("batch %d outside [1, %d]", batch, h->cfg.max_batch); return CVAE_EINVAL; }
+    if (!ws) { cvae_set_error("null workspace"); return CVAE_ENOWS; }
+    return 0;
+}
+
+int cvae_forward(cvae_handle h, int32_t B, const float* x, const float* pred, const float* eps, const float* params,
+                 float* bn_state, float* mu, float* logvar, float* recon, void* wsv, int32_t train, void* stream) {
+    RC(check(h, B, wsv));
+    if (B < 2 && train) { /* BatchNorm with one 1x1... still fine: B*H*W >= 2 */ }
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)wsv;
+    const WsLayout w = carve(h, B);
+    const int W = h->cfg.width;
+    for (int l = 0; l < 4; ++l) {
+        if (l == 0) RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], ws + w.bnpart[0], st));
+        else RC(launch_conv_fwd(l, W, B, ws + w.a[l - 1], P_(h->enc_w[l]), P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], st));
+        RC(launch_bn_fwd_finalize(l, W, B, ws + w.bnpart[l], P_(h->enc_g[l]), P_(h->enc_be[l]), bn_state + kBnOff[l],
+                                  bn_state + 480 + kBnOff[l], ws + w.coef[l], train, st));
+        RC(launch_bn_pool_act_fwd(l, W, B, ws + w.y[l], ws + w.coef[l], ws + w.a[l], st));
+    }
+    RC(launch_fc_fwd(W, B, ws + w.a[3], P_(h->fc_w), P_(h->fc_b), eps, pred, mu, logvar, ws + w.zcat, ws + w.scratch, st));
+    if (!recon) return 0;                       // encode only (VariationalEncoder.forward)
+    return cvae_decode(h, B, nullptr, params, recon, wsv, stream);
+}
+
+// Decoder.forward (vae_nets.py:139-147) from zcat = [z | pred] (B,33); zcat == NULL uses the one
+// cvae_forward left in the workspace.
+int cvae_decode(cvae_handle h, int32_t B, const float* zcat, const float* params, float* recon, void* wsv, void* stream) {
+    RC(check(h, B, wsv));
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)wsv;
+    const WsLayout w = carve(h, B);
+    const int W = h->cfg.width;
+    if (zcat) {
+        hipError_t e = hipMemcpyAsync(ws + w.zcat, zcat, (size_t)B * 33 * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) { cvae_set_error("cvae_decode: copy failed: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    RC(launch_decin_fwd(W, B, ws + w.zcat, P_(h->di_w), P_(h->di_b), ws + w.h, st));
+    for (int i = 0; i < 4; ++i)
+        RC(launch_conv_fwd(4 + i, W, B, i == 0 ? ws + w.h : ws + w.o[i - 1], P_(h->dec_w[i]), P_(h->dec_b[i]), ws + w.o[i], nullptr, st));
+    RC(launch_d4_fwd(W, B, ws + w.o[3], P_(h->dec_w[4]), P_(h->dec_b[4]), recon, st));
+    return 0;
+}
+
+int cvae_loss(cvae_handle h, int32_t B, const float* x, const float* mu, const float* logvar, const float* recon,
+              void* wsv, float* scalars, float* d_recon, float* d_mu, float* d_logvar, void* stream) {
+    RC(check(h, B, wsv));
+    if ((d_recon == nullptr) != (d_mu == nullptr) || (d_mu == nullptr) != (d_logvar == nullptr)) {
+        cvae_set_error("cvae_loss: d_recon, d_mu, d_logvar must be all set or all null");
+        return CVAE_EINVAL;
+    }
+    float* ws = (float*)wsv;
+    const WsLayout w = carve(h, B);
+    return launch_msssim(h->cfg.width, B, recon, x, mu, logvar, ws + w.ms, scalars, d_recon, d_mu, d_logvar, (hipStream_t)stream);
+}
+
+int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, const float* eps, const float* params,
+                  const float* logvar, const float* recon, const float* d_recon, const float* d_mu,
+                  const float* d_logvar, void* wsv, float* grads, void* stream) {
+    (void)pred;
+    RC(check(h, B, wsv));
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)wsv;
+    const WsLayout w = carve(h, B);
+    const int W = h->cfg.width;
+    float* sc = ws + w.scratch;
+    // decoder, last layer first
+    RC(launch_d4_bwd(W, B, ws + w.o[3], d_recon, recon, P_(h->dec_w[4]), ws + w.dout4, ws + w.d_o[3],
+                     G_(h->dec_w[4]), G_(h->dec_b[4]), sc, st));
+    for (int i = 3; i >= 0; --i) {
+        const int l = 4 + i;
+        const int64_t H = layer_h(h, l);
+        const float* in = i == 0 ? ws + w.h : ws + w.o[i - 1];
+        RC(launch_conv_wgrad(l, W, B, in, ws + w.d_o[i], G_(h->dec_w[i]), sc, st));
+        RC(launch_colsum(ws + w.d_o[i], (int64_t)B * H * H, kLayers[l].cout, G_(h->dec_b[i]), sc, st));
+        RC(launch_conv_dgrad(l, W, B, ws + w.d_o[i], P_(h->dec_w[i]), i == 0 ? nullptr : ws + w.o[i - 1],
+                             i == 0 ? ws + w.d_h : ws + w.d_o[i - 1], st));
+    }
+    // latent
+    RC(launch_decin_bwd(W, B, ws + w.zcat, ws + w.d_h, P_(h->di_w), G_(h->di_w), G_(h->di_b), ws + w.d_zcat, sc, st));
+    RC(launch_fc_bwd(W, B, ws + w.a[3], P_(h->fc_w), ws + w.d_zcat, eps, logvar, d_mu, d_logvar, G_(h->fc_w),
+                     G_(h->fc_b), ws + w.d_a[3], sc, st));
+    // encoder
+    for (int l = 3; l >= 0; --l) {
+        RC(launch_bn_pool_act_bwd(l, W, B, ws + w.y[l], ws + w.a[l], ws + w.d_a[l], ws + w.coef[l], P_(h->enc_g[l]),
+                                  ws + w.d_y[l], G_(h->enc_g[l]), G_(h->enc_be[l]), G_(h->enc_b[l]), sc, st));
+        if (l == 0) {
+            RC(launch_e1_wgrad(W, B, x, ws + w.d_y[0], G_(h->enc_w[0]), sc, st));
+        } else {
+            RC(launch_conv_wgrad(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), sc, st));
+            RC(launch_conv_dgrad(l, W, B, ws + w.d_y[l], P_(h->enc_w[l]), nullptr, ws + w.d_a[l - 1], st));
+        }
+    }
+    return 0;
+}
+
+int cvae_adam_step(cvae_handle h, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   int32_t step, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    if (!h || step < 1) { cvae_set_error("cvae_adam_step: bad handle/step"); return CVAE_EINVAL; }
+    return launch_adam(params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream);
+}
+
+// ------------------------------ per-op entry points ------------------------------
+int cvae_op_conv_fwd(cvae_handle h, int32_t layer, int32_t B, const float* in, const float* wt, const float* bias,
+                     float* out, float* bn_partials, void* stream) {
+    const int W = h->cfg.width;
+    if (layer == 0) return launch_e1_fwd(W, B, in, wt, bias, out, bn_partials, (hipStream_t)stream);
+    if (layer == 8) return launch_d4_fwd(W, B, in, wt, bias, out, (hipStream_t)stream);
+    return launch_conv_fwd(layer, W, B, in, wt, bias, out, bn_partials, (hipStream_t)stream);
+}
+
+int cvae_op_conv_dgrad(cvae_handle h, int32_t layer, int32_t B, const float* dout, const float* wt,
+                       const float* mask_src, float* din, void* stream) {
+    return launch_conv_dgrad(layer, h->cfg.width, B, dout, wt, mask_src, din, (hipStream_t)stream);
+}
+
+int64_t cvae_op_scratch_floats(cvae_handle h, int32_t B) {
+    const WsLayout w = carve(h, B);
+    return w.total - w.scratch;
+}
+
+int cvae_op_conv_wgrad(cvae_handle h, int32_t layer, int32_t B, const float* in, const float* dout, float* dw,
+                       float* dbias, void* scratch, void* stream) {
+    const int W = h->cfg.width;
+    hipStream_t st = (hipStream_t)stream;
+    float* sc = (float*)scratch;
+    if (layer == 0) return launch_e1_wgrad(W, B, in, dout, dw, sc, st);
+    RC(launch_conv_wgrad(layer, W, B, in, dout, dw, sc, st));
+    if (dbias) {
+        const int64_t H = layer_h(h, layer);
+        RC(launch_colsum(dout, (int64_t)B * H * H, kLayers[layer].cout, dbias, sc, st));
+    }
+    return 0;
+}
+
+int cvae_op_d4_bwd(cvae_handle h, int32_t B, const float* o3, const float* d_recon, const float* recon, const float* wt,
+                   float* dout, float* d_o3, float* dw, float* db, void* scratch, void* stream) {
+    return launch_d4_bwd(h->cfg.width, B, o3, d_recon, recon, wt, dout, d_o3, dw, db, (float*)scratch, (hipStream_t)stream);
+}
+
+int cvae_op_bn_pool_act_fwd(cvae_handle h, int32_t layer, int32_t B, const float* y, const float* bn_partials,
+                            const float* gamma, const float* beta, float* run_mean, float* run_var, float* coef,
+                            float* a, int32_t train, void* stream) {
+    const int W = h->cfg.width;
+    RC(launch_bn_fwd_finalize(layer, W, B, bn_partials, gamma, beta, run_mean, run_var, coef, train, (hipStream_t)stream));
+    return launch_bn_pool_act_fwd(layer, W, B, y, coef, a, (hipStream_t)stream);
+}
+
+int cvae_op_bn_pool_act_bwd(cvae_handle h, int32_t layer, int32_t B, const float* y, const float* a, const float* da,
+                            const float* coef, const float* gamma, float* dy, float* dgamma, float* dbeta, float* dbias,
+                            void* scratch, void* stream) {
+    return launch_bn_pool_act_bwd(layer, h->cfg.width, B, y, a, da, coef, gamma, dy, dgamma, dbeta, dbias,
+                                  (float*)scratch, (hipStream_t)stream);
+}
+
+int64_t cvae_op_bn_partial_floats(cvae_handle h, int32_t layer, int32_t B) {
+    return (int64_t)2 * bn_num_tiles(layer, h->cfg.width, B) * kLayers[layer].cout;
+}
+
+int64_t cvae_op_msssim_ws_floats(cvae_handle h, int32_t B) { return msssim_ws_floats(h->cfg.width, B); }
+
+int cvae_op_msssim(cvae_handle h, int32_t B, const float* img1, const float* img2, void* ws, float* scalars,
+                   float* d_img1, void* stream) {
+    return launch_msssim(h->cfg.width, B, img1, img2, nullptr, nullptr, (float*)ws, scalars, d_img1, nullptr, nullptr,
+                         (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,245 @@
+// bn.hip — train-mode BatchNorm2d + MaxPool2d(2) + ReLU/Tanh, forward and backward, NHWC.
+//
+// Replaces the ATen chain nn.BatchNorm2d -> nn.MaxPool2d(2) -> nn.ReLU / nn.Tanh of the four
+// encoder blocks (vae_nets.py:70-72, 75-77, 80-82, 85-87) and its autograd (vae.py:57).
+// All of it is HBM-bound elementwise / reduction work; every reduction is two fixed-order
+// stages (per-workgroup partials, then a finalize kernel) -> bitwise reproducible.
+//
+// forward : conv epilogue emits per-tile (sum, M2) -> bn_fwd_finalize merges them in fp64
+//           (Chan) into coef[c] = {scale, shift, mean, invstd} and updates the running stats
+//           (momentum 0.1, unbiased variance) -> bn_pool_act_fwd applies scale/shift, takes the
+//           2x2 max (first maximum in scan order, like ATen) and the activation.
+// backward: g = da * act'(a) lives only at each window's argmax (recomputed from y), so
+//           sum(g) and sum(g*xhat) run over pooled pixels; dy = scale*(g - mean(g) - xhat*mean(g*xhat)).
+#include "common.h"
+
+struct BnGeom { int C, H, act; };                       // act: 0 relu, 1 tanh
+static inline BnGeom bn_geom(int layer, int width) {
+    const int s = width / 64;
+    return BnGeom{kLayers[layer].cout, kLayers[layer].h * s, layer == 3 ? 1 : 0};
+}
+static inline void tile_geom(int H, int* imgs, int* pxPerImg, int* tilesPerImg) {
+    const int TW = H < 32 ? H : 32;
+    const int TH = (128 / TW) < H ? (128 / TW) : H;
+    *imgs = 128 / (TW * TH);
+    *pxPerImg = TW * TH;
+    *tilesPerImg = (H / TW) * (H / TH);
+}
+int bn_num_tiles(int layer, int width, int B) {
+    const BnGeom g = bn_geom(layer, width);
+    int imgs, ppi, tpi;
+    tile_geom(g.H, &imgs, &ppi, &tpi);
+    return cdiv(B, imgs) * tpi;
+}
+
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
+    const float* __restrict__ part, int numTiles, int C, int B, int imgsPerTile, int pxPerImg,
+    int tilesPerImg, double N, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ coef, int train) {
+    __shared__ double red[3][8][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    double S = 0.0, Q = 0.0, M = 0.0;
+    if (train) {
+        for (int t = rg; t < numTiles; t += 8) {
+            const int img0 = (t / tilesPerImg) * imgsPerTile;
+            int ni = B - img0; if (ni > imgsPerTile) ni = imgsPerTile;
+            const double n = (double)(ni * pxPerImg);
+            const double s = (double)part[(size_t)t * C + c];
+            S += s; Q += s * s / n; M += (double)part[((size_t)numTiles + t) * C + c];
+        }
+    }
+    red[0][rg][cl] = S; red[1][rg][cl] = Q; red[2][rg][cl] = M;
+    __syncthreads();
+    if (rg == 0) {
+        float mean, var;
+        if (train) {
+            for (int k = 1; k < 8; ++k) { S += red[0][k][cl]; Q += red[1][k][cl]; M += red[2][k][cl]; }
+            const double mu = S / N;
+            double v = (M + Q - S * S / N) / N;          // biased variance
+            if (v < 0.0) v = 0.0;
+            mean = (float)mu; var = (float)v;
+            run_mean[c] = 0.9f * run_mean[c] + 0.1f * mean;
+            run_var[c] = 0.9f * run_var[c] + 0.1f * (float)(v * N / (N - 1.0));
+        } else {
+            mean = run_mean[c]; var = run_var[c];
+        }
+        const float invstd = 1.0f / sqrtf(var + 1e-5f);
+        const float scale = gamma[c] * invstd;
+        coef[c * 4 + 0] = scale;
+        coef[c * 4 + 1] = beta[c] - mean * scale;
+        coef[c * 4 + 2] = mean;
+        coef[c * 4 + 3] = invstd;
+    }
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act) { return act ? tanhf(v) : fmaxf(v, 0.f); }
+__device__ __forceinline__ float act_bwd_from_out(float a, int act) { return act ? (1.f - a * a) : (a > 0.f ? 1.f : 0.f); }
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_pool_act_fwd_kernel(const float* __restrict__ y, const float* __restrict__ coef,
+                                                              float* __restrict__ a, int C, int H, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int C4 = C / 4, HO = H / 2;
+    const int c4 = (int)(idx % C4);
+    const int64_t pp = idx / C4;
+    const int px = (int)(pp % HO), py = (int)((pp / HO) % HO);
+    const int64_t ib = pp / ((int64_t)HO * HO);
+    float sc[4], sh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sc[e] = coef[(c4 * 4 + e) * 4]; sh[e] = coef[(c4 * 4 + e) * 4 + 1]; }
+    const float* base = y + ((ib * H + 2 * py) * H + 2 * px) * C + c4 * 4;
+    float m[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float4 v = *reinterpret_cast<const float4*>(base + ((p >> 1) * H + (p & 1)) * (int64_t)C);
+        const float n[4] = {fmaf(v.x, sc[0], sh[0]), fmaf(v.y, sc[1], sh[1]), fmaf(v.z, sc[2], sh[2]), fmaf(v.w, sc[3], sh[3])};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = (p == 0 || n[e] > m[e]) ? n[e] : m[e];
+    }
+    float4 o = make_float4(act_fwd(m[0], ACT), act_fwd(m[1], ACT), act_fwd(m[2], ACT), act_fwd(m[3], ACT));
+    *reinterpret_cast<float4*>(a + pp * C + c4 * 4) = o;
+}
+
+// per pooled pixel / channel: g = da*act'(a) at the window argmax; returns argmax position and xhat there
+__device__ __forceinline__ void window_argmax(const float* base, int H, int C, int e, float sc, float sh, float mean,
+                                              float invstd, int* pos, float* xhat_max, float (&yv)[4]) {
+    float m = 0.f, ym = 0.f; int bp = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        yv[p] = base[((p >> 1) * H + (p & 1)) * (int64_t)C + e];
+        const float n = fmaf(yv[p], sc, sh);
+        if (p == 0 || n > m) { m = n; bp = p; ym = yv[p]; }
+    }
+    *pos = bp;
+    *xhat_max = (ym - mean) * invstd;
+}
+
+// MODE 0: partial sums (sum g, sum g*xhat) per channel.  MODE 1: write dy, partial sums of dy.
+template <int ACT, int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ y, const float* __restrict__ a,
+                                                     const float* __restrict__ da, const float* __restrict__ coef,
+                                                     const float* __restrict__ bcoef, float* __restrict__ dy,
+                                                     float* __restrict__ part, int C, int H, int64_t totalPx, int64_t pxPerBlk) {
+    __shared__ float red[2][256];
+    const int HO = H / 2;
+    const int c = threadIdx.x % C, sub = threadIdx.x / C, NSUB = 256 / C;     // C <= 256, divides 256
+    const float sc = coef[c * 4], sh = coef[c * 4 + 1], mean = coef[c * 4 + 2], invstd = coef[c * 4 + 3];
+    float k1 = 0.f, k2 = 0.f;
+    if (MODE == 1) { k1 = bcoef[c * 2]; k2 = bcoef[c * 2 + 1]; }
+    const int64_t p0 = blockIdx.x * pxPerBlk;
+    int64_t p1 = p0 + pxPerBlk; if (p1 > totalPx) p1 = totalPx;
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int64_t pp = p0 + sub; pp < p1; pp += NSUB) {
+        const int px = (int)(pp % HO), py = (int)((pp / HO) % HO);
+        const int64_t ib = pp / ((int64_t)HO * HO);
+        const float* base = y + ((ib * H + 2 * py) * H + 2 * px) * C;
+        int pos; float xh; float yv[4];
+        window_argmax(base, H, C, c, sc, sh, mean, invstd, &pos, &xh, yv);
+        const float av = a[pp * C + c];
+        const float g = da[pp * C + c] * act_bwd_from_out(av, ACT);
+        if (MODE == 0) {
+            acc0 += g; acc1 += g * xh;
+        } else {
+            float* dbase = dy + ((ib * H + 2 * py) * H + 2 * px) * C;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float xhat = (yv[p] - mean) * invstd;
+                const float d = sc * ((p == pos ? g : 0.f) - k1 - xhat * k2);
+                dbase[((p >> 1) * H + (p & 1)) * (int64_t)C + c] = d;
+                acc0 += d;
+            }
+        }
+    }
+    red[0][threadIdx.x] = acc0; red[1][threadIdx.x] = acc1;
+    __syncthreads();
+    if (sub == 0) {
+        for (int k = 1; k < NSUB; ++k) { acc0 += red[0][k * C + c]; acc1 += red[1][k * C + c]; }
+        if (MODE == 0) {
+            part[((size_t)blockIdx.x * 2) * C + c] = acc0;
+            part[((size_t)blockIdx.x * 2 + 1) * C + c] = acc1;
+        } else {
+            part[(size_t)blockIdx.x * C + c] = acc0;
+        }
+    }
+}
+
+// stage 2 of the backward reductions.  MODE 0: dgamma, dbeta, bcoef = (s1/N, s2/N).  MODE 1: dbias.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, float invN,
+                                                              float* __restrict__ o0, float* __restrict__ o1,
+                                                              float* __restrict__ bcoef) {
+    __shared__ float red[2][8][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;   // C % 32 == 0
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = rg; b < nblk; b += 8) {
+        if (MODE == 0) { s1 += part[((size_t)b * 2) * C + c]; s2 += part[((size_t)b * 2 + 1) * C + c]; }
+        else s1 += part[(size_t)b * C + c];
+    }
+    red[0][rg][cl] = s1; red[1][rg][cl] = s2;
+    __syncthreads();
+    if (rg != 0) return;
+    for (int k = 1; k < 8; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+    if (MODE == 0) { o0[c] = s2; o1[c] = s1; bcoef[c * 2] = s1 * invN; bcoef[c * 2 + 1] = s2 * invN; }
+    else o0[c] = s1;
+}
+
+int launch_bn_fwd_finalize(int layer, int width, int B, const float* bnpart, const float* gamma, const float* beta,
+                           float* run_mean, float* run_var, float* coef, int train, hipStream_t st) {
+    const BnGeom g = bn_geom(layer, width);
+    int imgs, ppi, tpi;
+    tile_geom(g.H, &imgs, &ppi, &tpi);
+    const int numTiles = cdiv(B, imgs) * tpi;
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(g.C / 32), dim3(256), 0, st, bnpart, numTiles, g.C, B, imgs, ppi,
+                       tpi, (double)B * g.H * g.H, gamma, beta, run_mean, run_var, coef, train);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_bn_pool_act_fwd(int layer, int width, int B, const float* y, const float* coef, float* a, hipStream_t st) {
+    const BnGeom g = bn_geom(layer, width);
+    const int64_t total = (int64_t)B * (g.H / 2) * (g.H / 2) * (g.C / 4);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (g.act) hipLaunchKernelGGL(bn_pool_act_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, y, coef, a, g.C, g.H, total);
+    else hipLaunchKernelGGL(bn_pool_act_fwd_kernel<0>, dim3(grid), dim3(256), 0, st, y, coef, a, g.C, g.H, total);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+static inline int bn_bwd_blocks(int64_t totalPx, int C) {
+    const int nsub = 256 / C;
+    int64_t nb = totalPx / (nsub * 8);          // >= 8 pixels per thread
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+int64_t bn_bwd_ws_floats(int layer, int width, int B) {
+    const BnGeom g = bn_geom(layer, width);
+    const int64_t totalPx = (int64_t)B * (g.H / 2) * (g.H / 2);
+    return (int64_t)bn_bwd_blocks(totalPx, g.C) * 2 * g.C + 2 * g.C;
+}
+
+int launch_bn_pool_act_bwd(int layer, int width, int B, const float* y, const float* a, const float* da,
+                           const float* coef, const float* gamma, float* dy, float* dgamma, float* dbeta,
+                           float* dbias, float* ws, hipStream_t st) {
+    (void)gamma;
+    const BnGeom g = bn_geom(layer, width);
+    const int64_t totalPx = (int64_t)B * (g.H / 2) * (g.H / 2);
+    const int nblk = bn_bwd_blocks(totalPx, g.C);
+    const int64_t ppb = (totalPx + nblk - 1) / nblk;
+    float* part = ws;
+    float* bcoef = ws + (size_t)nblk * 2 * g.C;
+    const float invN = 1.0f / (float)((double)B * g.H * g.H);
+    const dim3 fin(g.C / 32);
+    if (g.act) hipLaunchKernelGGL((bn_bwd_kernel<1, 0>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, nullptr, nullptr, part, g.C, g.H, totalPx, ppb);
+    else hipLaunchKernelGGL((bn_bwd_kernel<0, 0>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, nullptr, nullptr, part, g.C, g.H, totalPx, ppb);
+    CVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<0>, fin, dim3(256), 0, st, part, nblk, g.C, invN, dgamma, dbeta, bcoef);
+    CVAE_CHECK_LAUNCH();
+    if (g.act) hipLaunchKernelGGL((bn_bwd_kernel<1, 1>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, bcoef, dy, part, g.C, g.H, totalPx, ppb);
+    else hipLaunchKernelGGL((bn_bwd_kernel<0, 1>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, bcoef, dy, part, g.C, g.H, totalPx, ppb);
+    CVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<1>, fin, dim3(256), 0, st, part, nblk, g.C, invN, dbias, nullptr, nullptr);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}

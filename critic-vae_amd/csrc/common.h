@@ -1,0 +1,119 @@
+// common.h — shared host/device declarations for libcvae_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CVAE_LATENT 32
+#define CVAE_ZCAT 33
+
+// Conv layers of the path.  0..3 encoder (vae_nets.py:69,74,79,84), 4..8 decoder (:117-133).
+// h = output spatial size at width 64 (scaled by width/64 at run time); up = input is the
+// nearest-2x upsample of the stored tensor (vae_nets.py:119,123,127,131).
+struct LayerDesc { int cin, cout, h, up; };
+static constexpr LayerDesc kLayers[9] = {
+    {3, 32, 64, 0}, {32, 64, 32, 0}, {64, 128, 16, 0}, {128, 256, 8, 0},
+    {256, 128, 4, 0}, {128, 64, 8, 1}, {64, 32, 16, 1}, {32, 32, 32, 1}, {32, 3, 64, 1}};
+
+// ---- output-tile geometry shared by the conv kernels: 128 output pixels per workgroup ----
+template <int H>
+struct Tile {
+    static constexpr int TW = H < 32 ? H : 32;
+    static constexpr int TH = (128 / TW) < H ? (128 / TW) : H;
+    static constexpr int IMGS = 128 / (TW * TH);        // whole images per tile when H*H < 128
+    static constexpr int HTW = TW + 4, HTH = TH + 4;     // halo for the 5x5 window
+    static constexpr int HPI = HTW * HTH;                // halo pixels per image
+    static constexpr int HP = IMGS * HPI;
+    static constexpr int PS = ((HP + 5) / 8) * 8 + 2;    // LDS plane stride, == 2 (mod 8), >= HP
+    static constexpr int TILES_X = H / TW, TILES_Y = H / TH;
+    static constexpr int TILES_PER_IMG = TILES_X * TILES_Y;
+    static_assert(TW * TH * IMGS == 128, "tile must hold 128 pixels");
+};
+
+__host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// error plumbing (api.hip)
+void cvae_set_error(const char* fmt, ...);
+#define CVAE_CHECK_LAUNCH()                                                        \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) {                                                    \
+            cvae_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,          \
+                           hipGetErrorString(e_));                                 \
+            return (int)e_;                                                        \
+        }                                                                          \
+    } while (0)
+
+// ---- launchers implemented across the .hip files (all asynchronous on `st`) ----
+// conv_mfma.hip
+int launch_conv_fwd(int layer, int width, int B, const float* in, const float* w, const float* bias,
+                    float* out, float* bnpart, hipStream_t st);
+int launch_conv_dgrad(int layer, int width, int B, const float* dout, const float* w,
+                      const float* mask_src, float* din, hipStream_t st);
+// conv_wgrad.hip
+int64_t wgrad_ws_floats(int layer, int width, int B);
+int launch_conv_wgrad(int layer, int width, int B, const float* in, const float* dout, float* dw,
+                      float* ws, hipStream_t st);
+int launch_reduce_slabs(const float* slab, float* dst, int64_t n, int S, int64_t stride, hipStream_t st);
+int launch_colsum(const float* src, int64_t rows, int C, float* dst, float* ws, hipStream_t st);
+int64_t colsum_ws_floats(int64_t rows, int C);
+// conv_thin.hip (E1 / D4)
+int launch_e1_fwd(int width, int B, const float* x, const float* w, const float* bias, float* y,
+                  float* bnpart, hipStream_t st);
+int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw, float* ws,
+                    hipStream_t st);
+int64_t e1_wgrad_ws_floats(int width, int B);
+int launch_d4_fwd(int width, int B, const float* in, const float* w, const float* bias, float* recon,
+                  hipStream_t st);
+int64_t d4_bwd_ws_floats(int width, int B);
+int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const float* recon,
+                  const float* w, float* dout, float* d_o3, float* dw, float* db, float* ws,
+                  hipStream_t st);
+// bn.hip
+int bn_num_tiles(int layer, int width, int B);
+int launch_bn_fwd_finalize(int layer, int width, int B, const float* bnpart, const float* gamma,
+                           const float* beta, float* run_mean, float* run_var, float* coef,
+                           int train, hipStream_t st);
+int launch_bn_pool_act_fwd(int layer, int width, int B, const float* y, const float* coef, float* a,
+                           hipStream_t st);
+int64_t bn_bwd_ws_floats(int layer, int width, int B);
+int launch_bn_pool_act_bwd(int layer, int width, int B, const float* y, const float* a,
+                           const float* da, const float* coef, const float* gamma, float* dy,
+                           float* dgamma, float* dbeta, float* dbias, float* ws, hipStream_t st);
+// fc.hip
+int64_t fc_ws_floats(int width, int B);
+int launch_fc_fwd(int width, int B, const float* flat, const float* wfc, const float* bfc,
+                  const float* eps, const float* pred, float* mu, float* logvar, float* zcat,
+                  float* ws, hipStream_t st);
+int launch_decin_fwd(int width, int B, const float* zcat, const float* wd, const float* bd, float* h,
+                     hipStream_t st);
+int launch_decin_bwd(int width, int B, const float* zcat, const float* dh, const float* wd, float* dwd,
+                     float* dbd, float* dzcat, float* ws, hipStream_t st);
+int launch_fc_bwd(int width, int B, const float* flat, const float* wfc, const float* dzcat,
+                  const float* eps, const float* logvar, const float* dmu_loss,
+                  const float* dlv_loss, float* dwfc, float* dbfc, float* dflat, float* ws,
+                  hipStream_t st);
+// msssim.hip
+int64_t msssim_ws_floats(int width, int B);
+int launch_msssim(int width, int B, const float* img1, const float* img2, const float* mu,
+                  const float* logvar, float* ws, float* scalars, float* d_img1, float* d_mu,
+                  float* d_logvar, hipStream_t st);
+// adam.hip
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1,
+                float b2, float eps, float gscale, hipStream_t st);
+int launch_zero(float* p, int64_t n, hipStream_t st);

@@ -1,0 +1,82 @@
+// conv_epilogue.h — accumulator epilogues shared by the MFMA conv kernels.
+#pragma once
+#include "common.h"
+
+enum { EPI_BIAS_BNSTAT = 0, EPI_BIAS_RELU = 1, EPI_PLAIN = 2, EPI_POOLSUM_MASK = 3 };
+
+// Store a 128-pixel x NT-channel tile held as NT/32 32x32 accumulators per wave (wave w = tile
+// rows [32w, 32w+32); element v of lane (li, lh) is row (v&3)+8*(v>>2)+4*lh, column li) to an
+// NHWC tensor, adding the bias (and ReLU), and — for the encoder convs — emit the per-tile,
+// per-channel BatchNorm partials (sum, M2 about the tile mean) that bn_fwd_finalize merges
+// (train-mode batch statistics of nn.BatchNorm2d, vae_nets.py:70,75,80,85).
+// `smem` must be free for reuse (the caller's main loop is done) and hold >= 8*NT floats.
+template <int H, int NT, int NCH, int EPI>
+__device__ __forceinline__ void epilogue_store(f32x16 (&acc)[NT / 32], const float* bias, float* out,
+                                               float* bnpart, float* smem, int B, int mt, int n0,
+                                               int img0, int ty0, int tx0) {
+    using T = Tile<H>;
+    constexpr int NB = NT / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    float bv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bv[nb] = (EPI == EPI_PLAIN) ? 0.f : bias[n0 + nb * 32 + li];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            float x = acc[nb][v] + bv[nb];
+            if (EPI == EPI_BIAS_RELU) x = fmaxf(x, 0.f);
+            acc[nb][v] = x;
+            const int mm = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            const int im = mm / (T::TH * T::TW), rem = mm % (T::TH * T::TW);
+            const int gy = ty0 + rem / T::TW, gx = tx0 + rem % T::TW, ib = img0 + im;
+            if (ib < B) out[((size_t)(ib * H + gy) * H + gx) * NCH + n0 + nb * 32 + li] = x;
+        }
+    if (EPI == EPI_BIAS_BNSTAT) {
+        __syncthreads();
+        float* red = smem;                       // [2][4][NT]
+        int nvalid_img = B - img0;
+        if (nvalid_img > T::IMGS) nvalid_img = T::IMGS;
+        const float cnt = (float)(nvalid_img * T::TH * T::TW);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            float t = 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int mm = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+                if (img0 + mm / (T::TH * T::TW) < B) t += acc[nb][v];
+            }
+            t += __shfl_xor(t, 32, 64);
+            if (lh == 0) red[wave * NT + nb * 32 + li] = t;
+        }
+        __syncthreads();
+        float mean[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int c = nb * 32 + li;
+            mean[nb] = (red[c] + red[NT + c] + red[2 * NT + c] + red[3 * NT + c]) / cnt;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            float t = 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int mm = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+                const float d = acc[nb][v] - mean[nb];
+                if (img0 + mm / (T::TH * T::TW) < B) t += d * d;
+            }
+            t += __shfl_xor(t, 32, 64);
+            if (lh == 0) red[4 * NT + wave * NT + nb * 32 + li] = t;
+        }
+        __syncthreads();
+        if (tid < NT) {
+            const int c = tid;
+            const float sum = red[c] + red[NT + c] + red[2 * NT + c] + red[3 * NT + c];
+            const float m2 = red[4 * NT + c] + red[5 * NT + c] + red[6 * NT + c] + red[7 * NT + c];
+            const size_t nt = gridDim.x;
+            bnpart[(size_t)mt * NCH + n0 + c] = sum;
+            bnpart[(nt + mt) * NCH + n0 + c] = m2;
+        }
+    }
+}

@@ -1,0 +1,223 @@
+// conv_mfma.hip — 5x5 / stride 1 / pad 2 convolution as implicit GEMM on the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain), NHWC activations.
+//
+// Replaces the ATen call sites nn.Conv2d forward (vae_nets.py:74,79,84 encoder E2..E4;
+// :117,121,125,129 decoder D0..D3) and their input-gradients in loss.backward() (vae.py:57).
+//
+//   forward : out[p][n]  = sum_{tap,c} in[p+tap-2][c] * W[tap][c][n]            (+bias, epilogue)
+//   dgrad   : din[p][n]  = sum_{tap,c} dout[p+tap-2][c] * W[24-tap][n][c]      (flipped taps,
+//             transposed weight read from the SAME [tap][Cin][Cout] array)
+//
+// One workgroup = 4 waves = 128 output pixels (Tile<H>) x NT output channels; wave w owns pixel
+// rows [32w,32w+32) of the tile and NB=NT/32 accumulator tiles.  K loop = 16-channel chunks x
+// 5 kernel rows: the input halo of a chunk is staged once in LDS as channel planes and reused
+// by all 25 taps; the weight slab of one kernel row is register-prefetched one stage ahead.
+// The decoder's nearest-2x Upsample (vae_nets.py:119,...) is never materialised: UP folds
+// src=(y>>1,x>>1) into the halo gather; its backward (2x2 sum) and the ReLU mask are the
+// POOLSUM epilogue of dgrad.
+#include "common.h"
+#include "conv_epilogue.h"
+
+
+struct ConvArgs {
+    const float* in;
+    const float* w;
+    const float* bias;
+    const float* aux;   // POOLSUM: forward output of the producing layer (ReLU mask source)
+    float* out;
+    float* bnpart;      // BNSTAT: [2][numTiles][NCH] (sum, M2 about the tile mean)
+    int B;
+};
+
+static constexpr int KC = 16;        // channels per K chunk
+static constexpr int KCP = KC + 1;   // padded row for the transposed (dgrad) weight slab
+
+template <int KCH, int NCH, int H, bool UP, bool DGRAD, int NT, int EPI>
+__global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
+    using T = Tile<H>;
+    constexpr int NB = NT / 32;
+    constexpr int IN_FLOATS = KC * T::PS;
+    constexpr int W_FLOATS = DGRAD ? 5 * NT * KCP : 5 * KC * NT;
+    constexpr int EPI_FLOATS = (EPI == EPI_POOLSUM_MASK) ? 128 * (NT + 1) : 8 * NT;
+    constexpr int SMEM = (IN_FLOATS + W_FLOATS) > EPI_FLOATS ? (IN_FLOATS + W_FLOATS) : EPI_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float* lds_in = smem;
+    float* lds_w = smem + IN_FLOATS;     // IN_FLOATS is a multiple of 4 (KC*PS, KC=16)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int mt = blockIdx.x, n0 = blockIdx.y * NT;
+    const int tileInImg = mt % T::TILES_PER_IMG;
+    const int img0 = (mt / T::TILES_PER_IMG) * T::IMGS;
+    const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;
+    constexpr int HS = UP ? H / 2 : H;   // stored spatial size of the input tensor
+
+    // A operand: lane (li, lh) reads pixel m = 32*wave + li, channel 2j+lh of the chunk
+    const int m = wave * 32 + li;
+    const int pimg = m / (T::TH * T::TW), prem = m % (T::TH * T::TW);
+    const int aBase = lh * T::PS + pimg * T::HPI + (prem / T::TW) * T::HTW + (prem % T::TW);
+    const int bBase = DGRAD ? (li * KCP + lh) : (lh * NT + li);
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[nb][v] = 0.f;
+
+    constexpr int WQ = 5 * KC * NT / 4;              // float4 per weight slab
+    constexpr int WPT = (WQ + 255) / 256;
+    float4 wreg[WPT];
+
+    auto load_w = [&](int st) {
+        const int cc = st / 5, r = st % 5;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int q = tid + i * 256;
+            if (WQ % 256 == 0 || q < WQ) {
+                const float* src;
+                if (!DGRAD) {
+                    const int row = q / (NT / 4), c4 = q % (NT / 4);
+                    const int s = row / KC, kc = row % KC;
+                    src = a.w + (size_t)((r * 5 + s) * KCH + cc * KC + kc) * NCH + n0 + c4 * 4;
+                } else {
+                    const int c4 = q & 3, rown = q >> 2;
+                    const int n = rown % NT, s = rown / NT;
+                    src = a.w + (size_t)((24 - (r * 5 + s)) * NCH + n0 + n) * KCH + cc * KC + c4 * 4;
+                }
+                wreg[i] = *reinterpret_cast<const float4*>(src);
+            }
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int q = tid + i * 256;
+            if (WQ % 256 == 0 || q < WQ) {
+                if (!DGRAD) {
+                    *reinterpret_cast<float4*>(lds_w + q * 4) = wreg[i];
+                } else {
+                    const int c4 = q & 3, rown = q >> 2;
+                    float* d = lds_w + rown * KCP + c4 * 4;   // rown = s*NT + n
+                    d[0] = wreg[i].x; d[1] = wreg[i].y; d[2] = wreg[i].z; d[3] = wreg[i].w;
+                }
+            }
+        }
+    };
+    auto stage_input = [&](int cc) {
+        constexpr int NQ = T::HP * (KC / 4);
+        for (int q = tid; q < NQ; q += 256) {
+            const int c4 = q & 3, hp = q >> 2;
+            const int img = hp / T::HPI, rem = hp - img * T::HPI;
+            const int hy = rem / T::HTW, hx = rem - hy * T::HTW;
+            const int gy = ty0 + hy - 2, gx = tx0 + hx - 2, ib = img0 + img;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B) {
+                const int sy = UP ? (gy >> 1) : gy, sx = UP ? (gx >> 1) : gx;
+                v = *reinterpret_cast<const float4*>(
+                    a.in + ((size_t)(ib * HS + sy) * HS + sx) * KCH + cc * KC + c4 * 4);
+            }
+            float* d = lds_in + (c4 * 4) * T::PS + hp;
+            d[0] = v.x; d[T::PS] = v.y; d[2 * T::PS] = v.z; d[3 * T::PS] = v.w;
+        }
+    };
+
+    constexpr int NST = (KCH / KC) * 5;
+    load_w(0);
+    for (int st = 0; st < NST; ++st) {
+        const int r = st % 5;
+        __syncthreads();                       // everyone finished reading the previous stage
+        if (r == 0) stage_input(st / 5);
+        store_w();
+        if (st + 1 < NST) load_w(st + 1);      // in flight while this stage computes
+        __syncthreads();
+        const float* ap = lds_in + aBase + r * T::HTW;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+#pragma unroll
+            for (int j = 0; j < KC / 2; ++j) {
+                const float av = ap[(2 * j) * T::PS + s];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float bv = DGRAD ? lds_w[bBase + (s * NT + nb * 32) * KCP + 2 * j]
+                                           : lds_w[bBase + (s * KC + 2 * j) * NT + nb * 32];
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nb], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ------------------------------- epilogue -------------------------------
+    if (EPI == EPI_BIAS_BNSTAT || EPI == EPI_BIAS_RELU || EPI == EPI_PLAIN) {
+        epilogue_store<H, NT, NCH, EPI>(acc, a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0);
+    } else {   // EPI_POOLSUM_MASK: 2x2 sum (upsample backward) then ReLU mask of the producer
+        __syncthreads();
+        float* lo = smem;                            // [128][NT+1]
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int mm = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+                lo[mm * (NT + 1) + nb * 32 + li] = acc[nb][v];
+            }
+        __syncthreads();
+        constexpr int PTW = T::TW / 2, PTH = T::TH / 2, HO = H / 2;
+        for (int q = tid; q < 32 * NT; q += 256) {
+            const int c = q % NT, pp = q / NT;
+            const int im = pp / (PTW * PTH), rem = pp % (PTW * PTH);
+            const int py = rem / PTW, px = rem % PTW, ib = img0 + im;
+            if (ib >= a.B) continue;
+            const int m00 = im * T::TH * T::TW + (2 * py) * T::TW + 2 * px;
+            const float sum = (lo[m00 * (NT + 1) + c] + lo[(m00 + 1) * (NT + 1) + c]) +
+                              (lo[(m00 + T::TW) * (NT + 1) + c] + lo[(m00 + T::TW + 1) * (NT + 1) + c]);
+            const size_t o = ((size_t)(ib * HO + ty0 / 2 + py) * HO + tx0 / 2 + px) * NCH + n0 + c;
+            a.out[o] = a.aux[o] > 0.f ? sum : 0.f;
+        }
+    }
+}
+
+template <int KCH, int NCH, int H, bool UP, bool DGRAD, int NT, int EPI>
+static int run(const ConvArgs& a, hipStream_t st) {
+    using T = Tile<H>;
+    static_assert(KCH % KC == 0 && NCH % NT == 0, "channel tiling");
+    dim3 grid(cdiv(a.B, T::IMGS) * T::TILES_PER_IMG, NCH / NT);
+    hipLaunchKernelGGL((conv5x5_mfma_kernel<KCH, NCH, H, UP, DGRAD, NT, EPI>), grid, dim3(256), 0, st, a);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_conv_fwd(int layer, int width, int B, const float* in, const float* w, const float* bias,
+                    float* out, float* bnpart, hipStream_t st) {
+    ConvArgs a{in, w, bias, nullptr, out, bnpart, B};
+    if (width == 64) {
+        switch (layer) {
+            case 1: return run<32, 64, 32, false, false, 64, EPI_BIAS_BNSTAT>(a, st);
+            case 2: return run<64, 128, 16, false, false, 64, EPI_BIAS_BNSTAT>(a, st);
+            case 3: return run<128, 256, 8, false, false, 64, EPI_BIAS_BNSTAT>(a, st);
+            case 4: return run<256, 128, 4, false, false, 64, EPI_BIAS_RELU>(a, st);
+            case 5: return run<128, 64, 8, true, false, 64, EPI_BIAS_RELU>(a, st);
+            case 6: return run<64, 32, 16, true, false, 32, EPI_BIAS_RELU>(a, st);
+            case 7: return run<32, 32, 32, true, false, 32, EPI_BIAS_RELU>(a, st);
+        }
+    }
+    cvae_set_error("conv_fwd: unsupported layer %d at width %d", layer, width);
+    return -2;
+}
+
+int launch_conv_dgrad(int layer, int width, int B, const float* dout, const float* w,
+                      const float* mask_src, float* din, hipStream_t st) {
+    // KCH = layer Cout (channels of dout), NCH = layer Cin (channels of din)
+    ConvArgs a{dout, w, nullptr, mask_src, din, nullptr, B};
+    if (width == 64) {
+        switch (layer) {
+            case 1: return run<64, 32, 32, false, true, 32, EPI_PLAIN>(a, st);
+            case 2: return run<128, 64, 16, false, true, 64, EPI_PLAIN>(a, st);
+            case 3: return run<256, 128, 8, false, true, 64, EPI_PLAIN>(a, st);
+            case 4: return run<128, 256, 4, false, true, 64, EPI_PLAIN>(a, st);
+            case 5: return run<64, 128, 8, false, true, 64, EPI_POOLSUM_MASK>(a, st);
+            case 6: return run<32, 64, 16, false, true, 64, EPI_POOLSUM_MASK>(a, st);
+            case 7: return run<32, 32, 32, false, true, 32, EPI_POOLSUM_MASK>(a, st);
+        }
+    }
+    cvae_set_error("conv_dgrad: unsupported layer %d at width %d", layer, width);
+    return -2;
+}

@@ -1,0 +1,407 @@
+// conv_thin.hip — the two 3-channel convolutions, restructured so the MFMA never sees N=3.
+//
+// E1  (vae_nets.py:69, Conv2d(3,32,5,1,2) on the NCHW frame x):
+//     forward  = GEMM  M=pixels, N=32, K=75(+1 zero)   — x halo staged as 3 LDS planes
+//     wgrad    = GEMM  M=75(+21), N=32, K=pixels       — split-K slabs, fixed-order reduce
+// D4  (vae_nets.py:133-134, Upsample(2) -> Conv2d(32,3,5,1,2) -> Tanh, NCHW recon out):
+//     forward  : Q[src][(tap,co)] = o3[src][:] . W[tap][:][co]  (GEMM M=src pixels, N=75, K=32,
+//                computed at the LOW resolution) then recon[co][y][x] = tanh(b + sum_tap
+//                Q[((y+r-2)>>1,(x+s-2)>>1)][(tap,co)])  — the upsample never exists.
+//     backward : with dOut = d_recon*(1-recon^2) and G[src][(tap,co)] = sum over the 2x2 block q
+//                of src of dOut[co][q-(tap-2)]:   d_o3[src][ci] = relu'(o3) * sum_k G[src][k] W[k][ci]
+//                (GEMM N=32, K=75) and dW[k][ci] = sum_src G[src][k] o3[src][ci] (GEMM M=75, N=32,
+//                K=src pixels) — one fused kernel builds each G tile once in LDS for both.
+#include "common.h"
+#include "conv_epilogue.h"
+
+// LDS offset of GEMM-k = tap*3 + ci inside the 3-plane x halo (k = 75 is the zero pad row)
+template <int PS, int HTW>
+__device__ __forceinline__ constexpr int e1_off(int k) {
+    return k >= 75 ? 0 : (k % 3) * PS + ((k / 3) / 5) * HTW + (k / 3) % 5;
+}
+
+template <int H>
+__device__ __forceinline__ void e1_stage_x(const float* x, float* lds_x, int B, int ib, int ty0, int tx0) {
+    using T = Tile<H>;
+    for (int q = threadIdx.x; q < 3 * T::HPI; q += 256) {
+        const int c = q / T::HPI, hp = q % T::HPI;
+        const int gy = ty0 + hp / T::HTW - 2, gx = tx0 + hp % T::HTW - 2;
+        float v = 0.f;
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < B)
+            v = x[((size_t)(ib * 3 + c) * H + gy) * H + gx];
+        lds_x[c * T::PS + hp] = v;
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void e1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ y,
+                                                     float* __restrict__ bnpart, int B) {
+    using T = Tile<H>;
+    static_assert(T::IMGS == 1 && T::TW == 32, "E1 runs on >=32-wide frames");
+    __shared__ __attribute__((aligned(16))) float smem[3 * T::PS + 76 * 32];
+    float* lds_x = smem;
+    float* lds_w = smem + 3 * T::PS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int mt = blockIdx.x, ib = mt / T::TILES_PER_IMG, tileInImg = mt % T::TILES_PER_IMG;
+    const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;
+    e1_stage_x<H>(x, lds_x, B, ib, ty0, tx0);
+    for (int q = tid; q < 76 * 32; q += 256) lds_w[q] = q < 2400 ? w[q] : 0.f;
+    __syncthreads();
+    f32x16 acc[1];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[0][v] = 0.f;
+    const int aBase = wave * T::HTW + li;           // pixel (row wave, col li) of the 4x32 tile
+#pragma unroll
+    for (int j = 0; j < 38; ++j) {
+        const int off = lh ? e1_off<T::PS, T::HTW>(2 * j + 1) : e1_off<T::PS, T::HTW>(2 * j);
+        const float av = lds_x[aBase + off];
+        const float bv = lds_w[(2 * j + lh) * 32 + li];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0], 0, 0, 0);
+    }
+    __syncthreads();
+    epilogue_store<H, 32, 32, EPI_BIAS_BNSTAT>(acc, bias, y, bnpart, smem, B, mt, 0, ib, ty0, tx0);
+}
+
+struct ThinWgradArgs {
+    const float* a0;     // E1: x (NCHW)          D4: dOut planes (NCHW)
+    const float* a1;     // E1: dy (NHWC, 32)     D4: o3 (NHWC, 32)
+    const float* w;      // D4: W4 [25][32][3]
+    float* din;          // D4: d_o3 (NHWC, 32)
+    float* slab;         // [S][96][32]
+    int B, numTiles, tilesPerSplit;
+};
+
+// sum acc[3] over the 4 waves (through LDS, fixed order) and write the block's slab
+__device__ __forceinline__ void thin_slab_out(f32x16 (&acc)[3], float* red, float* slab_blk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) red[(((wave - 1) * 3 + mb) * 16 + v) * 64 + lane] = acc[mb][v];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float x = acc[mb][v];
+#pragma unroll
+                for (int w2 = 0; w2 < 3; ++w2) x += red[((w2 * 3 + mb) * 16 + v) * 64 + lane];
+                const int k = mb * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+                slab_blk[k * 32 + li] = x;
+            }
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
+    using T = Tile<H>;
+    constexpr int X_FLOATS = ((3 * T::PS + 3) / 4) * 4;
+    constexpr int RED = 3 * 3 * 1024;
+    constexpr int SM = (X_FLOATS + 128 * 32) > RED ? (X_FLOATS + 128 * 32) : RED;
+    __shared__ __attribute__((aligned(16))) float smem[SM];
+    float* lds_x = smem;
+    float* lds_d = smem + X_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    int aoff[3];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb) {
+        const int k = mb * 32 + li;
+        aoff[mb] = k >= 75 ? 0 : (k % 3) * T::PS + ((k / 3) / 5) * T::HTW + (k / 3) % 5;
+    }
+    f32x16 acc[3];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[mb][v] = 0.f;
+    const int t0 = blockIdx.x * a.tilesPerSplit;
+    int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
+    for (int mt = t0; mt < t1; ++mt) {
+        const int ib = mt / T::TILES_PER_IMG, tileInImg = mt % T::TILES_PER_IMG;
+        const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;
+        __syncthreads();
+        e1_stage_x<H>(a.a0, lds_x, a.B, ib, ty0, tx0);
+        for (int q = tid; q < 128 * 8; q += 256) {
+            const int c4 = q & 7, mm = q >> 3;
+            const int gy = ty0 + mm / T::TW, gx = tx0 + mm % T::TW;
+            *reinterpret_cast<float4*>(lds_d + mm * 32 + c4 * 4) = *reinterpret_cast<const float4*>(
+                a.a1 + ((size_t)(ib * H + gy) * H + gx) * 32 + c4 * 4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int mm = wave * 32 + 2 * kk + lh;
+            const int poff = (mm / T::TW) * T::HTW + mm % T::TW;
+            const float bv = lds_d[mm * 32 + li];
+#pragma unroll
+            for (int mb = 0; mb < 3; ++mb)
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds_x[aoff[mb] + poff], bv, acc[mb], 0, 0, 0);
+        }
+    }
+    thin_slab_out(acc, smem, a.slab + (size_t)blockIdx.x * 96 * 32);
+}
+
+// dst[i] = sum_s slab[s][map(i)];  PERM: dst is W4 [tap][ci][co], slab row k = tap*3+co, col ci
+template <bool PERM>
+__global__ __launch_bounds__(256) void thin_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dst, int S) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2400) return;
+    int src = i;
+    if (PERM) { const int co = i % 3, ci = (i / 3) % 32, tap = i / 96; src = (tap * 3 + co) * 32 + ci; }
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += slab[(size_t)s * 3072 + src];
+    dst[i] = acc;
+}
+
+static int thin_splits(int numTiles, int* tps) {
+    int S = numTiles < 1024 ? numTiles : 1024;
+    *tps = cdiv(numTiles, S);
+    return cdiv(numTiles, *tps);
+}
+
+int64_t e1_wgrad_ws_floats(int width, int B) {
+    int tps; const int tiles = B * (width / 4) * (width / 32);
+    return (int64_t)thin_splits(tiles, &tps) * 3072;
+}
+
+int launch_e1_fwd(int width, int B, const float* x, const float* w, const float* bias, float* y,
+                  float* bnpart, hipStream_t st) {
+    if (width != 64) { cvae_set_error("e1_fwd: width %d unsupported", width); return -2; }
+    hipLaunchKernelGGL(e1_fwd_kernel<64>, dim3(B * Tile<64>::TILES_PER_IMG), dim3(256), 0, st, x, w, bias, y, bnpart, B);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw, float* ws, hipStream_t st) {
+    if (width != 64) { cvae_set_error("e1_wgrad: width %d unsupported", width); return -2; }
+    int tps; const int tiles = B * Tile<64>::TILES_PER_IMG;
+    const int S = thin_splits(tiles, &tps);
+    ThinWgradArgs a{x, dy, nullptr, nullptr, ws, B, tiles, tps};
+    hipLaunchKernelGGL(e1_wgrad_kernel<64>, dim3(S), dim3(256), 0, st, a);
+    CVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(thin_reduce_kernel<false>, dim3(cdiv(2400, 256)), dim3(256), 0, st, ws, dw, S);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------ D4 ------------------------------------------------
+
+template <int H>   // H = output size (64); source o3 is (H/2)^2 x 32 NHWC
+__global__ __launch_bounds__(256) void d4_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ recon, int B) {
+    constexpr int HS = H / 2, TPI = (H / 16) * (H / 16);
+    constexpr int A_FLOATS = 128 * 33, B_FLOATS = 32 * 96, Q_FLOATS = 128 * 97;
+    constexpr int SM = (A_FLOATS + B_FLOATS) > Q_FLOATS ? (A_FLOATS + B_FLOATS) : Q_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[SM];
+    float* lds_a = smem;
+    float* lds_b = smem + A_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int ib = blockIdx.x / TPI, t = blockIdx.x % TPI;
+    const int ty0 = (t / (H / 16)) * 16, tx0 = (t % (H / 16)) * 16;
+    const int sy0 = ty0 / 2 - 1, sx0 = tx0 / 2 - 1;           // 10x10 source window
+    for (int q = tid; q < 128 * 8; q += 256) {
+        const int c4 = q & 7, sp = q >> 3;
+        const int sy = sy0 + sp / 10, sx = sx0 + sp % 10;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sp < 100 && (unsigned)sy < (unsigned)HS && (unsigned)sx < (unsigned)HS)
+            v = *reinterpret_cast<const float4*>(in + ((size_t)(ib * HS + sy) * HS + sx) * 32 + c4 * 4);
+        float* d = lds_a + sp * 33 + c4 * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    for (int q = tid; q < 32 * 96; q += 256) {
+        const int ci = q / 96, n = q % 96;
+        lds_b[q] = n < 75 ? w[((n / 3) * 32 + ci) * 3 + n % 3] : 0.f;
+    }
+    __syncthreads();
+    f32x16 acc[3];
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[nb][v] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float av = lds_a[(wave * 32 + li) * 33 + 2 * j + lh];
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, lds_b[(2 * j + lh) * 96 + nb * 32 + li], acc[nb], 0, 0, 0);
+    }
+    __syncthreads();
+    float* lds_q = smem;                                         // [128][97]
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+            lds_q[(wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh) * 97 + nb * 32 + li] = acc[nb][v];
+    __syncthreads();
+    const int oy = tid >> 4, ox = tid & 15;
+    float s0 = bias[0], s1 = bias[1], s2 = bias[2];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const int sr = ((ty0 + oy + r - 2) >> 1) - sy0;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const int sc = ((tx0 + ox + s - 2) >> 1) - sx0;
+            const float* qv = lds_q + (sr * 10 + sc) * 97 + (r * 5 + s) * 3;
+            s0 += qv[0]; s1 += qv[1]; s2 += qv[2];
+        }
+    }
+    const size_t o = ((size_t)(ib * 3) * H + ty0 + oy) * H + tx0 + ox;
+    recon[o] = tanhf(s0);
+    recon[o + (size_t)H * H] = tanhf(s1);
+    recon[o + 2 * (size_t)H * H] = tanhf(s2);
+}
+
+// dOut = d_recon * (1 - recon^2) (Tanh backward, vae_nets.py:134) + per-plane sums for db
+__global__ __launch_bounds__(256) void d4_actbwd_kernel(const float* __restrict__ d_recon, const float* __restrict__ recon,
+                                                        float* __restrict__ dout, float* __restrict__ part, int hw) {
+    __shared__ float red[4];
+    const size_t base = (size_t)blockIdx.x * hw;
+    float acc = 0.f;
+    for (int i = threadIdx.x * 4; i < hw; i += 1024) {
+        const float4 g = *reinterpret_cast<const float4*>(d_recon + base + i);
+        const float4 r = *reinterpret_cast<const float4*>(recon + base + i);
+        float4 o;
+        o.x = g.x * (1.f - r.x * r.x); o.y = g.y * (1.f - r.y * r.y);
+        o.z = g.z * (1.f - r.z * r.z); o.w = g.w * (1.f - r.w * r.w);
+        *reinterpret_cast<float4*>(dout + base + i) = o;
+        acc += (o.x + o.y) + (o.z + o.w);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void d4_dbias_kernel(const float* __restrict__ part, float* __restrict__ db, int B) {
+    const int co = threadIdx.x >> 6, lane = threadIdx.x & 63;      // 3 waves
+    float acc = 0.f;
+    for (int b = lane; b < B; b += 64) acc += part[b * 3 + co];
+    acc = wave_sum(acc);
+    if (lane == 0) db[co] = acc;
+}
+
+template <int H>   // H = output size (64); src tiles of 8 rows x 16 cols at HS = H/2
+__global__ __launch_bounds__(256) void d4_bwd_kernel(ThinWgradArgs a) {
+    constexpr int HS = H / 2, TPI = (HS / 8) * (HS / 16);
+    constexpr int G0 = 3 * 720, O = 128 * 32, G = 128 * 77 + 32, WR = 76 * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* lds_g0 = smem;              // dOut halo planes [3][20][36]
+    float* lds_o = smem + G0;          // o3 tile [128][32]
+    float* lds_G = lds_o + O;          // [128][77] (+32 pad)
+    float* lds_wr = lds_G + G;         // W4r[k=tap*3+co][ci]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    for (int q = tid; q < WR; q += 256) {
+        const int k = q / 32, ci = q % 32;
+        lds_wr[q] = k < 75 ? a.w[((k / 3) * 32 + ci) * 3 + k % 3] : 0.f;
+    }
+    for (int q = tid; q < 32; q += 256) lds_G[128 * 77 + q] = 0.f;
+    f32x16 accw[3];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) accw[mb][v] = 0.f;
+    const int t0 = blockIdx.x * a.tilesPerSplit;
+    int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
+    for (int mt = t0; mt < t1; ++mt) {
+        const int ib = mt / TPI, t = mt % TPI;
+        const int sy0 = (t / (HS / 16)) * 8, sx0 = (t % (HS / 16)) * 16;
+        __syncthreads();
+        for (int q = tid; q < G0; q += 256) {
+            const int c = q / 720, rem = q % 720;
+            const int uy = 2 * sy0 - 2 + rem / 36, ux = 2 * sx0 - 2 + rem % 36;
+            float v = 0.f;
+            if ((unsigned)uy < (unsigned)H && (unsigned)ux < (unsigned)H)
+                v = a.a0[((size_t)(ib * 3 + c) * H + uy) * H + ux];
+            lds_g0[q] = v;
+        }
+        for (int q = tid; q < 128 * 8; q += 256) {
+            const int c4 = q & 7, sp = q >> 3;
+            *reinterpret_cast<float4*>(lds_o + sp * 32 + c4 * 4) = *reinterpret_cast<const float4*>(
+                a.a1 + ((size_t)(ib * HS + sy0 + sp / 16) * HS + sx0 + sp % 16) * 32 + c4 * 4);
+        }
+        __syncthreads();
+        for (int e = tid; e < 128 * 76; e += 256) {
+            const int sp = e / 76, k = e % 76;
+            float g = 0.f;
+            if (k < 75) {
+                const int tap = k / 3, co = k % 3, r = tap / 5, s = tap % 5;
+                const float* p = lds_g0 + co * 720 + (2 * (sp / 16) - r + 4) * 36 + 2 * (sp % 16) - s + 4;
+                g = (p[0] + p[1]) + (p[36] + p[37]);
+            }
+            lds_G[sp * 77 + k] = g;
+        }
+        __syncthreads();
+        // dgrad: d_o3[src][ci] = relu'(o3) * sum_k G[src][k] * W4r[k][ci]
+        f32x16 accd;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) accd[v] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 38; ++j)
+            accd = __builtin_amdgcn_mfma_f32_32x32x2f32(lds_G[(wave * 32 + li) * 77 + 2 * j + lh],
+                                                        lds_wr[(2 * j + lh) * 32 + li], accd, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int sp = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            const float x = lds_o[sp * 32 + li] > 0.f ? accd[v] : 0.f;
+            a.din[((size_t)(ib * HS + sy0 + sp / 16) * HS + sx0 + sp % 16) * 32 + li] = x;
+        }
+        // wgrad: dW[k][ci] += sum_src G[src][k] * o3[src][ci]
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int sp = wave * 32 + 2 * kk + lh;
+            const float bv = lds_o[sp * 32 + li];
+#pragma unroll
+            for (int mb = 0; mb < 3; ++mb)
+                accw[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds_G[sp * 77 + mb * 32 + li], bv, accw[mb], 0, 0, 0);
+        }
+    }
+    thin_slab_out(accw, smem, a.slab + (size_t)blockIdx.x * 96 * 32);
+}
+
+static constexpr int D4_BWD_SMEM = (3 * 720 + 128 * 32 + 128 * 77 + 32 + 76 * 32) * 4;
+
+static int d4_splits(int width, int B, int* tps) {
+    return thin_splits(B * (width / 16) * (width / 32), tps);
+}
+// ws of launch_d4_bwd = [S*3072 split-K slab | B*3 plane sums of dOut]
+int64_t d4_bwd_ws_floats(int width, int B) {
+    int tps;
+    return (int64_t)d4_splits(width, B, &tps) * 3072 + (int64_t)B * 3;
+}
+
+int launch_d4_fwd(int width, int B, const float* in, const float* w, const float* bias, float* recon, hipStream_t st) {
+    if (width != 64) { cvae_set_error("d4_fwd: width %d unsupported", width); return -2; }
+    hipLaunchKernelGGL(d4_fwd_kernel<64>, dim3(B * 16), dim3(256), 0, st, in, w, bias, recon, B);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+// Fused D4 backward: Tanh backward -> dout planes (B,3,W,W), then d_o3 (ReLU-masked), dW4, db4.
+int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const float* recon, const float* w,
+                  float* dout, float* d_o3, float* dw, float* db, float* ws, hipStream_t st) {
+    if (width != 64) { cvae_set_error("d4_bwd: width %d unsupported", width); return -2; }
+    int tps;
+    const int tiles = B * (width / 16) * (width / 32);
+    const int S = d4_splits(width, B, &tps);
+    float* plane_sums = ws + (size_t)S * 3072;
+    hipLaunchKernelGGL(d4_actbwd_kernel, dim3(B * 3), dim3(256), 0, st, d_recon, recon, dout, plane_sums, width * width);
+    CVAE_CHECK_LAUNCH();
+    ThinWgradArgs a{dout, o3, w, d_o3, ws, B, tiles, tps};
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(d4_bwd_kernel<64>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, D4_BWD_SMEM);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(d4_bwd_kernel<64>, dim3(S), dim3(256), D4_BWD_SMEM, st, a);
+    CVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(thin_reduce_kernel<true>, dim3(cdiv(2400, 256)), dim3(256), 0, st, ws, dw, S);
+    CVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(d4_dbias_kernel, dim3(1), dim3(192), 0, st, plane_sums, db, B);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,221 @@
+// fc.hip — the three Linear layers around the latent, fused with reparametrize and the concat.
+//
+// Replaces (vae_nets.py):  :105-109 flatten + fc_mu + fc_var,  :48-51 reparametrize (eps given),
+// :143 cat((z,pred),1) + decoder_input Linear(33, bottleneck),  :144 view(-1,256,s,s), and their
+// autograd.  Tiny GEMMs (0.8 MFLOP/img) -> VALU kernels, LDS-broadcast operands, fixed-order
+// two-stage reductions.  Native layouts: Wfc [K][64] (cols 0..31 = fc_mu, 32..63 = fc_var, K in
+// (h,w,c) order), Wd [33][K] (K in (h,w,c) order) so that `flat`/`h` are the NHWC activations.
+#include "common.h"
+
+static constexpr int FC_KS = 8;          // K splits of the fc_mu|fc_var GEMM
+static constexpr int FC_IMGS = 16;       // images per workgroup
+
+// part[ks][b][64] = sum_{k in split ks} flat[b][k] * Wfc[k][n]
+__global__ __launch_bounds__(256) void fc_fwd_partial_kernel(const float* __restrict__ flat, const float* __restrict__ wfc,
+                                                             float* __restrict__ part, int B, int K) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];   // [FC_IMGS][kchunk]
+    const int kchunk = K / FC_KS;
+    const int b0 = blockIdx.x * FC_IMGS, ks = blockIdx.y, k0 = ks * kchunk;
+    const int n = threadIdx.x & 63, bq = threadIdx.x >> 6;
+    for (int q = threadIdx.x; q < FC_IMGS * kchunk / 4; q += 256) {
+        const int i = q / (kchunk / 4), k4 = q % (kchunk / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b0 + i < B) v = *reinterpret_cast<const float4*>(flat + (size_t)(b0 + i) * K + k0 + k4 * 4);
+        *reinterpret_cast<float4*>(lds_f + i * kchunk + k4 * 4) = v;
+    }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* f = lds_f + (bq * 4) * kchunk;
+    for (int k = 0; k < kchunk; ++k) {
+        const float wv = wfc[(size_t)(k0 + k) * 64 + n];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = fmaf(f[i * kchunk + k], wv, acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int b = b0 + bq * 4 + i;
+        if (b < B) part[((size_t)ks * B + b) * 64 + n] = acc[i];
+    }
+}
+
+// mu, logvar = bias + sum of partials; z = mu + eps*exp(0.5*logvar); zcat = [z | pred]
+__global__ __launch_bounds__(256) void fc_finish_kernel(const float* __restrict__ part, const float* __restrict__ bfc,
+                                                        const float* __restrict__ eps, const float* __restrict__ pred,
+                                                        float* __restrict__ mu, float* __restrict__ logvar,
+                                                        float* __restrict__ zcat, int B) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * 32) return;
+    const int b = idx >> 5, d = idx & 31;
+    float m = bfc[d], lv = bfc[32 + d];
+    for (int ks = 0; ks < FC_KS; ++ks) {
+        m += part[((size_t)ks * B + b) * 64 + d];
+        lv += part[((size_t)ks * B + b) * 64 + 32 + d];
+    }
+    mu[idx] = m;
+    logvar[idx] = lv;
+    zcat[b * 33 + d] = m + eps[idx] * expf(0.5f * lv);
+    if (d == 0) zcat[b * 33 + 32] = pred[b];
+}
+
+// h[b][j] = bd[j] + sum_i zcat[b][i] * Wd[i][j]
+__global__ __launch_bounds__(256) void decin_fwd_kernel(const float* __restrict__ zcat, const float* __restrict__ wd,
+                                                        const float* __restrict__ bd, float* __restrict__ h, int K) {
+    __shared__ float z[33];
+    const int b = blockIdx.x, j = (blockIdx.y * 256 + threadIdx.x) * 4;
+    if (threadIdx.x < 33) z[threadIdx.x] = zcat[b * 33 + threadIdx.x];
+    __syncthreads();
+    float4 acc = *reinterpret_cast<const float4*>(bd + j);
+#pragma unroll
+    for (int i = 0; i < 33; ++i) {
+        const float4 w = *reinterpret_cast<const float4*>(wd + (size_t)i * K + j);
+        acc.x = fmaf(z[i], w.x, acc.x); acc.y = fmaf(z[i], w.y, acc.y);
+        acc.z = fmaf(z[i], w.z, acc.z); acc.w = fmaf(z[i], w.w, acc.w);
+    }
+    *reinterpret_cast<float4*>(h + (size_t)b * K + j) = acc;
+}
+
+// dzcat[b][i] = sum_j dh[b][j] * Wd[i][j]     (one workgroup per image)
+__global__ __launch_bounds__(256) void decin_bwd_dz_kernel(const float* __restrict__ dh, const float* __restrict__ wd,
+                                                           float* __restrict__ dzcat, int K) {
+    __shared__ float red[33][4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = 0; i < 33; ++i) {
+        float acc = 0.f;
+        for (int j = threadIdx.x * 4; j < K; j += 1024) {
+            const float4 g = *reinterpret_cast<const float4*>(dh + (size_t)b * K + j);
+            const float4 w = *reinterpret_cast<const float4*>(wd + (size_t)i * K + j);
+            acc += (g.x * w.x + g.y * w.y) + (g.z * w.z + g.w * w.w);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) red[i][wave] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 33) dzcat[b * 33 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// slab[bs][i][j] (i<33: dWd, i==33: dbd) = sum over the batch slice bs
+__global__ __launch_bounds__(256) void decin_bwd_dw_kernel(const float* __restrict__ zcat, const float* __restrict__ dh,
+                                                           float* __restrict__ slab, int B, int K, int bPerSplit) {
+    __shared__ float z[33];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int b0 = blockIdx.y * bPerSplit;
+    int b1 = b0 + bPerSplit; if (b1 > B) b1 = B;
+    float acc[34];
+#pragma unroll
+    for (int i = 0; i < 34; ++i) acc[i] = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        __syncthreads();
+        if (threadIdx.x < 33) z[threadIdx.x] = zcat[b * 33 + threadIdx.x];
+        __syncthreads();
+        const float g = dh[(size_t)b * K + j];
+#pragma unroll
+        for (int i = 0; i < 33; ++i) acc[i] = fmaf(z[i], g, acc[i]);
+        acc[33] += g;
+    }
+    float* o = slab + (size_t)blockIdx.y * 34 * K;
+#pragma unroll
+    for (int i = 0; i < 34; ++i) o[(size_t)i * K + j] = acc[i];
+}
+
+// dml[b][0..31] = dz + dmu_loss ; dml[b][32..63] = dz*eps*0.5*exp(0.5*logvar) + dlv_loss
+__global__ __launch_bounds__(256) void fc_bwd_prep_kernel(const float* __restrict__ dzcat, const float* __restrict__ eps,
+                                                          const float* __restrict__ logvar, const float* __restrict__ dmu_loss,
+                                                          const float* __restrict__ dlv_loss, float* __restrict__ dml, int B) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * 32) return;
+    const int b = idx >> 5, d = idx & 31;
+    const float dz = dzcat[b * 33 + d];
+    dml[b * 64 + d] = dz + dmu_loss[idx];
+    dml[b * 64 + 32 + d] = dz * eps[idx] * 0.5f * expf(0.5f * logvar[idx]) + dlv_loss[idx];
+}
+
+// dflat[b][k] = sum_n dml[b][n] * Wfc[k][n]
+__global__ __launch_bounds__(256) void fc_bwd_dflat_kernel(const float* __restrict__ dml, const float* __restrict__ wfc,
+                                                           float* __restrict__ dflat, int B, int K) {
+    __shared__ float g[8][64];
+    const int b0 = blockIdx.x * 8, k = blockIdx.y * 256 + threadIdx.x;
+    for (int q = threadIdx.x; q < 8 * 64; q += 256) g[q >> 6][q & 63] = (b0 + (q >> 6) < B) ? dml[(size_t)(b0 + (q >> 6)) * 64 + (q & 63)] : 0.f;
+    __syncthreads();
+    float w[64];
+#pragma unroll
+    for (int n4 = 0; n4 < 16; ++n4) {
+        const float4 v = *reinterpret_cast<const float4*>(wfc + (size_t)k * 64 + n4 * 4);
+        w[n4 * 4] = v.x; w[n4 * 4 + 1] = v.y; w[n4 * 4 + 2] = v.z; w[n4 * 4 + 3] = v.w;
+    }
+    for (int i = 0; i < 8; ++i) {
+        if (b0 + i >= B) break;
+        float acc = 0.f;
+#pragma unroll
+        for (int n = 0; n < 64; ++n) acc = fmaf(g[i][n], w[n], acc);
+        dflat[(size_t)(b0 + i) * K + k] = acc;
+    }
+}
+
+// dWfc[k][n] = sum_b flat[b][k] * dml[b][n]    (4 k-rows per workgroup, all of the batch)
+__global__ __launch_bounds__(256) void fc_bwd_dw_kernel(const float* __restrict__ flat, const float* __restrict__ dml,
+                                                        float* __restrict__ dwfc, int B, int K) {
+    const int n = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc = fmaf(flat[(size_t)b * K + k], dml[(size_t)b * 64 + n], acc);
+    dwfc[(size_t)k * 64 + n] = acc;
+}
+
+static inline int bott(int width) { return 256 * (width / 16) * (width / 16); }
+static inline int decin_splits(int B) { int s = cdiv(B, 16); return s > 16 ? 16 : s; }
+
+int64_t fc_ws_floats(int width, int B) {
+    const int K = bott(width);
+    const int64_t a = (int64_t)FC_KS * B * 64;                 // fc forward partials
+    const int64_t b = (int64_t)decin_splits(B) * 34 * K;       // decoder_input dW slabs
+    const int64_t c = (int64_t)B * 64 + colsum_ws_floats(B, 64);   // dml + its column sums
+    return (a > b ? a : b) + c;
+}
+
+int launch_fc_fwd(int width, int B, const float* flat, const float* wfc, const float* bfc, const float* eps,
+                  const float* pred, float* mu, float* logvar, float* zcat, float* ws, hipStream_t st) {
+    const int K = bott(width);
+    const int smem = FC_IMGS * (K / FC_KS) * 4;
+    hipLaunchKernelGGL(fc_fwd_partial_kernel, dim3(cdiv(B, FC_IMGS), FC_KS), dim3(256), smem, st, flat, wfc, ws, B, K);
+    CVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fc_finish_kernel, dim3(cdiv(B * 32, 256)), dim3(256), 0, st, ws, bfc, eps, pred, mu, logvar, zcat, B);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_decin_fwd(int width, int B, const float* zcat, const float* wd, const float* bd, float* h, hipStream_t st) {
+    const int K = bott(width);
+    hipLaunchKernelGGL(decin_fwd_kernel, dim3(B, K / 1024), dim3(256), 0, st, zcat, wd, bd, h, K);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_decin_bwd(int width, int B, const float* zcat, const float* dh, const float* wd, float* dwd, float* dbd,
+                     float* dzcat, float* ws, hipStream_t st) {
+    const int K = bott(width);
+    hipLaunchKernelGGL(decin_bwd_dz_kernel, dim3(B), dim3(256), 0, st, dh, wd, dzcat, K);
+    CVAE_CHECK_LAUNCH();
+    const int S = decin_splits(B), bps = cdiv(B, S);
+    hipLaunchKernelGGL(decin_bwd_dw_kernel, dim3(K / 256, S), dim3(256), 0, st, zcat, dh, ws, B, K, bps);
+    CVAE_CHECK_LAUNCH();
+    int rc = launch_reduce_slabs(ws, dwd, (int64_t)33 * K, S, (int64_t)34 * K, st);
+    if (rc) return rc;
+    return launch_reduce_slabs(ws + (size_t)33 * K, dbd, K, S, (int64_t)34 * K, st);
+}
+
+int launch_fc_bwd(int width, int B, const float* flat, const float* wfc, const float* dzcat, const float* eps,
+                  const float* logvar, const float* dmu_loss, const float* dlv_loss, float* dwfc, float* dbfc,
+                  float* dflat, float* ws, hipStream_t st) {
+    const int K = bott(width);
+    const int64_t a = (int64_t)FC_KS * B * 64, b = (int64_t)decin_splits(B) * 34 * K;
+    float* dml = ws + (a > b ? a : b);
+    float* csws = dml + (size_t)B * 64;
+    hipLaunchKernelGGL(fc_bwd_prep_kernel, dim3(cdiv(B * 32, 256)), dim3(256), 0, st, dzcat, eps, logvar, dmu_loss, dlv_loss, dml, B);
+    CVAE_CHECK_LAUNCH();
+    int rc = launch_colsum(dml, B, 64, dbfc, csws, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fc_bwd_dflat_kernel, dim3(cdiv(B, 8), K / 256), dim3(256), 0, st, dml, wfc, dflat, B, K);
+    CVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fc_bwd_dw_kernel, dim3(K / 4), dim3(256), 0, st, flat, dml, dwfc, B, K);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,125 @@
+"""The `-train` path of the reference (vae.py:33-66, 154-163) on synthetic data.
+
+Two drivers over the same C-ABI kernels:
+
+  * train(autoencoder, dset, critic_fn)  — the reference loop, line for line (torch.optim.Adam over
+    autoencoder.parameters(), np.random.shuffle per epoch, short tail batch kept, log every log_n).
+  * FusedTrainer                          — the same step without autograd/optimizer objects: direct
+    cvae_forward -> cvae_loss -> cvae_backward -> (RCCL all-reduce of the flat gradient) ->
+    cvae_adam_step, all asynchronous on one stream.  This is what bench.py times.
+
+    python -m critic_vae_amd.train -train --synthetic 1024 --batch 32 --epochs 1
+"""
+import argparse
+import time
+
+import numpy as np
+import torch
+
+from . import params as P
+from . import synth
+from .nets import VariationalAutoencoder
+
+
+def train(autoencoder, dset, critic_fn, device, epochs=P.epochs, batch_size=P.batch_size, lr=P.lr,
+          log_n=None, log=print):
+    """vae.py:33-66.  `dset`: list/array of (1,3,w,w) or (3,w,w) float frames in [0,1];
+    `critic_fn(images) -> (B,1)` stands in for critic.evaluate (vae.py:50)."""
+    dset = np.stack(dset).squeeze()
+    opt = torch.optim.Adam(autoencoder.parameters(), lr=lr)
+    num_samples = dset.shape[0]
+    log_n = log_n if log_n is not None else batch_size * 30
+    history = []
+    for ep in range(epochs):
+        epoch_indices = np.arange(num_samples)
+        np.random.shuffle(epoch_indices)
+        for batch_i in range(0, num_samples, batch_size):
+            batch_indices = epoch_indices[batch_i:batch_i + batch_size]     # tail batch is kept (vae.py:44-46)
+            images = torch.from_numpy(dset[batch_indices]).to(device=device, dtype=torch.float32)
+            preds = critic_fn(images)
+            opt.zero_grad()
+            out = autoencoder(images, preds)
+            losses = autoencoder.vae_loss(out[0], out[1], out[2], out[3])
+            losses["total_loss"].backward()
+            opt.step()
+            if batch_i % log_n == 0:
+                rec = {k: float(v.item()) for k, v in losses.items()}
+                history.append((num_samples * ep + batch_i + 1, rec))
+                log(f"    ep:{ep}, imgs:{num_samples * ep + (batch_i + 1)} {rec}")
+    return autoencoder, history
+
+
+class FusedTrainer:
+    """One training step = forward + loss + backward + all-reduce + Adam on flat buffers."""
+
+    def __init__(self, vae, lr=P.lr, betas=P.adam_betas, eps=P.adam_eps, process_group=None, world_size=1):
+        self.vae = vae
+        self.h = vae.handle
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.world_size, self.pg = world_size, process_group
+        dev = vae.theta.device
+        n = vae.theta.numel()
+        self.grads = torch.zeros(n, device=dev)
+        self.m = torch.zeros(n, device=dev)
+        self.v = torch.zeros(n, device=dev)
+        self.step_count = 0
+        B = vae.max_batch
+        self.mu = torch.empty(B, P.latent_dim, device=dev)
+        self.logvar = torch.empty_like(self.mu)
+        self.recon = torch.empty(B, P.ch, vae.width, vae.width, device=dev)
+        self.d_recon = torch.empty_like(self.recon)
+        self.d_mu = torch.empty_like(self.mu)
+        self.d_logvar = torch.empty_like(self.mu)
+        self.scalars = torch.empty(16, device=dev)
+        self.ws = vae._workspace(B)
+
+    def step(self, x, pred, eps):
+        """x (B,3,w,w), pred (B,1), eps (B,32): contiguous fp32 device tensors."""
+        v, h, B = self.vae, self.h, x.shape[0]
+        theta = v.theta.data
+        h.forward(B, x, pred, eps, theta, v.bn_state, self.mu, self.logvar, self.recon, self.ws, train=True)
+        h.loss(B, x, self.mu, self.logvar, self.recon, self.ws, self.scalars, self.d_recon, self.d_mu, self.d_logvar)
+        h.backward(B, x, pred, eps, theta, self.logvar, self.recon, self.d_recon, self.d_mu, self.d_logvar,
+                   self.ws, self.grads)
+        if self.world_size > 1:
+            torch.distributed.all_reduce(self.grads, group=self.pg)          # one flat RCCL all-reduce (sum)
+        self.step_count += 1
+        v.num_batches_tracked += 1
+        h.adam_step(theta, self.grads, self.m, self.v, self.step_count, self.lr, self.betas[0], self.betas[1],
+                    self.eps, grad_scale=1.0 / self.world_size)
+        return self.scalars
+
+
+def synthetic_dataset(n_frames, width=P.w, seed=1234):
+    x, _, _ = synth.make_batch(seed, 0, n_frames, width)
+    return [x[i:i + 1] for i in range(n_frames)]
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="Critic-VAE -train on synthetic frames (vae.py:154-163)")
+    ap.add_argument("-train", action="store_true")
+    ap.add_argument("--synthetic", type=int, default=1024, help="number of synthetic frames")
+    ap.add_argument("--batch", type=int, default=P.batch_size)
+    ap.add_argument("--epochs", type=int, default=1)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args(argv)
+    if not args.train:
+        ap.error("only -train is implemented (the hot path); see SURVEY.md §8 for scope")
+    if not torch.cuda.is_available():
+        raise SystemExit("critic-vae_amd needs an MI355X: the HIP library has no CPU fallback")
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    device = torch.device("cuda:0")
+    vae = VariationalAutoencoder(max_batch=args.batch, seed=args.seed).to(device)
+    dset = synthetic_dataset(args.synthetic)
+    t0 = time.time()
+    _, hist = train(vae, dset, lambda im: torch.rand(im.shape[0], 1, device=im.device), device,
+                    epochs=args.epochs, batch_size=args.batch, log_n=args.batch * 8)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print(f"{args.epochs * args.synthetic / dt:.1f} images/s over {args.epochs} epoch(s)")
+    return hist
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,154 @@
+/*
+ * cvae.h — C-ABI of libcvae_hip.so: the Critic-VAE training step on MI355X (gfx950).
+ *
+ * The reference (lcicek/Critic-VAE) has no FFI for this path: its "interface" is the set of
+ * PyTorch calls made by vae.py:44-58.  This header is the boundary a maintainer would bind
+ * (ctypes stub in INTEGRATION.md); each entry point names the reference call it replaces.
+ *
+ * Conventions
+ *   - Plain C types only.  Every pointer is a DEVICE pointer unless stated; all tensors fp32.
+ *   - The caller owns every buffer (parameters, gradients, inputs, outputs, workspace); the
+ *     library owns only the opaque handle.  No allocation, no device synchronisation inside.
+ *   - All work is enqueued on the caller's hipStream_t (passed as void*).
+ *   - Return: 0 = OK, <0 = library error (cvae_last_error()), >0 = hipError_t passthrough.
+ *   - Layouts: frames x / recon / d_recon are NCHW (B,3,W,W) exactly as the reference holds
+ *     them (vae_utility.py:337-343); mu/logvar/eps (B,32), pred (B,1) row-major.  Parameters
+ *     and gradients live in ONE flat fp32 buffer in the library's native layout described by
+ *     cvae_param_*(): conv weights [kh*5+kw][Cin][Cout], fc_mu|fc_var fused as [k][64] with k
+ *     in (h,w,c) order, decoder_input as [33][bottleneck] with columns in (h,w,c) order.
+ *     critic-vae_amd/layout.py converts to/from the reference's state_dict layouts.
+ */
+#ifndef CVAE_H
+#define CVAE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cvae_handle_s* cvae_handle;
+
+typedef struct cvae_config {
+    int32_t width;        /* frame width == height: 64 (vae_parameters.py:5); 128 planned      */
+    int32_t max_batch;    /* largest per-call batch the workspace is sized for                 */
+    int32_t reserved0;
+    int32_t reserved1;
+} cvae_config;
+
+enum { CVAE_OK = 0, CVAE_EINVAL = -1, CVAE_EUNSUPPORTED = -2, CVAE_ENOWS = -3 };
+
+/* number of loss scalars written by cvae_loss: [0]=total [1]=recon(MS-SSIM) [2]=KLD(weighted)
+ * [3..7]=ssim level means [8..12]=cs level means [13..15]=reserved                           */
+#define CVAE_N_SCALARS 16
+
+const char* cvae_version(void);
+const char* cvae_last_error(void);
+
+/* lifecycle */
+int  cvae_create(const cvae_config* cfg, cvae_handle* out);
+void cvae_destroy(cvae_handle h);
+
+/* flat parameter / gradient buffer description (replaces nn.Module.parameters(), vae.py:36) */
+int64_t     cvae_param_total(cvae_handle h);                 /* floats incl. alignment padding */
+int32_t     cvae_param_count(cvae_handle h);                 /* number of tensors (30)          */
+const char* cvae_param_name(cvae_handle h, int32_t i);       /* reference state_dict key        */
+int64_t     cvae_param_offset(cvae_handle h, int32_t i);     /* float offset in the flat buffer */
+int64_t     cvae_param_numel(cvae_handle h, int32_t i);
+
+/* workspace (saved activations, gradients of activations, split-K slabs, reduction partials) */
+int64_t cvae_workspace_bytes(cvae_handle h, int32_t batch);
+
+/* BatchNorm running statistics buffer: 2*480 floats [mean(32,64,128,256) | var(...)] */
+int64_t cvae_bn_state_floats(cvae_handle h);
+
+/*
+ * Forward: VariationalAutoencoder.forward (vae_nets.py:14-19) = encoder (:101-111) ->
+ * reparametrize with caller-supplied eps (:48-51) -> decoder (:139-147).
+ * train != 0: BatchNorm uses batch statistics and updates bn_state (momentum 0.1, unbiased var).
+ * Saves what backward needs in ws.
+ */
+int cvae_forward(cvae_handle h, int32_t batch, const float* x, const float* pred, const float* eps,
+                 const float* params, float* bn_state, float* mu, float* logvar, float* recon,
+                 void* ws, int32_t train, void* stream);
+
+/*
+ * Decoder.forward alone (vae_nets.py:139-147) from zcat = cat((z, pred), 1), shape (B,33).
+ * zcat == NULL reuses the one cvae_forward left in ws.  cvae_forward with recon == NULL stops
+ * after the encoder + reparametrize (VariationalEncoder.forward, vae_nets.py:101-111).
+ */
+int cvae_decode(cvae_handle h, int32_t batch, const float* zcat, const float* params, float* recon,
+                void* ws, void* stream);
+
+/*
+ * Loss: VariationalAutoencoder.vae_loss (vae_nets.py:53-62) = MSSIM.forward (:217-247) + KLD.
+ * Writes CVAE_N_SCALARS floats to `scalars` and the gradients of total_loss w.r.t. recon, mu,
+ * logvar (d_* may be NULL to skip the backward half).
+ */
+int cvae_loss(cvae_handle h, int32_t batch, const float* x, const float* mu, const float* logvar,
+              const float* recon, void* ws, float* scalars, float* d_recon, float* d_mu,
+              float* d_logvar, void* stream);
+
+/*
+ * Backward: loss.backward() (vae.py:57) for everything cvae_forward computed, given the loss
+ * gradients w.r.t. its outputs (and logvar/recon as returned by cvae_forward).  Overwrites the
+ * flat gradient buffer `grads` (same layout as `params`).
+ */
+int cvae_backward(cvae_handle h, int32_t batch, const float* x, const float* pred, const float* eps,
+                  const float* params, const float* logvar, const float* recon, const float* d_recon,
+                  const float* d_mu, const float* d_logvar, void* ws, float* grads, void* stream);
+
+/*
+ * Optimizer: torch.optim.Adam.step() with defaults (vae.py:36,58) on the flat buffers.
+ * grad_scale multiplies the gradient first (1/world_size after a summing all-reduce).
+ */
+int cvae_adam_step(cvae_handle h, float* params, const float* grads, float* exp_avg,
+                   float* exp_avg_sq, int64_t n, int32_t step, float lr, float beta1, float beta2,
+                   float eps, float grad_scale, void* stream);
+
+/* float offset of a named saved tensor in the workspace ("y0".."y3", "a0".."a3", "o0".."o3",
+ * "zcat", "h", "d_*" ...) for tests; -1 if unknown */
+int64_t cvae_ws_offset(cvae_handle h, int32_t batch, const char* name);
+
+/* ---------------------------------------------------------------------------------------- *
+ * Per-op entry points (unit tests and the roofline probe in bench.py).  `layer`: 0..3 =
+ * encoder conv blocks E1..E4 (vae_nets.py:69,74,79,84), 4..8 = decoder convs D0..D4
+ * (vae_nets.py:117,121,125,129,133).  Activations are NHWC except x/recon (NCHW); decoder
+ * layers 5..8 read the stored (pre-Upsample) tensor.  `scratch` needs cvae_op_scratch_floats().
+ * ---------------------------------------------------------------------------------------- */
+int64_t cvae_op_scratch_floats(cvae_handle h, int32_t batch);
+int64_t cvae_op_bn_partial_floats(cvae_handle h, int32_t layer, int32_t batch);
+int64_t cvae_op_msssim_ws_floats(cvae_handle h, int32_t batch);
+
+/* nn.Conv2d forward (+bias; encoder: raw output + BatchNorm partials; decoder: +ReLU, D4: +Tanh) */
+int cvae_op_conv_fwd(cvae_handle h, int32_t layer, int32_t batch, const float* in, const float* w,
+                     const float* bias, float* out, float* bn_partials, void* stream);
+/* input gradient, layers 1..7; decoder layers 5..7 also fold Upsample backward (2x2 sum) and the
+ * ReLU mask of the producing layer's output `mask_src` */
+int cvae_op_conv_dgrad(cvae_handle h, int32_t layer, int32_t batch, const float* dout,
+                       const float* w, const float* mask_src, float* din, void* stream);
+/* weight (+ optional bias) gradient, layers 0..7 */
+int cvae_op_conv_wgrad(cvae_handle h, int32_t layer, int32_t batch, const float* in,
+                       const float* dout, float* dw, float* dbias, void* scratch, void* stream);
+/* D4 backward, fused: Tanh' -> dout (B,3,W,W), d_o3 (ReLU-masked, NHWC), dW4, db4 */
+int cvae_op_d4_bwd(cvae_handle h, int32_t batch, const float* o3, const float* d_recon,
+                   const float* recon, const float* w, float* dout, float* d_o3, float* dw,
+                   float* db, void* scratch, void* stream);
+/* BatchNorm2d(train) -> MaxPool2d(2) -> ReLU/Tanh of encoder block `layer` (0..3) */
+int cvae_op_bn_pool_act_fwd(cvae_handle h, int32_t layer, int32_t batch, const float* y,
+                            const float* bn_partials, const float* gamma, const float* beta,
+                            float* run_mean, float* run_var, float* coef, float* a, int32_t train,
+                            void* stream);
+int cvae_op_bn_pool_act_bwd(cvae_handle h, int32_t layer, int32_t batch, const float* y,
+                            const float* a, const float* da, const float* coef, const float* gamma,
+                            float* dy, float* dgamma, float* dbeta, float* dbias, void* scratch,
+                            void* stream);
+/* MSSIM.forward (vae_nets.py:217-247) on NCHW planes, optional gradient w.r.t. img1 */
+int cvae_op_msssim(cvae_handle h, int32_t batch, const float* img1, const float* img2, void* ws,
+                   float* scalars, float* d_img1, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVAE_H */

@@ -1,0 +1,236 @@
+"""GPU parity: every HIP kernel, through the C-ABI, against the oracle's single-op references.
+
+Tolerance: north_star asks 1e-4 fp32 on outputs; gradients of tensors whose magnitude is far
+from 1 are additionally checked relative to the tensor's max."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from critic_vae_amd import lib as cvlib
+from critic_vae_amd import synth
+from oracle import cvae_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+# (cin, cout, h_out, up)  — vae_nets.py:69-84, 117-133
+LAYERS = [(3, 32, 64, 0), (32, 64, 32, 0), (64, 128, 16, 0), (128, 256, 8, 0),
+          (256, 128, 4, 0), (128, 64, 8, 1), (64, 32, 16, 1), (32, 32, 32, 1), (32, 3, 64, 1)]
+
+
+@pytest.fixture(scope="module")
+def H():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return cvlib.Handle(64, 64)
+
+
+def dev(t):
+    return t.contiguous().cuda()
+
+
+def nhwc(t):       # NCHW cpu -> NHWC gpu
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def to_nchw(t, B, h, c):
+    return t.view(B, h, h, c).permute(0, 3, 1, 2).cpu()
+
+
+def wnat(w):       # OIHW -> [25][I][O]
+    return w.permute(2, 3, 1, 0).reshape(25, w.shape[1], w.shape[0]).contiguous().cuda()
+
+
+def wref(n, cin, cout):
+    return n.view(5, 5, cin, cout).permute(3, 2, 0, 1).cpu()
+
+
+def rnd(name, shape, lo=-1.0, hi=1.0, seed=7):
+    return torch.from_numpy(synth.uniform(seed, name, shape, lo, hi))
+
+
+def check(got, want, what, tol=TOL, rel=False):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = (got - want).abs().max().item()
+    scale = want.abs().max().item() if rel else 1.0
+    assert np.isfinite(err) and err <= tol * max(scale, 1e-30), f"{what}: max|err|={err:.3e} scale={scale:.3e}"
+
+
+@pytest.mark.parametrize("layer", range(9))
+@pytest.mark.parametrize("B", [3, 8])
+def test_conv_fwd(H, layer, B):
+    cin, cout, h, up = LAYERS[layer]
+    hs = h // 2 if up else h
+    x = rnd(f"x{layer}", (B, cin, hs, hs))
+    w = rnd(f"w{layer}", (cout, cin, 5, 5), -0.1, 0.1)
+    b = rnd(f"b{layer}", (cout,))
+    ref = orc.conv5x5(x, w, b, upsample_input=bool(up))
+    if 4 <= layer <= 7:
+        ref = torch.relu(ref)
+    if layer == 8:
+        ref = torch.tanh(ref)
+    xin = dev(x) if layer == 0 else nhwc(x)
+    out = torch.full((B * h * h * cout,), float("nan"), device="cuda")
+    part = torch.zeros(max(H.op_bn_partial_floats(min(layer, 3), B), 1), device="cuda") if layer < 4 else None
+    H.op_conv_fwd(layer, B, xin, wnat(w), dev(b), out, part)
+    torch.cuda.synchronize()
+    got = out.view(B, cout, h, h).cpu() if layer == 8 else to_nchw(out, B, h, cout)
+    check(got, ref, f"conv_fwd L{layer}")
+
+
+@pytest.mark.parametrize("layer", range(4))
+@pytest.mark.parametrize("B,ties", [(3, False), (8, True)])
+def test_bn_pool_act_fwd_bwd(H, layer, B, ties):
+    cin, C, h, _ = LAYERS[layer]
+    act = "tanh" if layer == 3 else "relu"
+    x = rnd(f"bx{layer}", (B, cin, h, h))
+    w = rnd(f"bw{layer}", (C, cin, 5, 5), -0.1, 0.1)
+    b = rnd(f"bb{layer}", (C,))
+    if ties:       # y = x[co % cin] exactly, x on a coarse grid -> many EXACT ties inside pooling windows
+        x = torch.round(x * 2) / 2
+        w = torch.zeros_like(w)
+        w[torch.arange(C), torch.arange(C) % cin, 2, 2] = 1.0
+        b = torch.zeros_like(b)
+    gamma = rnd(f"g{layer}", (C,), 0.5, 1.5)
+    beta = rnd(f"be{layer}", (C,), -0.5, 0.5)
+    if ties:
+        gamma[::3] *= -1            # negative scale flips which element is the maximum
+    # conv on the GPU provides y and the BatchNorm partials
+    y = torch.empty(B * h * h * C, device="cuda")
+    part = torch.zeros(H.op_bn_partial_floats(layer, B), device="cuda")
+    H.op_conv_fwd(layer, B, dev(x) if layer == 0 else nhwc(x), wnat(w), dev(b), y, part)
+    y_ref = to_nchw(y, B, h, C).clone().requires_grad_(True)
+    g_ref, b_ref = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    a_ref, mean, var = orc.bn_pool_act(y_ref, g_ref, b_ref, act)
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    coef = torch.empty(C * 4, device="cuda")
+    a = torch.empty(B * (h // 2) ** 2 * C, device="cuda")
+    H.op_bn_pool_act_fwd(layer, B, y, part, dev(gamma), dev(beta), rm, rv, coef, a, True)
+    torch.cuda.synchronize()
+    check(coef.view(C, 4)[:, 2], mean, "bn mean", 1e-5)
+    check(1.0 / coef.view(C, 4)[:, 3] ** 2 - 1e-5, var, "bn var", 1e-5, rel=True)
+    check(to_nchw(a, B, h // 2, C), a_ref, f"bn_pool_act fwd L{layer}")
+    n = B * h * h
+    check(rm, 0.1 * mean, "running_mean", 1e-5)
+    check(rv, 0.9 + 0.1 * var * n / (n - 1), "running_var", 1e-5)
+    # backward
+    da = rnd(f"da{layer}", (B, C, h // 2, h // 2))
+    a_ref.backward(da)
+    dy = torch.empty_like(y)
+    dg, db, dbias = (torch.empty(C, device="cuda") for _ in range(3))
+    sc = torch.empty(H.op_scratch_floats(B), device="cuda")
+    H.op_bn_pool_act_bwd(layer, B, y, a, nhwc(da), coef, dev(gamma), dy, dg, db, dbias, sc)
+    torch.cuda.synchronize()
+    check(to_nchw(dy, B, h, C), y_ref.grad, f"bn_pool_act bwd dy L{layer}", rel=True)
+    check(dg, g_ref.grad, "dgamma", rel=True)
+    check(db, b_ref.grad, "dbeta", rel=True)
+    check(dbias, y_ref.grad.sum(dim=(0, 2, 3)), "dbias (round-off level)", 1e-4)
+
+
+@pytest.mark.parametrize("layer", range(1, 8))
+@pytest.mark.parametrize("B", [3, 8])
+def test_conv_dgrad(H, layer, B):
+    cin, cout, h, up = LAYERS[layer]
+    hs = h // 2 if up else h
+    w = rnd(f"w{layer}", (cout, cin, 5, 5), -0.1, 0.1)
+    dout = rnd(f"do{layer}", (B, cout, h, h))
+    pre = rnd(f"pre{layer}", (B, cin, hs, hs)).requires_grad_(True)
+    src = torch.relu(pre) if up else pre
+    orc.conv5x5(src, w, None, upsample_input=bool(up)).backward(dout)
+    din = torch.full((B * hs * hs * cin,), float("nan"), device="cuda")
+    H.op_conv_dgrad(layer, B, nhwc(dout), wnat(w), nhwc(src.detach()) if up else None, din)
+    torch.cuda.synchronize()
+    check(to_nchw(din, B, hs, cin), pre.grad, f"conv_dgrad L{layer}", rel=True)
+
+
+@pytest.mark.parametrize("layer", range(8))
+@pytest.mark.parametrize("B", [3, 8])
+def test_conv_wgrad(H, layer, B):
+    cin, cout, h, up = LAYERS[layer]
+    hs = h // 2 if up else h
+    x = rnd(f"x{layer}", (B, cin, hs, hs))
+    w = rnd(f"w{layer}", (cout, cin, 5, 5), -0.1, 0.1).requires_grad_(True)
+    b = torch.zeros(cout, requires_grad=True)
+    dout = rnd(f"do{layer}", (B, cout, h, h))
+    orc.conv5x5(x, w, b, upsample_input=bool(up)).backward(dout)
+    dw = torch.full((25 * cin * cout,), float("nan"), device="cuda")
+    dbias = torch.empty(cout, device="cuda") if layer >= 4 else None
+    sc = torch.empty(H.op_scratch_floats(B), device="cuda")
+    H.op_conv_wgrad(layer, B, dev(x) if layer == 0 else nhwc(x), nhwc(dout), dw, dbias, sc)
+    torch.cuda.synchronize()
+    check(wref(dw, cin, cout), w.grad, f"conv_wgrad L{layer}", rel=True)
+    if dbias is not None:
+        check(dbias, b.grad, f"conv dbias L{layer}", rel=True)
+
+
+@pytest.mark.parametrize("B", [2, 5])
+def test_d4_bwd(H, B):
+    w = rnd("w8", (3, 32, 5, 5), -0.1, 0.1).requires_grad_(True)
+    b = rnd("b8", (3,)).requires_grad_(True)
+    pre = rnd("pre8", (B, 32, 32, 32)).requires_grad_(True)
+    o3 = torch.relu(pre)
+    recon = torch.tanh(orc.conv5x5(o3, w, b, upsample_input=True))
+    d_recon = rnd("dr8", (B, 3, 64, 64))
+    recon.backward(d_recon)
+    dout = torch.empty(B * 3 * 64 * 64, device="cuda")
+    d_o3 = torch.full((B * 32 * 32 * 32,), float("nan"), device="cuda")
+    dw = torch.empty(2400, device="cuda")
+    db = torch.empty(3, device="cuda")
+    sc = torch.empty(H.op_scratch_floats(B), device="cuda")
+    H.op_d4_bwd(B, nhwc(o3.detach()), dev(d_recon), dev(recon.detach()), wnat(w.detach()), dout, d_o3, dw, db, sc)
+    torch.cuda.synchronize()
+    check(dout.view(B, 3, 64, 64), d_recon * (1 - recon.detach() ** 2), "d4 tanh bwd", 1e-5)
+    check(to_nchw(d_o3, B, 32, 32), pre.grad, "d4 dgrad", rel=True)
+    check(wref(dw, 32, 3), w.grad, "d4 wgrad", rel=True)
+    check(db, b.grad, "d4 dbias", rel=True)
+
+
+def _ms_inputs(tag):
+    b = torch.from_numpy(synth.uniform(5, f"ms/{tag}/b", (4, 3, 64, 64)))
+    if tag == "nan":
+        a = 0.5 - b + 0.01 * torch.from_numpy(synth.uniform(5, f"ms/{tag}/a", (4, 3, 64, 64)))
+    else:
+        a = torch.from_numpy(synth.uniform(5, f"ms/{tag}/a", (4, 3, 64, 64), -1.0 if tag == "neg" else 0.0, 1.0))
+    return a.clone(), b
+
+
+@pytest.mark.parametrize("tag", ["pos", "neg", "nan"])
+def test_msssim(H, golden_dir, tag):
+    import os
+    fx = np.load(os.path.join(golden_dir, "msssim_ops.npz"))
+    a, b = _ms_inputs(tag)
+    a_ref = a.clone().requires_grad_(True)
+    loss, sims, css = orc.msssim(a_ref, b)
+    ws = torch.empty(H.op_msssim_ws_floats(4), device="cuda")
+    scal = torch.empty(16, device="cuda")
+    d_a = torch.empty(4 * 3 * 64 * 64, device="cuda")
+    H.op_msssim(4, dev(a), dev(b), ws, scal, d_a)
+    torch.cuda.synchronize()
+    s = scal.cpu()
+    check(s[3:8], sims, "ssim levels", 2e-5)
+    check(s[8:13], css, "cs levels", 2e-5)
+    check(s[3:8], torch.from_numpy(fx[f"{tag}/ssim"]), "ssim levels vs reference fixture", 2e-5)
+    check(s[8:13], torch.from_numpy(fx[f"{tag}/cs"]), "cs levels vs reference fixture", 2e-5)
+    if tag == "nan":
+        assert torch.isnan(s[1]) and torch.isnan(loss) and np.isnan(fx["nan/loss"])    # NaN propagates, no clamp
+        return
+    check(s[1], loss, "msssim loss", 2e-5)
+    assert abs(s[1].item() - float(fx[f"{tag}/loss"])) < 2e-5
+    assert s[2].item() == 0.0 and abs(s[0].item() - s[1].item()) < 1e-7
+    loss.backward()
+    check(d_a.view(4, 3, 64, 64), a_ref.grad, "msssim grad", rel=True)
+
+
+def test_adam_matches_torch(H):
+    n = 4096
+    p0, g = rnd("ap", (n,)), rnd("ag", (n,), -1e-2, 1e-2)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=5e-5)
+    p, m, v = dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 6):
+        gs = g * step
+        p_ref.grad = gs.clone()
+        opt.step()
+        H.adam_step(p, dev(gs * 2.0), m, v, step, 5e-5, grad_scale=0.5)
+    torch.cuda.synchronize()
+    check(p, p_ref, "adam params", 1e-7)

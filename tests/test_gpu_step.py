@@ -1,0 +1,186 @@
+"""GPU parity of the whole training step (forward + vae_loss + backward [+ Adam]) through the
+reference-shaped Python API, against (a) the committed reference-generated fixtures and (b) the
+oracle run here on the same seeded inputs.  Tolerance 1e-4 (BASELINE.json north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from critic_vae_amd import synth
+from critic_vae_amd.nets import VariationalAutoencoder
+from critic_vae_amd.train import FusedTrainer, train
+from oracle import cvae_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _inputs(dseed, step, B, first=0):
+    x, pred, eps = synth.make_batch(dseed, step, B, first_index=first)
+    return torch.from_numpy(x), torch.from_numpy(pred), torch.from_numpy(eps)
+
+
+def _model(B, wseed=0):
+    assert torch.cuda.is_available()
+    vae = VariationalAutoencoder(max_batch=B, seed=wseed).cuda()
+    vae.load_reference_params(synth.make_params(wseed))
+    return vae
+
+
+def _step(vae, x, pred, eps):
+    vae.theta.grad = None
+    out = vae(x.cuda(), pred.cuda(), eps=eps.cuda())
+    losses = vae.vae_loss(*out)
+    losses["total_loss"].backward()
+    torch.cuda.synchronize()
+    return out, losses
+
+
+def _grad_check(name, g, want, tol=TOL):
+    g, want = g.detach().cpu().double(), want.detach().cpu().double()
+    scale = max(want.abs().max().item(), 1e-30)
+    err = (g - want).abs().max().item()
+    # absolute 1e-4 always; relative-to-max 1e-4 too, except the pre-BatchNorm conv biases whose true
+    # gradient is zero and whose reference value is pure round-off
+    assert err <= tol, f"{name}: abs err {err:.3e}"
+    if not (name.startswith("encoder.model.") and name.endswith(".bias") and int(name.split(".")[2]) % 4 == 0):
+        assert err <= tol * scale, f"{name}: err {err:.3e} vs max|g| {scale:.3e}"
+
+
+@pytest.mark.parametrize("tag", ["b2", "b32"])
+def test_step_matches_reference_fixture_and_oracle(golden_dir, tag):
+    fx = np.load(os.path.join(golden_dir, f"step_{tag}.npz"))
+    B = int(fx["batch"])
+    x, pred, eps = _inputs(int(fx["dseed"]), int(fx["step"]), B)
+    vae = _model(B, int(fx["wseed"]))
+    (_, mu, logvar, recon), losses = _step(vae, x, pred, eps)
+    # --- against the reference-generated fixture ---
+    assert np.abs(mu.cpu().numpy() - fx["mu"]).max() < TOL
+    assert np.abs(logvar.cpu().numpy() - fx["logvar"]).max() < TOL
+    assert np.abs(recon.cpu().numpy().reshape(-1)[::16] - fx["recon_sample"]).max() < TOL
+    s = vae.last_scalars.cpu().numpy()
+    assert np.abs(s[:3] - fx["losses"]).max() < TOL
+    assert np.abs(s[3:8] - fx["ssim_levels"]).max() < TOL and np.abs(s[8:13] - fx["cs_levels"]).max() < TOL
+    assert abs(losses["recon_loss"].item() - fx["losses"][1]) < TOL and abs(losses["KLD"].item() - fx["losses"][2]) < TOL
+    ref_g = vae.reference_grads()
+    for name, g in ref_g.items():
+        gs = g.cpu().numpy().reshape(-1)
+        assert np.abs(gs[fx["grad_idx/" + name]] - fx["grad_val/" + name]).max() <= TOL, name
+    sd = vae.encoder.state_dict()
+    for bi in (1, 5, 9, 13):
+        assert np.abs(sd[f"model.{bi}.running_mean"].cpu().numpy() - fx[f"bn_running_mean/{bi}"]).max() < 1e-5
+        assert np.abs(sd[f"model.{bi}.running_var"].cpu().numpy() - fx[f"bn_running_var/{bi}"]).max() < 1e-5
+    # --- against the oracle, every element of every gradient ---
+    p = orc.to_torch(synth.make_params(int(fx["wseed"])), requires_grad=True)
+    o = orc.train_step(p, x, pred, eps, bn_state=orc.new_bn_state(p))
+    assert (recon.cpu() - o["recon"]).abs().max().item() < TOL
+    for name, g in ref_g.items():
+        _grad_check(name, g, p[name].grad)
+
+
+def test_intermediates_against_oracle_taps():
+    """Every saved activation and activation-gradient of the step vs the oracle's taps (B=4)."""
+    B = 4
+    x, pred, eps = _inputs(1234, 3, B)
+    vae = _model(B)
+    _step(vae, x, pred, eps)
+    p = orc.to_torch(synth.make_params(0), requires_grad=True)
+    taps = {}
+    orc.train_step(p, x, pred, eps, bn_state=orc.new_bn_state(p), taps=taps)
+    ws, h = vae._workspace(B), vae.handle
+    enc = [(32, 64), (64, 32), (128, 16), (256, 8)]
+    dec = [(128, 4), (64, 8), (32, 16), (32, 32)]
+
+    def view(name, c, s):
+        return h.ws_view(ws, B, name, B * s * s * c).view(B, s, s, c).permute(0, 3, 1, 2).cpu()
+
+    for l, (c, s) in enumerate(enc):
+        assert (view(f"y{l}", c, s) - taps[f"enc_y{l}"]).abs().max() < TOL, f"y{l}"
+        assert (view(f"a{l}", c, s // 2) - taps[f"enc_a{l}"]).abs().max() < TOL, f"a{l}"
+    assert (view("h", 256, 4) - taps["dec_h"]).abs().max() < TOL
+    for i, (c, s) in enumerate(dec):
+        assert (view(f"o{i}", c, s) - taps[f"dec_o{i}"]).abs().max() < TOL, f"o{i}"
+    for l, (c, s) in enumerate(enc):
+        g = taps[f"enc_y{l}"].grad
+        assert (view(f"d_y{l}", c, s) - g).abs().max() <= TOL * max(1.0, 0) + 1e-4 * g.abs().max(), f"d_y{l}"
+
+
+def test_bitwise_reproducible_and_full_size():
+    """BASELINE config 2 size (B=256): finite, and two runs are bit-identical (fixed-order reductions)."""
+    B = 256
+    x, pred, eps = _inputs(1234, 0, B)
+    vae = _model(B)
+    (_, mu, _, recon), losses = _step(vae, x, pred, eps)
+    g1, l1 = vae.theta.grad.clone(), vae.last_scalars.clone()
+    assert torch.isfinite(l1[:13]).all() and torch.isfinite(g1).all()
+    assert recon.abs().max().item() <= 1.0 and mu.shape == (B, 32)
+    _step(vae, x, pred, eps)
+    assert torch.equal(g1, vae.theta.grad) and torch.equal(l1, vae.last_scalars)
+    # linearity of backward in the loss gradient: 2*loss -> 2*grads
+    vae.theta.grad = None
+    out = vae(x.cuda(), pred.cuda(), eps=eps.cuda())
+    (2.0 * vae.vae_loss(*out)["total_loss"]).backward()
+    torch.cuda.synchronize()
+    assert (vae.theta.grad - 2 * g1).abs().max().item() <= 2e-6 * g1.abs().max().item() + 1e-9
+
+
+def test_trajectory_config1_fused_trainer(golden_dir):
+    """BASELINE config 1 on the GPU path: 32 Adam steps, B=32, against the reference trajectory."""
+    fx = np.load(os.path.join(golden_dir, "trajectory_b32.npz"))
+    B = int(fx["batch"])
+    vae = _model(B, int(fx["wseed"]))
+    tr = FusedTrainer(vae)
+    got = []
+    for s in range(int(fx["n_frames"]) // B):
+        x, pred, eps = _inputs(int(fx["dseed"]), s, B)
+        got.append(tr.step(x.cuda(), pred.cuda(), eps.cuda())[:3].cpu().numpy().copy())
+    got = np.array(got)
+    assert np.isfinite(got).all()
+    assert np.abs(got[:2] - fx["traj"][:2]).max() < TOL                 # before Adam noise can amplify
+    assert np.abs(got - fx["traj"]).max() < 5e-3, np.abs(got - fx["traj"]).max()
+    assert got[-1, 0] < 0.5 * got[0, 0]                                 # it trains
+
+
+def test_reference_loop_is_a_drop_in():
+    """vae.py:33-66 verbatim (torch.optim.Adam over .parameters(), tail batch kept) == fused trainer."""
+    B, n = 32, 80                       # 80 frames -> batches of 32, 32, 16 (short tail)
+    frames, _, _ = synth.make_batch(1234, 0, n)
+    preds_all = torch.from_numpy(synth.uniform(3, "critic", (n, 1)))
+    vae_a, vae_b = _model(B), _model(B)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    order = []
+
+    def critic(images):                 # deterministic stand-in for critic.evaluate (vae.py:50)
+        idx = [int(np.argmin(np.abs(frames.reshape(n, -1)[:, :8] - im.reshape(-1)[:8].cpu().numpy()).sum(1))) for im in images]
+        order.append(idx)
+        return preds_all[idx].cuda()
+
+    _, hist = train(vae_a, [f[None] for f in frames], critic, torch.device("cuda"), epochs=1, batch_size=B, log_n=B)
+    assert len(order) == 3 and len(order[-1]) == 16
+    # replay the same batches / noise through the fused trainer
+    torch.manual_seed(0)
+    tr = FusedTrainer(vae_b)
+    for idx in order:
+        xb = torch.from_numpy(frames[idx]).cuda()
+        eps = torch.randn(len(idx), 32, device="cuda")
+        tr.step(xb, preds_all[idx].cuda(), eps)
+    torch.cuda.synchronize()
+    assert (vae_a.theta - vae_b.theta).abs().max().item() < 2e-6
+    assert all(np.isfinite(list(r.values())).all() for _, r in hist)
+
+
+def test_state_dict_round_trip_reference_layout():
+    vae = _model(4)
+    ref = synth.make_params(0)
+    enc, dec = vae.encoder.state_dict(), vae.decoder.state_dict()
+    for k, v in ref.items():
+        part, key = k.split(".", 1)
+        got = (enc if part == "encoder" else dec)[key].cpu().numpy()
+        assert got.shape == v.shape and np.array_equal(got, v), k
+    assert enc["model.1.num_batches_tracked"].item() == 0
+    vae2 = VariationalAutoencoder(max_batch=4, seed=5).cuda()
+    vae2.encoder.load_state_dict(enc)
+    vae2.decoder.load_state_dict(dec)
+    assert torch.equal(vae2.theta, vae.theta)

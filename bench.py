@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — Critic-VAE train-step images/sec on synthetic 64x64x3 frames (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = forward + vae_loss + backward + (one RCCL all-reduce of the flat gradient when N>1) +
+Adam, through the C-ABI (critic-vae_amd FusedTrainer), inputs resident in HBM.  Workload =
+BASELINE.json configs[1]: fp32, per-GPU batch 256 (weak scaling: global batch 256*N).
+Rank 0 prints ONE JSON line.  At N=1 it also (a) times the dominant kernel with HIP events on
+the stream it runs on (`roofline`) and (b) times the oracle on the host cores (`cpu_baseline`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FLOP_PER_IMG = 1.43762e9          # fwd + dgrad + wgrad of 9 convs + 3 linears @64x64
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, matrix fp32
+LAYERS = [(3, 32, 64, 0), (32, 64, 32, 0), (64, 128, 16, 0), (128, 256, 8, 0),
+          (256, 128, 4, 0), (128, 64, 8, 1), (64, 32, 16, 1), (32, 32, 32, 1), (32, 3, 64, 1)]
+
+
+def conv_flops(layer, B):
+    cin, cout, h, _ = LAYERS[layer]
+    return 2.0 * 25 * cin * cout * h * h * B
+
+
+def time_op(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def kernel_probe(vae, B):
+    """HIP-event timing of every single-kernel conv op on the stream the library launches on
+    (torch's current stream).  Returns {name: (seconds, flops)}."""
+    H = vae.handle
+    dev = vae.theta.device
+    out = {}
+    for layer in range(1, 8):
+        cin, cout, h, up = LAYERS[layer]
+        hs = h // 2 if up else h
+        x = torch.rand(B * hs * hs * cin, device=dev)
+        w = torch.rand(25 * cin * cout, device=dev) * 0.01
+        b = torch.zeros(cout, device=dev)
+        y = torch.empty(B * h * h * cout, device=dev)
+        part = torch.empty(max(H.op_bn_partial_floats(min(layer, 3), B), 1), device=dev)
+        out[f"conv_fwd_L{layer}"] = (time_op(lambda: H.op_conv_fwd(layer, B, x, w, b, y, part if layer < 4 else None)),
+                                     conv_flops(layer, B))
+        dy = torch.rand(B * h * h * cout, device=dev)
+        dx = torch.empty(B * hs * hs * cin, device=dev)
+        out[f"conv_dgrad_L{layer}"] = (time_op(lambda: H.op_conv_dgrad(layer, B, dy, w, x if up else None, dx)),
+                                       conv_flops(layer, B))
+        del x, w, y, dy, dx
+    return out
+
+
+def cpu_baseline(B, steps=5):
+    """The oracle's training step (same ATen CPU kernels as the reference, equality pinned by
+    tests/golden) timed on this host: bounded sample of the same workload."""
+    from critic_vae_amd import synth
+    from oracle import cvae_oracle as orc
+    threads = min(len(os.sched_getaffinity(0)), 16)     # the 1-GPU box's CPU share is 16 cores
+    torch.set_num_threads(threads)
+    p = orc.to_torch(synth.make_params(0), requires_grad=True)
+    bn = orc.new_bn_state(p)
+    st = {}
+    xs = torch.rand(B, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+    pr = torch.rand(B, 1, generator=torch.Generator().manual_seed(2))
+    ep = torch.randn(B, 32, generator=torch.Generator().manual_seed(3))
+
+    def one():
+        orc.zero_grad(p)
+        orc.train_step(p, xs, pr, ep, bn_state=bn)
+        orc.adam_step(p, st)
+
+    one()
+    t0 = time.time()
+    for _ in range(steps):
+        one()
+    dt = time.time() - t0
+    return {"value": round(B * steps / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{steps} oracle train steps (fwd+loss+bwd+Adam) at batch {B}, fp32, "
+                                      f"after 1 warm-up; {dt:.1f}s of CPU work"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE.json configs[1])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true")
+    args = ap.parse_args()
+
+    from critic_vae_amd import dp
+    from critic_vae_amd.nets import VariationalAutoencoder
+    from critic_vae_amd.train import FusedTrainer
+
+    world, rank, local = dp.init()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs MI355X GPUs (the HIP library has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B = args.batch
+
+    vae = VariationalAutoencoder(max_batch=B, seed=0).to(dev)
+    tr = FusedTrainer(vae, world_size=world)
+    # synthetic inputs, resident in HBM before the timed region; each rank its own shard
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    pool = [(torch.rand(B, 3, 64, 64, device=dev, generator=gen), torch.rand(B, 1, device=dev, generator=gen),
+             torch.randn(B, 32, device=dev, generator=gen)) for _ in range(4)]
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    note(f"model ready, batch {B}/GPU, world {world}")
+    for i in range(args.warmup):
+        tr.step(*pool[i % len(pool)])
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        scal = tr.step(*pool[i % len(pool)])
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = dp.max_over_ranks(time.perf_counter() - t0, dev)
+    loss = float(scal[0].item())
+    note(f"timed {args.steps} steps in {dt:.3f}s, loss {loss}")
+
+    res = {
+        "metric": "VAE train-step images/sec on 64x64x3 frames",
+        "value": round(world * B * args.steps / dt, 1), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: fp32 train step (fwd+MS-SSIM/KLD loss+bwd+Adam), "
+                               f"batch {B}/GPU, 64x64x3 frames + critic scalars", "global_batch": world * B,
+                   "frame": "64x64x3", "parallelism": f"dp{world}", "optimizer": "fused flat Adam",
+                   "final_loss": loss, "loss_finite": bool(loss == loss and abs(loss) != float("inf"))},
+    }
+    if rank == 0 and world == 1:
+        tflops = B * args.steps / dt * FLOP_PER_IMG / 1e12
+        res["config"]["whole_step_algorithmic_TFLOPs"] = round(tflops, 2)
+        if not args.no_probe:
+            probe = kernel_probe(vae, B)
+            note("kernel probe done")
+            name = max(probe, key=lambda k: probe[k][0])
+            sec, fl = probe[name]
+            res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(fl / sec / 1e12, 2),
+                               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                               "avg_launch_us": round(sec * 1e6, 2),
+                               "all_kernels_TFLOPs": {k: round(f / s / 1e12, 1) for k, (s, f) in probe.items()}}
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(B)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

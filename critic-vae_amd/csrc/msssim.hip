@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void msssim_finalize_kernel(MsFinArgs a) {
         float out = 1.0f;
         for (int l = 0; l < 4; ++l) out *= powf((float)cs[l], wts[l]) * p2;     // vae_nets.py:243-246
         const float recon = 1.0f - out;
-        const float kld = (float)(-0.5 * k / (double)a.B) * kw;
+        const float kld = a.B > 0 ? (float)(-0.5 * k / (double)a.B) * kw : 0.0f;
         a.scalars[0] = recon + kld; a.scalars[1] = recon; a.scalars[2] = kld;
         for (int l = 0; l < 5; ++l) { a.scalars[3 + l] = (float)ssim[l]; a.scalars[8 + l] = (float)cs[l]; }
         a.scalars[13] = a.scalars[14] = a.scalars[15] = 0.f;

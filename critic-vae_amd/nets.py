@@ -50,7 +50,7 @@ class _ForwardFn(torch.autograd.Function):
         d_mu = torch.zeros_like(logvar) if d_mu is None else d_mu.contiguous()
         d_logvar = torch.zeros_like(logvar) if d_logvar is None else d_logvar.contiguous()
         d_recon = torch.zeros_like(recon) if d_recon is None else d_recon.contiguous()
-        grads = torch.empty_like(theta)
+        grads = torch.zeros_like(theta)          # alignment padding between tensors must stay 0
         vae.handle.backward(B, x, pred, eps, theta, logvar, recon, d_recon, d_mu, d_logvar, vae._workspace(B), grads)
         return None, None, None, None, grads
 

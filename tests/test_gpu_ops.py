@@ -124,7 +124,10 @@ def test_bn_pool_act_fwd_bwd(H, layer, B, ties):
     check(to_nchw(dy, B, h, C), y_ref.grad, f"bn_pool_act bwd dy L{layer}", rel=True)
     check(dg, g_ref.grad, "dgamma", rel=True)
     check(db, b_ref.grad, "dbeta", rel=True)
-    check(dbias, y_ref.grad.sum(dim=(0, 2, 3)), "dbias (round-off level)", 1e-4)
+    # the conv bias feeds a train-mode BatchNorm: its true gradient is 0 and both sides hold pure
+    # summation round-off, so compare against the size of the summed terms
+    noise = 2e-6 * y_ref.grad.abs().sum(dim=(0, 2, 3)).max().item()
+    check(dbias, y_ref.grad.sum(dim=(0, 2, 3)), "dbias (round-off level)", max(noise, 1e-9))
 
 
 @pytest.mark.parametrize("layer", range(1, 8))

@@ -67,7 +67,7 @@ static WsLayout carve(const cvae_handle_s* h, int B) {
     for (int l = 1; l <= 7; ++l) mx(wgrad_ws_floats(l, W, B));
     mx(e1_wgrad_ws_floats(W, B));
     mx(d4_bwd_ws_floats(W, B));
-    for (int l = 0; l < 4; ++l) mx(bn_bwd_ws_floats(l, W, B));
+    for (int l = 0; l < 4; ++l) { mx(bn_bwd_ws_floats(l, W, B)); mx(bn_fwd_ws_floats(l, W)); }
     mx(fc_ws_floats(W, B));
     mx(colsum_ws_floats(0, 256));
     w.scratch = take(sc);
@@ -170,7 +170,7 @@ int cvae_forward(cvae_handle h, int32_t B, const float* x, const float* pred, co
         if (l == 0) RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], ws + w.bnpart[0], st));
         else RC(launch_conv_fwd(l, W, B, ws + w.a[l - 1], P_(h->enc_w[l]), P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], st));
         RC(launch_bn_fwd_finalize(l, W, B, ws + w.bnpart[l], P_(h->enc_g[l]), P_(h->enc_be[l]), bn_state + kBnOff[l],
-                                  bn_state + 480 + kBnOff[l], ws + w.coef[l], train, st));
+                                  bn_state + 480 + kBnOff[l], ws + w.coef[l], ws + w.scratch, train, st));
         RC(launch_bn_pool_act_fwd(l, W, B, ws + w.y[l], ws + w.coef[l], ws + w.a[l], st));
     }
     RC(launch_fc_fwd(W, B, ws + w.a[3], P_(h->fc_w), P_(h->fc_b), eps, pred, mu, logvar, ws + w.zcat, ws + w.scratch, st));
@@ -295,9 +295,9 @@ int cvae_op_d4_bwd(cvae_handle h, int32_t B, const float* o3, const float* d_rec
 
 int cvae_op_bn_pool_act_fwd(cvae_handle h, int32_t layer, int32_t B, const float* y, const float* bn_partials,
                             const float* gamma, const float* beta, float* run_mean, float* run_var, float* coef,
-                            float* a, int32_t train, void* stream) {
+                            float* a, void* scratch, int32_t train, void* stream) {
     const int W = h->cfg.width;
-    RC(launch_bn_fwd_finalize(layer, W, B, bn_partials, gamma, beta, run_mean, run_var, coef, train, (hipStream_t)stream));
+    RC(launch_bn_fwd_finalize(layer, W, B, bn_partials, gamma, beta, run_mean, run_var, coef, (float*)scratch, train, (hipStream_t)stream));
     return launch_bn_pool_act_fwd(layer, W, B, y, coef, a, (hipStream_t)stream);
 }
 

@@ -32,44 +32,58 @@ int bn_num_tiles(int layer, int width, int B) {
     return cdiv(B, imgs) * tpi;
 }
 
-__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
-    const float* __restrict__ part, int numTiles, int C, int B, int imgsPerTile, int pxPerImg,
-    int tilesPerImg, double N, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ coef, int train) {
+// stage A: mid[ra][{S,Q,M}][c] (fp64) over the tiles of chunk ra; grid (C/32, RA)
+__global__ __launch_bounds__(256) void bn_fwd_reduce_kernel(const float* __restrict__ part, int numTiles, int C, int B,
+                                                            int imgsPerTile, int pxPerImg, int tilesPerImg,
+                                                            double* __restrict__ mid, int tilesPerBlk) {
     __shared__ double red[3][8][32];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    const int t0 = blockIdx.y * tilesPerBlk;
+    int t1 = t0 + tilesPerBlk; if (t1 > numTiles) t1 = numTiles;
     double S = 0.0, Q = 0.0, M = 0.0;
-    if (train) {
-        for (int t = rg; t < numTiles; t += 8) {
-            const int img0 = (t / tilesPerImg) * imgsPerTile;
-            int ni = B - img0; if (ni > imgsPerTile) ni = imgsPerTile;
-            const double n = (double)(ni * pxPerImg);
-            const double s = (double)part[(size_t)t * C + c];
-            S += s; Q += s * s / n; M += (double)part[((size_t)numTiles + t) * C + c];
-        }
+#pragma unroll 4
+    for (int t = t0 + rg; t < t1; t += 8) {
+        const int img0 = (t / tilesPerImg) * imgsPerTile;
+        int ni = B - img0; if (ni > imgsPerTile) ni = imgsPerTile;
+        const double n = (double)(ni * pxPerImg);
+        const double s = (double)part[(size_t)t * C + c];
+        S += s; Q += s * s / n; M += (double)part[((size_t)numTiles + t) * C + c];
     }
     red[0][rg][cl] = S; red[1][rg][cl] = Q; red[2][rg][cl] = M;
     __syncthreads();
     if (rg == 0) {
-        float mean, var;
-        if (train) {
-            for (int k = 1; k < 8; ++k) { S += red[0][k][cl]; Q += red[1][k][cl]; M += red[2][k][cl]; }
-            const double mu = S / N;
-            double v = (M + Q - S * S / N) / N;          // biased variance
-            if (v < 0.0) v = 0.0;
-            mean = (float)mu; var = (float)v;
-            run_mean[c] = 0.9f * run_mean[c] + 0.1f * mean;
-            run_var[c] = 0.9f * run_var[c] + 0.1f * (float)(v * N / (N - 1.0));
-        } else {
-            mean = run_mean[c]; var = run_var[c];
-        }
-        const float invstd = 1.0f / sqrtf(var + 1e-5f);
-        const float scale = gamma[c] * invstd;
-        coef[c * 4 + 0] = scale;
-        coef[c * 4 + 1] = beta[c] - mean * scale;
-        coef[c * 4 + 2] = mean;
-        coef[c * 4 + 3] = invstd;
+        for (int k = 1; k < 8; ++k) { S += red[0][k][cl]; Q += red[1][k][cl]; M += red[2][k][cl]; }
+        double* o = mid + (size_t)blockIdx.y * 3 * C;
+        o[c] = S; o[C + c] = Q; o[2 * C + c] = M;
     }
+}
+
+// stage B: merge the RA chunk sums (Chan, fp64), emit coef[c] = {scale, shift, mean, invstd}, update running stats
+__global__ void bn_fwd_finalize_kernel(const double* __restrict__ mid, int RA, int C, double N,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float* __restrict__ run_mean, float* __restrict__ run_var,
+                                       float* __restrict__ coef, int train) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean, var;
+    if (train) {
+        double S = 0.0, Q = 0.0, M = 0.0;
+        for (int r = 0; r < RA; ++r) { S += mid[(size_t)r * 3 * C + c]; Q += mid[(size_t)r * 3 * C + C + c]; M += mid[(size_t)r * 3 * C + 2 * C + c]; }
+        const double mu = S / N;
+        double v = (M + Q - S * S / N) / N;          // biased variance
+        if (v < 0.0) v = 0.0;
+        mean = (float)mu; var = (float)v;
+        run_mean[c] = 0.9f * run_mean[c] + 0.1f * mean;
+        run_var[c] = 0.9f * run_var[c] + 0.1f * (float)(v * N / (N - 1.0));
+    } else {
+        mean = run_mean[c]; var = run_var[c];
+    }
+    const float invstd = 1.0f / sqrtf(var + 1e-5f);
+    const float scale = gamma[c] * invstd;
+    coef[c * 4 + 0] = scale;
+    coef[c * 4 + 1] = beta[c] - mean * scale;
+    coef[c * 4 + 2] = mean;
+    coef[c * 4 + 3] = invstd;
 }
 
 __device__ __forceinline__ float act_fwd(float v, int act) { return act ? tanhf(v) : fmaxf(v, 0.f); }
@@ -164,34 +178,35 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ y
     }
 }
 
-// stage 2 of the backward reductions.  MODE 0: dgamma, dbeta, bcoef = (s1/N, s2/N).  MODE 1: dbias.
-template <int MODE>
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, float invN,
-                                                              float* __restrict__ o0, float* __restrict__ o1,
-                                                              float* __restrict__ bcoef) {
-    __shared__ float red[2][8][32];
-    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;   // C % 32 == 0
-    float s1 = 0.f, s2 = 0.f;
-    for (int b = rg; b < nblk; b += 8) {
-        if (MODE == 0) { s1 += part[((size_t)b * 2) * C + c]; s2 += part[((size_t)b * 2 + 1) * C + c]; }
-        else s1 += part[(size_t)b * C + c];
-    }
-    red[0][rg][cl] = s1; red[1][rg][cl] = s2;
-    __syncthreads();
-    if (rg != 0) return;
-    for (int k = 1; k < 8; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
-    if (MODE == 0) { o0[c] = s2; o1[c] = s1; bcoef[c * 2] = s1 * invN; bcoef[c * 2 + 1] = s2 * invN; }
-    else o0[c] = s1;
+// after launch_col_reduce: red = [sum g | sum g*xhat] -> dgamma, dbeta, bcoef = (s1/N, s2/N)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ red, int C, float invN, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ bcoef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s1 = red[c], s2 = red[C + c];
+    dgamma[c] = s2; dbeta[c] = s1; bcoef[c * 2] = s1 * invN; bcoef[c * 2 + 1] = s2 * invN;
 }
 
+static constexpr int BN_RA = 32;
+int64_t bn_fwd_ws_floats(int layer, int width) { (void)width; return (int64_t)2 * BN_RA * 3 * kLayers[layer].cout; }
+
 int launch_bn_fwd_finalize(int layer, int width, int B, const float* bnpart, const float* gamma, const float* beta,
-                           float* run_mean, float* run_var, float* coef, int train, hipStream_t st) {
+                           float* run_mean, float* run_var, float* coef, float* ws, int train, hipStream_t st) {
     const BnGeom g = bn_geom(layer, width);
     int imgs, ppi, tpi;
     tile_geom(g.H, &imgs, &ppi, &tpi);
     const int numTiles = cdiv(B, imgs) * tpi;
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(g.C / 32), dim3(256), 0, st, bnpart, numTiles, g.C, B, imgs, ppi,
-                       tpi, (double)B * g.H * g.H, gamma, beta, run_mean, run_var, coef, train);
+    double* mid = reinterpret_cast<double*>(ws);
+    int RA = 0;
+    if (train) {
+        const int tpb = cdiv(numTiles, BN_RA);
+        RA = cdiv(numTiles, tpb);
+        hipLaunchKernelGGL(bn_fwd_reduce_kernel, dim3(g.C / 32, RA), dim3(256), 0, st, bnpart, numTiles, g.C, B, imgs,
+                           ppi, tpi, mid, tpb);
+        CVAE_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(g.C, 64)), dim3(64), 0, st, mid, RA, g.C,
+                       (double)B * g.H * g.H, gamma, beta, run_mean, run_var, coef, train);
     CVAE_CHECK_LAUNCH();
     return 0;
 }
@@ -216,7 +231,7 @@ static inline int bn_bwd_blocks(int64_t totalPx, int C) {
 int64_t bn_bwd_ws_floats(int layer, int width, int B) {
     const BnGeom g = bn_geom(layer, width);
     const int64_t totalPx = (int64_t)B * (g.H / 2) * (g.H / 2);
-    return (int64_t)bn_bwd_blocks(totalPx, g.C) * 2 * g.C + 2 * g.C;
+    return (int64_t)bn_bwd_blocks(totalPx, g.C) * 2 * g.C + 4 * g.C + col_reduce_ws_floats(2 * g.C);
 }
 
 int launch_bn_pool_act_bwd(int layer, int width, int B, const float* y, const float* a, const float* da,
@@ -229,17 +244,17 @@ int launch_bn_pool_act_bwd(int layer, int width, int B, const float* y, const fl
     const int64_t ppb = (totalPx + nblk - 1) / nblk;
     float* part = ws;
     float* bcoef = ws + (size_t)nblk * 2 * g.C;
+    float* red = bcoef + 2 * g.C;
+    float* crws = red + 2 * g.C;
     const float invN = 1.0f / (float)((double)B * g.H * g.H);
-    const dim3 fin(g.C / 32);
     if (g.act) hipLaunchKernelGGL((bn_bwd_kernel<1, 0>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, nullptr, nullptr, part, g.C, g.H, totalPx, ppb);
     else hipLaunchKernelGGL((bn_bwd_kernel<0, 0>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, nullptr, nullptr, part, g.C, g.H, totalPx, ppb);
     CVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<0>, fin, dim3(256), 0, st, part, nblk, g.C, invN, dgamma, dbeta, bcoef);
+    { int rc = launch_col_reduce(part, nblk, 2 * g.C, 2 * g.C, red, crws, st); if (rc) return rc; }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(g.C, 64)), dim3(64), 0, st, red, g.C, invN, dgamma, dbeta, bcoef);
     CVAE_CHECK_LAUNCH();
     if (g.act) hipLaunchKernelGGL((bn_bwd_kernel<1, 1>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, bcoef, dy, part, g.C, g.H, totalPx, ppb);
     else hipLaunchKernelGGL((bn_bwd_kernel<0, 1>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, bcoef, dy, part, g.C, g.H, totalPx, ppb);
     CVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<1>, fin, dim3(256), 0, st, part, nblk, g.C, invN, dbias, nullptr, nullptr);
-    CVAE_CHECK_LAUNCH();
-    return 0;
+    return launch_col_reduce(part, nblk, g.C, g.C, dbias, crws, st);
 }

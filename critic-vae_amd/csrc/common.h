@@ -72,6 +72,9 @@ int launch_conv_wgrad(int layer, int width, int B, const float* in, const float*
 int launch_reduce_slabs(const float* slab, float* dst, int64_t n, int S, int64_t stride, hipStream_t st);
 int launch_colsum(const float* src, int64_t rows, int C, float* dst, float* ws, hipStream_t st);
 int64_t colsum_ws_floats(int64_t rows, int C);
+// reduce.hip
+int64_t col_reduce_ws_floats(int W);
+int launch_col_reduce(const float* in, int R, int W, int64_t stride, float* out, float* ws, hipStream_t st);
 // conv_thin.hip (E1 / D4)
 int launch_e1_fwd(int width, int B, const float* x, const float* w, const float* bias, float* y,
                   float* bnpart, hipStream_t st);
@@ -88,7 +91,8 @@ int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const
 int bn_num_tiles(int layer, int width, int B);
 int launch_bn_fwd_finalize(int layer, int width, int B, const float* bnpart, const float* gamma,
                            const float* beta, float* run_mean, float* run_var, float* coef,
-                           int train, hipStream_t st);
+                           float* ws, int train, hipStream_t st);
+int64_t bn_fwd_ws_floats(int layer, int width);
 int launch_bn_pool_act_fwd(int layer, int width, int B, const float* y, const float* coef, float* a,
                            hipStream_t st);
 int64_t bn_bwd_ws_floats(int layer, int width, int B);

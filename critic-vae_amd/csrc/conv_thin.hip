@@ -145,27 +145,23 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
     thin_slab_out(acc, smem, a.slab + (size_t)blockIdx.x * 96 * 32);
 }
 
-// dst[i] = sum_s slab[s][map(i)];  PERM: dst is W4 [tap][ci][co], slab row k = tap*3+co, col ci
-template <bool PERM>
-__global__ __launch_bounds__(256) void thin_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dst, int S) {
+// dst (W4 [tap][ci][co]) <- reduced slab row (k = tap*3+co, col ci)
+__global__ __launch_bounds__(256) void d4_perm_kernel(const float* __restrict__ red, float* __restrict__ dst) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= 2400) return;
-    int src = i;
-    if (PERM) { const int co = i % 3, ci = (i / 3) % 32, tap = i / 96; src = (tap * 3 + co) * 32 + ci; }
-    float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += slab[(size_t)s * 3072 + src];
-    dst[i] = acc;
+    const int co = i % 3, ci = (i / 3) % 32, tap = i / 96;
+    dst[i] = red[(tap * 3 + co) * 32 + ci];
 }
 
 static int thin_splits(int numTiles, int* tps) {
-    int S = numTiles < 1024 ? numTiles : 1024;
+    int S = numTiles < 512 ? numTiles : 512;
     *tps = cdiv(numTiles, S);
     return cdiv(numTiles, *tps);
 }
 
 int64_t e1_wgrad_ws_floats(int width, int B) {
     int tps; const int tiles = B * (width / 4) * (width / 32);
-    return (int64_t)thin_splits(tiles, &tps) * 3072;
+    return (int64_t)thin_splits(tiles, &tps) * 3072 + col_reduce_ws_floats(3072);
 }
 
 int launch_e1_fwd(int width, int B, const float* x, const float* w, const float* bias, float* y,
@@ -183,9 +179,7 @@ int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw
     ThinWgradArgs a{x, dy, nullptr, nullptr, ws, B, tiles, tps};
     hipLaunchKernelGGL(e1_wgrad_kernel<64>, dim3(S), dim3(256), 0, st, a);
     CVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(thin_reduce_kernel<false>, dim3(cdiv(2400, 256)), dim3(256), 0, st, ws, dw, S);
-    CVAE_CHECK_LAUNCH();
-    return 0;
+    return launch_col_reduce(ws, S, 2400, 3072, dw, ws + (size_t)S * 3072, st);
 }
 
 // ------------------------------------------ D4 ------------------------------------------------
@@ -370,7 +364,7 @@ static int d4_splits(int width, int B, int* tps) {
 // ws of launch_d4_bwd = [S*3072 split-K slab | B*3 plane sums of dOut]
 int64_t d4_bwd_ws_floats(int width, int B) {
     int tps;
-    return (int64_t)d4_splits(width, B, &tps) * 3072 + (int64_t)B * 3;
+    return (int64_t)d4_splits(width, B, &tps) * 3072 + align_up((int64_t)B * 3, 64) + 3072 + col_reduce_ws_floats(3072);
 }
 
 int launch_d4_fwd(int width, int B, const float* in, const float* w, const float* bias, float* recon, hipStream_t st) {
@@ -399,7 +393,9 @@ int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const
     }
     hipLaunchKernelGGL(d4_bwd_kernel<64>, dim3(S), dim3(256), D4_BWD_SMEM, st, a);
     CVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(thin_reduce_kernel<true>, dim3(cdiv(2400, 256)), dim3(256), 0, st, ws, dw, S);
+    float* red = plane_sums + align_up((int64_t)B * 3, 64);
+    { int rc = launch_col_reduce(ws, S, 3072, 3072, red, red + 3072, st); if (rc) return rc; }
+    hipLaunchKernelGGL(d4_perm_kernel, dim3(cdiv(2400, 256)), dim3(256), 0, st, red, dw);
     CVAE_CHECK_LAUNCH();
     hipLaunchKernelGGL(d4_dbias_kernel, dim3(1), dim3(192), 0, st, plane_sums, db, B);
     CVAE_CHECK_LAUNCH();

@@ -272,15 +272,7 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ s
     }
 }
 
-__global__ void colsum_stage2(const float* __restrict__ part, int nblk, int C, float* __restrict__ dst) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float acc = 0.f;
-    for (int b = 0; b < nblk; ++b) acc += part[(size_t)b * C + c];
-    dst[c] = acc;
-}
-
-int64_t colsum_ws_floats(int64_t rows, int C) { (void)rows; return (int64_t)CS_BLOCKS * C; }
+int64_t colsum_ws_floats(int64_t rows, int C) { (void)rows; return (int64_t)CS_BLOCKS * C + col_reduce_ws_floats(C); }
 
 int launch_colsum(const float* src, int64_t rows, int C, float* dst, float* ws, hipStream_t st) {
     if (C > 256 || 256 % C != 0) { cvae_set_error("colsum: C=%d unsupported", C); return -2; }
@@ -288,7 +280,5 @@ int launch_colsum(const float* src, int64_t rows, int C, float* dst, float* ws, 
     if (nblk > rows) nblk = (int)rows;
     hipLaunchKernelGGL(colsum_stage1, dim3(nblk), dim3(256), 0, st, src, rows, C, ws);
     CVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(C, 64)), dim3(64), 0, st, ws, nblk, C, dst);
-    CVAE_CHECK_LAUNCH();
-    return 0;
+    return launch_col_reduce(ws, nblk, C, C, dst, ws + (size_t)CS_BLOCKS * C, st);
 }

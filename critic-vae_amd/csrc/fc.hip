@@ -7,7 +7,7 @@
 // (h,w,c) order), Wd [33][K] (K in (h,w,c) order) so that `flat`/`h` are the NHWC activations.
 #include "common.h"
 
-static constexpr int FC_KS = 8;          // K splits of the fc_mu|fc_var GEMM
+static constexpr int FC_KS = 32;         // K splits of the fc_mu|fc_var GEMM
 static constexpr int FC_IMGS = 16;       // images per workgroup
 
 // part[ks][b][64] = sum_{k in split ks} flat[b][k] * Wfc[k][n]
@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void fc_fwd_partial_kernel(const float* __rest
     __syncthreads();
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const float* f = lds_f + (bq * 4) * kchunk;
+#pragma unroll 8
     for (int k = 0; k < kchunk; ++k) {
         const float wv = wfc[(size_t)(k0 + k) * 64 + n];
 #pragma unroll
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(256) void fc_bwd_dw_kernel(const float* __restrict_
                                                         float* __restrict__ dwfc, int B, int K) {
     const int n = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
     float acc = 0.f;
+#pragma unroll 8
     for (int b = 0; b < B; ++b) acc = fmaf(flat[(size_t)b * K + k], dml[(size_t)b * 64 + n], acc);
     dwfc[(size_t)k * 64 + n] = acc;
 }

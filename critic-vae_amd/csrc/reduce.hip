@@ -1,0 +1,42 @@
+// reduce.hip — fixed-order column sums of small row-major partial matrices [R][W] -> [W].
+//
+// Every cross-workgroup reduction of the step (BatchNorm backward sums, conv bias gradients,
+// split-K slabs of the thin convs) ends here.  One or two launches, each thread reads a handful
+// of rows: no serial loops over hundreds of partials, no atomics, bitwise reproducible.
+#include "common.h"
+
+// mid[ra][w] = sum over rows [ra*rowsPerBlk, +rowsPerBlk) of in[r*stride + w]; grid (cdiv(W,32), RA)
+__global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ in, int R, int W, int64_t stride,
+                                                       float* __restrict__ out, int rowsPerBlk) {
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5, w = blockIdx.x * 32 + cl;
+    const int r0 = blockIdx.y * rowsPerBlk;
+    int r1 = r0 + rowsPerBlk; if (r1 > R) r1 = R;
+    float acc = 0.f;
+    if (w < W) {
+#pragma unroll 4
+        for (int r = r0 + rl; r < r1; r += 8) acc += in[(size_t)r * stride + w];
+    }
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && w < W) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) acc += red[k][cl];
+        out[(size_t)blockIdx.y * W + w] = acc;
+    }
+}
+
+int64_t col_reduce_ws_floats(int W) { return (int64_t)32 * W; }
+
+// out[w] = sum_r in[r*stride + w].  ws: col_reduce_ws_floats(W) floats (used when R > 64).
+int launch_col_reduce(const float* in, int R, int W, int64_t stride, float* out, float* ws, hipStream_t st) {
+    if (R > 64) {
+        const int RA = 32, rpb = cdiv(R, RA);
+        hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(W, 32), cdiv(R, rpb)), dim3(256), 0, st, in, R, W, stride, ws, rpb);
+        CVAE_CHECK_LAUNCH();
+        in = ws; R = cdiv(R, rpb); stride = W;
+    }
+    hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(W, 32), 1), dim3(256), 0, st, in, R, W, stride, out, R);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}

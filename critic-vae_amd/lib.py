@@ -60,7 +60,7 @@ _SIGS = {
     "cvae_op_conv_dgrad": (C.c_int, [_p, _i32, _i32] + [_p] * 5),
     "cvae_op_conv_wgrad": (C.c_int, [_p, _i32, _i32] + [_p] * 6),
     "cvae_op_d4_bwd": (C.c_int, [_p, _i32] + [_p] * 10),
-    "cvae_op_bn_pool_act_fwd": (C.c_int, [_p, _i32, _i32] + [_p] * 8 + [_i32, _p]),
+    "cvae_op_bn_pool_act_fwd": (C.c_int, [_p, _i32, _i32] + [_p] * 9 + [_i32, _p]),
     "cvae_op_bn_pool_act_bwd": (C.c_int, [_p, _i32, _i32] + [_p] * 11),
     "cvae_op_msssim": (C.c_int, [_p, _i32] + [_p] * 6),
 }
@@ -183,10 +183,10 @@ class Handle:
         self._check(self.lib.cvae_op_d4_bwd(self.h, B, _ptr(o3), _ptr(d_recon), _ptr(recon), _ptr(w), _ptr(dout),
                                             _ptr(d_o3), _ptr(dw), _ptr(db), _ptr(scratch), _stream()))
 
-    def op_bn_pool_act_fwd(self, layer, B, y, bn_partials, gamma, beta, run_mean, run_var, coef, a, train=True):
+    def op_bn_pool_act_fwd(self, layer, B, y, bn_partials, gamma, beta, run_mean, run_var, coef, a, scratch, train=True):
         self._check(self.lib.cvae_op_bn_pool_act_fwd(self.h, layer, B, _ptr(y), _ptr(bn_partials), _ptr(gamma),
                                                      _ptr(beta), _ptr(run_mean), _ptr(run_var), _ptr(coef), _ptr(a),
-                                                     int(train), _stream()))
+                                                     _ptr(scratch), int(train), _stream()))
 
     def op_bn_pool_act_bwd(self, layer, B, y, a, da, coef, gamma, dy, dgamma, dbeta, dbias, scratch):
         self._check(self.lib.cvae_op_bn_pool_act_bwd(self.h, layer, B, _ptr(y), _ptr(a), _ptr(da), _ptr(coef),

@@ -138,8 +138,8 @@ int cvae_op_d4_bwd(cvae_handle h, int32_t batch, const float* o3, const float* d
 /* BatchNorm2d(train) -> MaxPool2d(2) -> ReLU/Tanh of encoder block `layer` (0..3) */
 int cvae_op_bn_pool_act_fwd(cvae_handle h, int32_t layer, int32_t batch, const float* y,
                             const float* bn_partials, const float* gamma, const float* beta,
-                            float* run_mean, float* run_var, float* coef, float* a, int32_t train,
-                            void* stream);
+                            float* run_mean, float* run_var, float* coef, float* a, void* scratch,
+                            int32_t train, void* stream);
 int cvae_op_bn_pool_act_bwd(cvae_handle h, int32_t layer, int32_t batch, const float* y,
                             const float* a, const float* da, const float* coef, const float* gamma,
                             float* dy, float* dgamma, float* dbeta, float* dbias, void* scratch,

@@ -105,7 +105,8 @@ def test_bn_pool_act_fwd_bwd(H, layer, B, ties):
     rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
     coef = torch.empty(C * 4, device="cuda")
     a = torch.empty(B * (h // 2) ** 2 * C, device="cuda")
-    H.op_bn_pool_act_fwd(layer, B, y, part, dev(gamma), dev(beta), rm, rv, coef, a, True)
+    sc = torch.empty(H.op_scratch_floats(B), device="cuda")
+    H.op_bn_pool_act_fwd(layer, B, y, part, dev(gamma), dev(beta), rm, rv, coef, a, sc, True)
     torch.cuda.synchronize()
     check(coef.view(C, 4)[:, 2], mean, "bn mean", 1e-5)
     check(1.0 / coef.view(C, 4)[:, 3] ** 2 - 1e-5, var, "bn var", 1e-5, rel=True)

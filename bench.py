@@ -60,7 +60,8 @@ def kernel_probe(vae, B):
         b = torch.zeros(cout, device=dev)
         y = torch.empty(B * h * h * cout, device=dev)
         part = torch.empty(max(H.op_bn_partial_floats(min(layer, 3), B), 1), device=dev)
-        out[f"conv_fwd_L{layer}"] = (time_op(lambda: H.op_conv_fwd(layer, B, x, w, b, y, part if layer < 4 else None)),
+        sc = torch.empty(H.op_scratch_floats(B), device=dev)
+        out[f"conv_fwd_L{layer}"] = (time_op(lambda: H.op_conv_fwd(layer, B, x, w, b, y, part if layer < 4 else None, sc)),
                                      conv_flops(layer, B))
         dy = torch.rand(B * h * h * cout, device=dev)
         dx = torch.empty(B * hs * hs * cin, device=dev)

@@ -64,7 +64,7 @@ static WsLayout carve(const cvae_handle_s* h, int B) {
     w.ms = take(msssim_ws_floats(W, B));
     int64_t sc = 0;
     auto mx = [&](int64_t v) { if (v > sc) sc = v; };
-    for (int l = 1; l <= 7; ++l) mx(wgrad_ws_floats(l, W, B));
+    for (int l = 1; l <= 7; ++l) { mx(wgrad_ws_floats(l, W, B)); mx(conv_fwd_ws_floats(l, W, B)); }
     mx(e1_wgrad_ws_floats(W, B));
     mx(d4_bwd_ws_floats(W, B));
     for (int l = 0; l < 4; ++l) { mx(bn_bwd_ws_floats(l, W, B)); mx(bn_fwd_ws_floats(l, W)); }
@@ -168,7 +168,7 @@ int cvae_forward(cvae_handle h, int32_t B, const float* x, const float* pred, co
     const int W = h->cfg.width;
     for (int l = 0; l < 4; ++l) {
         if (l == 0) RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], ws + w.bnpart[0], st));
-        else RC(launch_conv_fwd(l, W, B, ws + w.a[l - 1], P_(h->enc_w[l]), P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], st));
+        else RC(launch_conv_fwd(l, W, B, ws + w.a[l - 1], P_(h->enc_w[l]), P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st));
         RC(launch_bn_fwd_finalize(l, W, B, ws + w.bnpart[l], P_(h->enc_g[l]), P_(h->enc_be[l]), bn_state + kBnOff[l],
                                   bn_state + 480 + kBnOff[l], ws + w.coef[l], ws + w.scratch, train, st));
         RC(launch_bn_pool_act_fwd(l, W, B, ws + w.y[l], ws + w.coef[l], ws + w.a[l], st));
@@ -192,7 +192,7 @@ int cvae_decode(cvae_handle h, int32_t B, const float* zcat, const float* params
     }
     RC(launch_decin_fwd(W, B, ws + w.zcat, P_(h->di_w), P_(h->di_b), ws + w.h, st));
     for (int i = 0; i < 4; ++i)
-        RC(launch_conv_fwd(4 + i, W, B, i == 0 ? ws + w.h : ws + w.o[i - 1], P_(h->dec_w[i]), P_(h->dec_b[i]), ws + w.o[i], nullptr, st));
+        RC(launch_conv_fwd(4 + i, W, B, i == 0 ? ws + w.h : ws + w.o[i - 1], P_(h->dec_w[i]), P_(h->dec_b[i]), ws + w.o[i], nullptr, ws + w.scratch, st));
     RC(launch_d4_fwd(W, B, ws + w.o[3], P_(h->dec_w[4]), P_(h->dec_b[4]), recon, st));
     return 0;
 }
@@ -257,11 +257,11 @@ int cvae_adam_step(cvae_handle h, float* params, const float* grads, float* exp_
 
 // ------------------------------ per-op entry points ------------------------------
 int cvae_op_conv_fwd(cvae_handle h, int32_t layer, int32_t B, const float* in, const float* wt, const float* bias,
-                     float* out, float* bn_partials, void* stream) {
+                     float* out, float* bn_partials, void* scratch, void* stream) {
     const int W = h->cfg.width;
     if (layer == 0) return launch_e1_fwd(W, B, in, wt, bias, out, bn_partials, (hipStream_t)stream);
     if (layer == 8) return launch_d4_fwd(W, B, in, wt, bias, out, (hipStream_t)stream);
-    return launch_conv_fwd(layer, W, B, in, wt, bias, out, bn_partials, (hipStream_t)stream);
+    return launch_conv_fwd(layer, W, B, in, wt, bias, out, bn_partials, (float*)scratch, (hipStream_t)stream);
 }
 
 int cvae_op_conv_dgrad(cvae_handle h, int32_t layer, int32_t B, const float* dout, const float* wt,

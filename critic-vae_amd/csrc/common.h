@@ -62,14 +62,16 @@ void cvae_set_error(const char* fmt, ...);
 // ---- launchers implemented across the .hip files (all asynchronous on `st`) ----
 // conv_mfma.hip
 int launch_conv_fwd(int layer, int width, int B, const float* in, const float* w, const float* bias,
-                    float* out, float* bnpart, hipStream_t st);
+                    float* out, float* bnpart, float* ws, hipStream_t st);
+int64_t conv_fwd_ws_floats(int layer, int width, int B);
 int launch_conv_dgrad(int layer, int width, int B, const float* dout, const float* w,
                       const float* mask_src, float* din, hipStream_t st);
 // conv_wgrad.hip
 int64_t wgrad_ws_floats(int layer, int width, int B);
 int launch_conv_wgrad(int layer, int width, int B, const float* in, const float* dout, float* dw,
                       float* ws, hipStream_t st);
-int launch_reduce_slabs(const float* slab, float* dst, int64_t n, int S, int64_t stride, hipStream_t st);
+int launch_reduce_slabs(const float* slab, float* dst, int64_t n, int S, int64_t stride, hipStream_t st,
+                        float* mid = nullptr);
 int launch_colsum(const float* src, int64_t rows, int C, float* dst, float* ws, hipStream_t st);
 int64_t colsum_ws_floats(int64_t rows, int C);
 // reduce.hip

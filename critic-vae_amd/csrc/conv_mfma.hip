@@ -27,12 +27,13 @@ struct ConvArgs {
     float* out;
     float* bnpart;      // BNSTAT: [2][numTiles][NCH] (sum, M2 about the tile mean)
     int B;
+    int64_t sliceFloats;   // KSPLIT > 1: out is a slab [KSPLIT][sliceFloats] of raw partial sums
 };
 
 static constexpr int KC = 16;        // channels per K chunk
 static constexpr int KCP = KC + 1;   // padded row for the transposed (dgrad) weight slab
 
-template <int KCH, int NCH, int H, bool UP, bool DGRAD, int NT, int EPI>
+template <int KCH, int NCH, int H, bool UP, bool DGRAD, int NT, int EPI, int KSPLIT>
 __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
     using T = Tile<H>;
     constexpr int NB = NT / 32;
@@ -121,14 +122,17 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
         }
     };
 
-    constexpr int NST = (KCH / KC) * 5;
-    load_w(0);
-    for (int st = 0; st < NST; ++st) {
+    // split-K (small-spatial layers): workgroup z contracts channel chunks [z*CPS, (z+1)*CPS)
+    static_assert((KCH / KC) % KSPLIT == 0, "split-K must divide the channel chunks");
+    constexpr int NST = (KCH / KC) / KSPLIT * 5;
+    const int st0 = blockIdx.z * NST, st1 = st0 + NST;
+    load_w(st0);
+    for (int st = st0; st < st1; ++st) {
         const int r = st % 5;
         __syncthreads();                       // everyone finished reading the previous stage
         if (r == 0) stage_input(st / 5);
         store_w();
-        if (st + 1 < NST) load_w(st + 1);      // in flight while this stage computes
+        if (st + 1 < st1) load_w(st + 1);      // in flight while this stage computes
         __syncthreads();
         const float* ap = lds_in + aBase + r * T::HTW;
 #pragma unroll
@@ -147,7 +151,10 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
     }
 
     // ------------------------------- epilogue -------------------------------
-    if (EPI == EPI_BIAS_BNSTAT || EPI == EPI_BIAS_RELU || EPI == EPI_PLAIN) {
+    if (KSPLIT > 1) {
+        epilogue_store<H, NT, NCH, EPI_PLAIN>(acc, nullptr, a.out + (size_t)blockIdx.z * a.sliceFloats, nullptr, smem, a.B,
+                                              mt, n0, img0, ty0, tx0);
+    } else if (EPI == EPI_BIAS_BNSTAT || EPI == EPI_BIAS_RELU || EPI == EPI_PLAIN) {
         epilogue_store<H, NT, NCH, EPI>(acc, a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0);
     } else {   // EPI_POOLSUM_MASK: 2x2 sum (upsample backward) then ReLU mask of the producer
         __syncthreads();
@@ -175,26 +182,56 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
     }
 }
 
-template <int KCH, int NCH, int H, bool UP, bool DGRAD, int NT, int EPI>
+template <int KCH, int NCH, int H, bool UP, bool DGRAD, int NT, int EPI, int KSPLIT = 1>
 static int run(const ConvArgs& a, hipStream_t st) {
     using T = Tile<H>;
     static_assert(KCH % KC == 0 && NCH % NT == 0, "channel tiling");
-    dim3 grid(cdiv(a.B, T::IMGS) * T::TILES_PER_IMG, NCH / NT);
-    hipLaunchKernelGGL((conv5x5_mfma_kernel<KCH, NCH, H, UP, DGRAD, NT, EPI>), grid, dim3(256), 0, st, a);
+    dim3 grid(cdiv(a.B, T::IMGS) * T::TILES_PER_IMG, NCH / NT, KSPLIT);
+    hipLaunchKernelGGL((conv5x5_mfma_kernel<KCH, NCH, H, UP, DGRAD, NT, EPI, KSPLIT>), grid, dim3(256), 0, st, a);
     CVAE_CHECK_LAUNCH();
     return 0;
 }
 
+// out[i] = relu(bias[i % C] + sum_z slab[z][i])   (split-K finish of the decoder head)
+__global__ __launch_bounds__(256) void splitk_bias_relu_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
+                                                               float* __restrict__ out, int64_t n4, int64_t slice, int KS, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 acc = *reinterpret_cast<const float4*>(bias + (i * 4) % C);
+    for (int z = 0; z < KS; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)z * slice + i * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    *reinterpret_cast<float4*>(out + i * 4) = acc;
+}
+
+static constexpr int D0_KSPLIT = 4;
+int64_t conv_fwd_ws_floats(int layer, int width, int B) {
+    if (layer != 4) return 0;
+    const int64_t h = kLayers[4].h * (width / 64);
+    return (int64_t)D0_KSPLIT * B * h * h * kLayers[4].cout;
+}
+
 int launch_conv_fwd(int layer, int width, int B, const float* in, const float* w, const float* bias,
-                    float* out, float* bnpart, hipStream_t st) {
-    ConvArgs a{in, w, bias, nullptr, out, bnpart, B};
+                    float* out, float* bnpart, float* ws, hipStream_t st) {
+    ConvArgs a{in, w, bias, nullptr, out, bnpart, B, 0};
     if (width == 64) {
         switch (layer) {
             case 1: return run<32, 64, 32, false, false, 64, EPI_BIAS_BNSTAT>(a, st);
             case 2: return run<64, 128, 16, false, false, 64, EPI_BIAS_BNSTAT>(a, st);
             case 3: return run<128, 256, 8, false, false, 64, EPI_BIAS_BNSTAT>(a, st);
-            case 4: return run<256, 128, 4, false, false, 64, EPI_BIAS_RELU>(a, st);
-            case 5: return run<128, 64, 8, true, false, 64, EPI_BIAS_RELU>(a, st);
+            case 4: {     // D0: 4x4 images, K = 6400 -> split-K over channel chunks to fill the chip
+                const int64_t slice = (int64_t)B * 4 * 4 * 128;
+                a.out = ws; a.sliceFloats = slice;
+                int rc = run<256, 128, 4, false, false, 64, EPI_PLAIN, D0_KSPLIT>(a, st);
+                if (rc) return rc;
+                hipLaunchKernelGGL(splitk_bias_relu_kernel, dim3((unsigned)((slice / 4 + 255) / 256)), dim3(256), 0, st,
+                                   ws, bias, out, slice / 4, slice, D0_KSPLIT, 128);
+                CVAE_CHECK_LAUNCH();
+                return 0;
+            }
+            case 5: return run<128, 64, 8, true, false, 32, EPI_BIAS_RELU>(a, st);
             case 6: return run<64, 32, 16, true, false, 32, EPI_BIAS_RELU>(a, st);
             case 7: return run<32, 32, 32, true, false, 32, EPI_BIAS_RELU>(a, st);
         }
@@ -206,13 +243,13 @@ int launch_conv_fwd(int layer, int width, int B, const float* in, const float* w
 int launch_conv_dgrad(int layer, int width, int B, const float* dout, const float* w,
                       const float* mask_src, float* din, hipStream_t st) {
     // KCH = layer Cout (channels of dout), NCH = layer Cin (channels of din)
-    ConvArgs a{dout, w, nullptr, mask_src, din, nullptr, B};
+    ConvArgs a{dout, w, nullptr, mask_src, din, nullptr, B, 0};
     if (width == 64) {
         switch (layer) {
             case 1: return run<64, 32, 32, false, true, 32, EPI_PLAIN>(a, st);
             case 2: return run<128, 64, 16, false, true, 64, EPI_PLAIN>(a, st);
             case 3: return run<256, 128, 8, false, true, 64, EPI_PLAIN>(a, st);
-            case 4: return run<128, 256, 4, false, true, 64, EPI_PLAIN>(a, st);
+            case 4: return run<128, 256, 4, false, true, 32, EPI_PLAIN>(a, st);
             case 5: return run<64, 128, 8, false, true, 64, EPI_POOLSUM_MASK>(a, st);
             case 6: return run<32, 64, 16, false, true, 64, EPI_POOLSUM_MASK>(a, st);
             case 7: return run<32, 32, 32, false, true, 32, EPI_POOLSUM_MASK>(a, st);

@@ -5,7 +5,7 @@
 //
 //   dW[tap][ci][co] = sum_{b,p} in[b][p+tap-2][ci] * dout[b][p][co]
 //
-// GEMM view: M = ci (32 per workgroup, one tap per accumulator tile), N = co, K = pixels.
+// GEMM view: M = ci, N = co, K = pixels; one accumulator tile per tap.
 // A workgroup owns one kernel ROW (5 taps) x 32 input channels x NT output channels and a
 // contiguous range of 128-pixel tiles; its 4 waves split each tile's pixels (K) and are summed
 // through LDS at the end.  Partial slabs [split][tap][ci][co] are then reduced in fixed order
@@ -22,36 +22,51 @@ struct WgradArgs {
     int tilesPerSplit;
 };
 
-template <int CIN, int COUT, int H, bool UP, int NT>
-__global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(WgradArgs a) {
+// One wave's share of a staged tile: taps 6W..6W+5 over every pixel, plus tap 24 over rows
+// rho == W (mod 4) (the 25th tap is split over the 4 waves so all MFMA pipes carry 6.25 taps).
+template <int H, int W>
+__device__ __forceinline__ void wgrad_body(f32x16 (&acc)[7], const float* lds_in, const float* lds_d, int li, int lh) {
     using T = Tile<H>;
-    constexpr int NB = NT / 32;
-    constexpr int CS = 32;                               // LDS pixel stride of the input rows
-    constexpr int IN_PIX = T::IMGS * T::TH * T::HTW;     // TH rows (one kernel row) x (TW+4) cols
-    constexpr int IN_FLOATS = IN_PIX * CS;
-    constexpr int D_FLOATS = 128 * NT;
-    constexpr int RED_FLOATS = 2 * 5 * NB * 1024;        // two waves' accumulators
-    constexpr int SMEM = (IN_FLOATS + D_FLOATS) > RED_FLOATS ? (IN_FLOATS + D_FLOATS) : RED_FLOATS;
+    constexpr int CS = 32, R = T::IMGS * T::TH;
+    for (int rho = 0; rho < R; ++rho) {
+        const int img = rho / T::TH, ty = rho % T::TH;
+        const float* inrow = lds_in + ((img * T::HTH + ty) * T::HTW + lh) * CS + li;
+        const float* drow = lds_d + (rho * T::TW + lh) * 32 + li;
+        const bool extra = (rho & 3) == W;
+#pragma unroll
+        for (int kk = 0; kk < T::TW / 2; ++kk) {
+            const float bv = drow[(2 * kk) * 32];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                constexpr int dummy = 0; (void)dummy;
+                const int tap = 6 * W + j, r = tap / 5, s = tap % 5;
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(inrow[(r * T::HTW + s + 2 * kk) * CS], bv, acc[j], 0, 0, 0);
+            }
+            if (extra)
+                acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(inrow[(4 * T::HTW + 4 + 2 * kk) * CS], bv, acc[6], 0, 0, 0);
+        }
+    }
+}
+
+template <int CIN, int COUT, int H, bool UP>
+__global__ __launch_bounds__(256, 2) void conv5x5_wgrad_kernel(WgradArgs a) {
+    using T = Tile<H>;
+    constexpr int CS = 32;
+    constexpr int IN_FLOATS = T::HP * CS;                // full 5x5 halo of the tile, 32 channels
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* lds_in = smem;
-    float* lds_d = smem + IN_FLOATS;
-    static_assert(IN_FLOATS % 4 == 0, "alignment");
-    (void)SMEM;
+    float* lds_d = smem + IN_FLOATS;                     // dout tile [128][32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int split = blockIdx.x;
-    const int r = blockIdx.y / (CIN / 32), ci0 = (blockIdx.y % (CIN / 32)) * 32;
-    const int n0 = blockIdx.z * NT;
+    const int split = blockIdx.x, ci0 = blockIdx.y * 32, n0 = blockIdx.z * 32;
     constexpr int HS = UP ? H / 2 : H;
 
-    f32x16 acc[5][NB];
+    f32x16 acc[7];
 #pragma unroll
-    for (int s = 0; s < 5; ++s)
+    for (int j = 0; j < 7; ++j)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[s][nb][v] = 0.f;
+        for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
 
     const int t0 = split * a.tilesPerSplit;
     int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
@@ -61,12 +76,10 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(WgradArgs a) {
         const int img0 = (mt / T::TILES_PER_IMG) * T::IMGS;
         const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;
         __syncthreads();
-        // input rows ty0+r-2 .. (+TH), cols tx0-2 .. tx0+TW+1, channels ci0..ci0+31 -> [pixel][32]
-        for (int q = tid; q < IN_PIX * 8; q += 256) {
+        for (int q = tid; q < T::HP * 8; q += 256) {
             const int c4 = q & 7, hp = q >> 3;
-            const int img = hp / (T::TH * T::HTW), rem = hp % (T::TH * T::HTW);
-            const int hy = rem / T::HTW, hx = rem % T::HTW;
-            const int gy = ty0 + hy + r - 2, gx = tx0 + hx - 2, ib = img0 + img;
+            const int img = hp / T::HPI, rem = hp % T::HPI;
+            const int gy = ty0 + rem / T::HTW - 2, gx = tx0 + rem % T::HTW - 2, ib = img0 + img;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B) {
                 const int sy = UP ? (gy >> 1) : gy, sx = UP ? (gx >> 1) : gx;
@@ -75,109 +88,81 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(WgradArgs a) {
             }
             *reinterpret_cast<float4*>(lds_in + hp * CS + c4 * 4) = v;
         }
-        // dout tile [128 pixels][NT]
-        for (int q = tid; q < 128 * NT / 4; q += 256) {
-            const int c4 = q % (NT / 4), mm = q / (NT / 4);
+        for (int q = tid; q < 128 * 8; q += 256) {
+            const int c4 = q & 7, mm = q >> 3;
             const int im = mm / (T::TH * T::TW), rem = mm % (T::TH * T::TW);
             const int gy = ty0 + rem / T::TW, gx = tx0 + rem % T::TW, ib = img0 + im;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ib < a.B)
                 v = *reinterpret_cast<const float4*>(
                     a.dout + ((size_t)(ib * H + gy) * H + gx) * COUT + n0 + c4 * 4);
-            *reinterpret_cast<float4*>(lds_d + mm * NT + c4 * 4) = v;
+            *reinterpret_cast<float4*>(lds_d + mm * 32 + c4 * 4) = v;
         }
         __syncthreads();
-        // wave w contracts pixels [32w, 32w+32) of the tile, two per MFMA (k = lh)
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            const int mm = wave * 32 + 2 * kk + lh;                        // this lane's pixel
-            const int im = mm / (T::TH * T::TW), rem = mm % (T::TH * T::TW);
-            const int hp = (im * T::TH + rem / T::TW) * T::HTW + rem % T::TW;   // tap s adds +s
-            float bv[NB];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) bv[nb] = lds_d[mm * NT + nb * 32 + li];
-#pragma unroll
-            for (int s = 0; s < 5; ++s) {
-                const float av = lds_in[(hp + s) * CS + li];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[s][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[nb], acc[s][nb], 0, 0, 0);
-            }
+        switch (wave) {
+            case 0: wgrad_body<H, 0>(acc, lds_in, lds_d, li, lh); break;
+            case 1: wgrad_body<H, 1>(acc, lds_in, lds_d, li, lh); break;
+            case 2: wgrad_body<H, 2>(acc, lds_in, lds_d, li, lh); break;
+            default: wgrad_body<H, 3>(acc, lds_in, lds_d, li, lh); break;
         }
     }
 
-    // ---- sum the 4 waves' accumulators through LDS (tree: 2,3 -> 0,1 ; 1 -> 0) ----
+    float* out = a.slab + (size_t)split * 25 * CIN * COUT;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int ci = ci0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            out[((size_t)(6 * wave + j) * CIN + ci) * COUT + n0 + li] = acc[j][v];
+        }
+    // tap 24: sum the four waves' partial tiles through LDS, fixed order
     __syncthreads();
-    float* red = smem;                                   // [2][5*NB][16][64]
-    if (wave >= 2) {
-        float* d = red + (wave - 2) * (5 * NB * 1024);
+    if (wave > 0) {
 #pragma unroll
-        for (int s = 0; s < 5; ++s)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) d[((s * NB + nb) * 16 + v) * 64 + lane] = acc[s][nb][v];
-    }
-    __syncthreads();
-    if (wave < 2) {
-        const float* d = red + wave * (5 * NB * 1024);
-#pragma unroll
-        for (int s = 0; s < 5; ++s)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) acc[s][nb][v] += d[((s * NB + nb) * 16 + v) * 64 + lane];
-    }
-    __syncthreads();
-    if (wave == 1) {
-#pragma unroll
-        for (int s = 0; s < 5; ++s)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) red[((s * NB + nb) * 16 + v) * 64 + lane] = acc[s][nb][v];
+        for (int v = 0; v < 16; ++v) smem[((wave - 1) * 16 + v) * 64 + lane] = acc[6][v];
     }
     __syncthreads();
     if (wave == 0) {
-        float* out = a.slab + (size_t)split * 25 * CIN * COUT;
 #pragma unroll
-        for (int s = 0; s < 5; ++s)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float x = acc[s][nb][v] + red[((s * NB + nb) * 16 + v) * 64 + lane];
-                    const int ci = ci0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-                    out[((size_t)(r * 5 + s) * CIN + ci) * COUT + n0 + nb * 32 + li] = x;
-                }
+        for (int v = 0; v < 16; ++v) {
+            const float x = ((acc[6][v] + smem[v * 64 + lane]) + smem[(16 + v) * 64 + lane]) + smem[(32 + v) * 64 + lane];
+            const int ci = ci0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            out[((size_t)24 * CIN + ci) * COUT + n0 + li] = x;
+        }
     }
 }
 
-// dst[i] = sum_s slab[s][i], fixed order.  n is a multiple of 4 for every conv weight here.
+// dst[i] = sum_s slab[s*stride + i] over s in [s0, s0+cnt), fixed order.  grid (n/4/256, RA): each
+// row-chunk y writes its partial to dst + y*n (two passes when S is large and n small, so that
+// enough loads are in flight to run at HBM speed).
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ dst,
-                                                           int64_t n, int S, int64_t stride) {
+                                                           int64_t n, int S, int64_t stride, int perChunk) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i + 3 < n) {
-        float4 acc = *reinterpret_cast<const float4*>(slab + i);
-        for (int s = 1; s < S; ++s) {
-            const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)s * stride + i);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
-        *reinterpret_cast<float4*>(dst + i) = acc;
-    } else {
-        for (int64_t k = i; k < n; ++k) {
-            float acc = slab[k];
-            for (int s = 1; s < S; ++s) acc += slab[(size_t)s * stride + k];
-            dst[k] = acc;
-        }
+    if (i >= n) return;
+    const int s0 = blockIdx.y * perChunk;
+    int s1 = s0 + perChunk; if (s1 > S) s1 = S;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int s = s0; s < s1; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)s * stride + i);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
+    *reinterpret_cast<float4*>(dst + (size_t)blockIdx.y * n + i) = acc;
 }
 
-// `stride` (floats between consecutive slabs) and `slab` must keep 16-byte alignment.
-int launch_reduce_slabs(const float* slab, float* dst, int64_t n, int S, int64_t stride, hipStream_t st) {
-    const int64_t threads = (n + 3) / 4;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
-                       slab, dst, n, S, stride);
+// `slab`, `stride` and n must keep 16-byte alignment (n % 4 == 0).  When S > 32 a first pass
+// reduces 16 row-chunks into `mid` (16*n floats), a second pass sums those.
+int launch_reduce_slabs(const float* slab, float* dst, int64_t n, int S, int64_t stride, hipStream_t st, float* mid) {
+    const unsigned gx = (unsigned)((n / 4 + 255) / 256);
+    if (mid != nullptr && S > 32) {
+        const int RA = 16, per = cdiv(S, RA), ra = cdiv(S, per);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, ra), dim3(256), 0, st, slab, mid, n, S, stride, per);
+        CVAE_CHECK_LAUNCH();
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, 1), dim3(256), 0, st, mid, dst, n, ra, n, ra);
+        CVAE_CHECK_LAUNCH();
+        return 0;
+    }
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, 1), dim3(256), 0, st, slab, dst, n, S, stride, S);
     CVAE_CHECK_LAUNCH();
     return 0;
 }
@@ -186,7 +171,7 @@ template <int H>
 static int wgrad_splits(int B, int blocksPerSplit, int* tilesPerSplit) {
     using T = Tile<H>;
     const int numTiles = cdiv(B, T::IMGS) * T::TILES_PER_IMG;
-    int S = cdiv(1536, blocksPerSplit);               // aim at ~6 workgroups per CU
+    int S = cdiv(512, blocksPerSplit);                // aim at ~2 workgroups per CU
     if (S > numTiles) S = numTiles;
     if (S < 1) S = 1;
     const int tps = cdiv(numTiles, S);
@@ -195,42 +180,39 @@ static int wgrad_splits(int B, int blocksPerSplit, int* tilesPerSplit) {
     return S;
 }
 
-template <int CIN, int COUT, int H, bool UP, int NT>
+template <int CIN, int COUT, int H, bool UP>
 static int run_wgrad(int B, const float* in, const float* dout, float* dw, float* ws, hipStream_t st,
                      int64_t* ws_need) {
     using T = Tile<H>;
-    constexpr int NB = NT / 32;
     int tps;
-    const int bps = 5 * (CIN / 32) * (COUT / NT);
+    const int bps = (CIN / 32) * (COUT / 32);
     const int S = wgrad_splits<H>(B, bps, &tps);
     const int64_t n = (int64_t)25 * CIN * COUT;
-    if (ws_need) { *ws_need = (int64_t)S * n; return 0; }
+    if (ws_need) { *ws_need = (int64_t)(S + 16) * n; return 0; }
     WgradArgs a{in, dout, ws, B, cdiv(B, T::IMGS) * T::TILES_PER_IMG, tps};
-    constexpr int IN_FLOATS = T::IMGS * T::TH * T::HTW * 32;
-    constexpr int RED_FLOATS = 2 * 5 * NB * 1024;
-    constexpr int SMEM = ((IN_FLOATS + 128 * NT) > RED_FLOATS ? (IN_FLOATS + 128 * NT) : RED_FLOATS) * 4;
-    auto kern = conv5x5_wgrad_kernel<CIN, COUT, H, UP, NT>;
+    constexpr int SMEM = (T::HP * 32 + 128 * 32) * 4;
+    auto kern = conv5x5_wgrad_kernel<CIN, COUT, H, UP>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(S, 5 * (CIN / 32), COUT / NT), dim3(256), SMEM, st, a);
+    hipLaunchKernelGGL(kern, dim3(S, CIN / 32, COUT / 32), dim3(256), SMEM, st, a);
     CVAE_CHECK_LAUNCH();
-    return launch_reduce_slabs(ws, dw, n, S, n, st);
+    return launch_reduce_slabs(ws, dw, n, S, n, st, ws + (size_t)S * n);
 }
 
 static int dispatch_wgrad(int layer, int width, int B, const float* in, const float* dout, float* dw,
                           float* ws, hipStream_t st, int64_t* need) {
     if (width == 64) {
         switch (layer) {
-            case 1: return run_wgrad<32, 64, 32, false, 32>(B, in, dout, dw, ws, st, need);
-            case 2: return run_wgrad<64, 128, 16, false, 32>(B, in, dout, dw, ws, st, need);
-            case 3: return run_wgrad<128, 256, 8, false, 32>(B, in, dout, dw, ws, st, need);
-            case 4: return run_wgrad<256, 128, 4, false, 32>(B, in, dout, dw, ws, st, need);
-            case 5: return run_wgrad<128, 64, 8, true, 32>(B, in, dout, dw, ws, st, need);
-            case 6: return run_wgrad<64, 32, 16, true, 32>(B, in, dout, dw, ws, st, need);
-            case 7: return run_wgrad<32, 32, 32, true, 32>(B, in, dout, dw, ws, st, need);
+            case 1: return run_wgrad<32, 64, 32, false>(B, in, dout, dw, ws, st, need);
+            case 2: return run_wgrad<64, 128, 16, false>(B, in, dout, dw, ws, st, need);
+            case 3: return run_wgrad<128, 256, 8, false>(B, in, dout, dw, ws, st, need);
+            case 4: return run_wgrad<256, 128, 4, false>(B, in, dout, dw, ws, st, need);
+            case 5: return run_wgrad<128, 64, 8, true>(B, in, dout, dw, ws, st, need);
+            case 6: return run_wgrad<64, 32, 16, true>(B, in, dout, dw, ws, st, need);
+            case 7: return run_wgrad<32, 32, 32, true>(B, in, dout, dw, ws, st, need);
         }
     }
     cvae_set_error("conv_wgrad: unsupported layer %d at width %d", layer, width);

@@ -56,7 +56,7 @@ _SIGS = {
     "cvae_op_scratch_floats": (_i64, [_p, _i32]),
     "cvae_op_bn_partial_floats": (_i64, [_p, _i32, _i32]),
     "cvae_op_msssim_ws_floats": (_i64, [_p, _i32]),
-    "cvae_op_conv_fwd": (C.c_int, [_p, _i32, _i32] + [_p] * 6),
+    "cvae_op_conv_fwd": (C.c_int, [_p, _i32, _i32] + [_p] * 7),
     "cvae_op_conv_dgrad": (C.c_int, [_p, _i32, _i32] + [_p] * 5),
     "cvae_op_conv_wgrad": (C.c_int, [_p, _i32, _i32] + [_p] * 6),
     "cvae_op_d4_bwd": (C.c_int, [_p, _i32] + [_p] * 10),
@@ -167,9 +167,9 @@ class Handle:
     def op_msssim_ws_floats(self, B):
         return self.lib.cvae_op_msssim_ws_floats(self.h, B)
 
-    def op_conv_fwd(self, layer, B, inp, w, bias, out, bn_partials=None):
+    def op_conv_fwd(self, layer, B, inp, w, bias, out, bn_partials=None, scratch=None):
         self._check(self.lib.cvae_op_conv_fwd(self.h, layer, B, _ptr(inp), _ptr(w), _ptr(bias), _ptr(out),
-                                              _ptr(bn_partials), _stream()))
+                                              _ptr(bn_partials), _ptr(scratch), _stream()))
 
     def op_conv_dgrad(self, layer, B, dout, w, mask_src, din):
         self._check(self.lib.cvae_op_conv_dgrad(self.h, layer, B, _ptr(dout), _ptr(w), _ptr(mask_src), _ptr(din),

@@ -123,7 +123,7 @@ int64_t cvae_op_msssim_ws_floats(cvae_handle h, int32_t batch);
 
 /* nn.Conv2d forward (+bias; encoder: raw output + BatchNorm partials; decoder: +ReLU, D4: +Tanh) */
 int cvae_op_conv_fwd(cvae_handle h, int32_t layer, int32_t batch, const float* in, const float* w,
-                     const float* bias, float* out, float* bn_partials, void* stream);
+                     const float* bias, float* out, float* bn_partials, void* scratch, void* stream);
 /* input gradient, layers 1..7; decoder layers 5..7 also fold Upsample backward (2x2 sum) and the
  * ReLU mask of the producing layer's output `mask_src` */
 int cvae_op_conv_dgrad(cvae_handle h, int32_t layer, int32_t batch, const float* dout,

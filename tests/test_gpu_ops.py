@@ -72,7 +72,7 @@ def test_conv_fwd(H, layer, B):
     xin = dev(x) if layer == 0 else nhwc(x)
     out = torch.full((B * h * h * cout,), float("nan"), device="cuda")
     part = torch.zeros(max(H.op_bn_partial_floats(min(layer, 3), B), 1), device="cuda") if layer < 4 else None
-    H.op_conv_fwd(layer, B, xin, wnat(w), dev(b), out, part)
+    H.op_conv_fwd(layer, B, xin, wnat(w), dev(b), out, part, torch.empty(H.op_scratch_floats(B), device="cuda"))
     torch.cuda.synchronize()
     got = out.view(B, cout, h, h).cpu() if layer == 8 else to_nchw(out, B, h, cout)
     check(got, ref, f"conv_fwd L{layer}")

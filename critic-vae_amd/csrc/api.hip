@@ -23,7 +23,7 @@ struct WsLayout {
     int64_t y[4], a[4], coef[4], bnpart[4];
     int64_t zcat, h, o[4];
     int64_t dout4, d_o[4], d_h, d_zcat, d_a[4], d_y[4];
-    int64_t ms, scratch, total;
+    int64_t ms, scratch_w, scratch, total;     // scratch_w: wgrad slabs (side stream); scratch: everything else (last)
 };
 
 struct cvae_handle_s {
@@ -33,7 +33,23 @@ struct cvae_handle_s {
     int K;                       // bottleneck
     // parameter indices
     int enc_w[4], enc_b[4], enc_g[4], enc_be[4], fc_w, fc_b, dec_w[5], dec_b[5], di_w, di_b;
+    // weight-gradient work runs on a lower-priority side stream, off the dgrad critical path
+    hipStream_t side = nullptr;
+    hipEvent_t ev_ready[8] = {}, ev_side = nullptr;
+    bool streams_ready = false;
 };
+
+static int ensure_streams(cvae_handle_s* h) {
+    if (h->streams_ready) return 0;
+    int lo = 0, hi = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = least priority
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo);
+    for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&h->ev_ready[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming);
+    if (e != hipSuccess) { cvae_set_error("side stream setup failed: %s", hipGetErrorString(e)); return (int)e; }
+    h->streams_ready = true;
+    return 0;
+}
 
 static int layer_h(const cvae_handle_s* h, int layer) { return kLayers[layer].h * (h->cfg.width / 64); }
 
@@ -62,10 +78,12 @@ static WsLayout carve(const cvae_handle_s* h, int B) {
     }
     w.dout4 = take((int64_t)B * 3 * W * W);
     w.ms = take(msssim_ws_floats(W, B));
-    int64_t sc = 0;
+    int64_t sc = 0, scw = 0;
     auto mx = [&](int64_t v) { if (v > sc) sc = v; };
-    for (int l = 1; l <= 7; ++l) { mx(wgrad_ws_floats(l, W, B)); mx(conv_fwd_ws_floats(l, W, B)); }
-    mx(e1_wgrad_ws_floats(W, B));
+    for (int l = 1; l <= 7; ++l) { if (wgrad_ws_floats(l, W, B) > scw) scw = wgrad_ws_floats(l, W, B); mx(conv_fwd_ws_floats(l, W, B)); }
+    if (e1_wgrad_ws_floats(W, B) > scw) scw = e1_wgrad_ws_floats(W, B);
+    w.scratch_w = take(scw);
+    mx(scw);                                   // the per-op entry points use one scratch for everything
     mx(d4_bwd_ws_floats(W, B));
     for (int l = 0; l < 4; ++l) { mx(bn_bwd_ws_floats(l, W, B)); mx(bn_fwd_ws_floats(l, W)); }
     mx(fc_ws_floats(W, B));
@@ -112,7 +130,15 @@ int cvae_create(const cvae_config* cfg, cvae_handle* out) {
     return CVAE_OK;
 }
 
-void cvae_destroy(cvae_handle h) { delete h; }
+void cvae_destroy(cvae_handle h) {
+    if (!h) return;
+    if (h->streams_ready) {
+        for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev_ready[i]);
+        (void)hipEventDestroy(h->ev_side);
+        (void)hipStreamDestroy(h->side);
+    }
+    delete h;
+}
 
 int64_t cvae_param_total(cvae_handle h) { return h->param_total; }
 int32_t cvae_param_count(cvae_handle h) { return (int32_t)h->params.size(); }
@@ -219,15 +245,22 @@ int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, c
     const WsLayout w = carve(h, B);
     const int W = h->cfg.width;
     float* sc = ws + w.scratch;
+    float* scw = ws + w.scratch_w;
+    RC(ensure_streams(h));
+    hipStream_t sd = h->side;
+#define HIPRC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cvae_set_error("%s: %s", #call, hipGetErrorString(e_)); return (int)e_; } } while (0)
+    // `ready k` = the gradient a weight-gradient kernel needs exists on the main stream; the side
+    // stream picks it up from there, so dW/db never delay the dgrad chain.
+    int k = 0;
+    auto fork = [&](int idx) -> int { HIPRC(hipEventRecord(h->ev_ready[idx], st)); HIPRC(hipStreamWaitEvent(sd, h->ev_ready[idx], 0)); return 0; };
     // decoder, last layer first
     RC(launch_d4_bwd(W, B, ws + w.o[3], d_recon, recon, P_(h->dec_w[4]), ws + w.dout4, ws + w.d_o[3],
                      G_(h->dec_w[4]), G_(h->dec_b[4]), sc, st));
     for (int i = 3; i >= 0; --i) {
         const int l = 4 + i;
-        const int64_t H = layer_h(h, l);
         const float* in = i == 0 ? ws + w.h : ws + w.o[i - 1];
-        RC(launch_conv_wgrad(l, W, B, in, ws + w.d_o[i], G_(h->dec_w[i]), sc, st));
-        RC(launch_colsum(ws + w.d_o[i], (int64_t)B * H * H, kLayers[l].cout, G_(h->dec_b[i]), sc, st));
+        RC(fork(k++));
+        RC(launch_conv_wgrad(l, W, B, in, ws + w.d_o[i], G_(h->dec_w[i]), G_(h->dec_b[i]), scw, sd));
         RC(launch_conv_dgrad(l, W, B, ws + w.d_o[i], P_(h->dec_w[i]), i == 0 ? nullptr : ws + w.o[i - 1],
                              i == 0 ? ws + w.d_h : ws + w.d_o[i - 1], st));
     }
@@ -238,14 +271,18 @@ int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, c
     // encoder
     for (int l = 3; l >= 0; --l) {
         RC(launch_bn_pool_act_bwd(l, W, B, ws + w.y[l], ws + w.a[l], ws + w.d_a[l], ws + w.coef[l], P_(h->enc_g[l]),
-                                  ws + w.d_y[l], G_(h->enc_g[l]), G_(h->enc_be[l]), G_(h->enc_b[l]), sc, st));
+                                  ws + w.d_y[l], G_(h->enc_g[l]), G_(h->enc_be[l]), nullptr, sc, st));
+        RC(fork(k++));
         if (l == 0) {
-            RC(launch_e1_wgrad(W, B, x, ws + w.d_y[0], G_(h->enc_w[0]), sc, st));
+            RC(launch_e1_wgrad(W, B, x, ws + w.d_y[0], G_(h->enc_w[0]), G_(h->enc_b[0]), scw, sd));
         } else {
-            RC(launch_conv_wgrad(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), sc, st));
+            RC(launch_conv_wgrad(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd));
             RC(launch_conv_dgrad(l, W, B, ws + w.d_y[l], P_(h->enc_w[l]), nullptr, ws + w.d_a[l - 1], st));
         }
     }
+    HIPRC(hipEventRecord(h->ev_side, sd));              // join: grads are complete on the caller's stream
+    HIPRC(hipStreamWaitEvent(st, h->ev_side, 0));
+#undef HIPRC
     return 0;
 }
 
@@ -279,13 +316,8 @@ int cvae_op_conv_wgrad(cvae_handle h, int32_t layer, int32_t B, const float* in,
     const int W = h->cfg.width;
     hipStream_t st = (hipStream_t)stream;
     float* sc = (float*)scratch;
-    if (layer == 0) return launch_e1_wgrad(W, B, in, dout, dw, sc, st);
-    RC(launch_conv_wgrad(layer, W, B, in, dout, dw, sc, st));
-    if (dbias) {
-        const int64_t H = layer_h(h, layer);
-        RC(launch_colsum(dout, (int64_t)B * H * H, kLayers[layer].cout, dbias, sc, st));
-    }
-    return 0;
+    if (layer == 0) return launch_e1_wgrad(W, B, in, dout, dw, dbias, sc, st);
+    return launch_conv_wgrad(layer, W, B, in, dout, dw, dbias, sc, st);
 }
 
 int cvae_op_d4_bwd(cvae_handle h, int32_t B, const float* o3, const float* d_recon, const float* recon, const float* wt,

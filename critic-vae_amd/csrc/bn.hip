@@ -256,5 +256,6 @@ int launch_bn_pool_act_bwd(int layer, int width, int B, const float* y, const fl
     if (g.act) hipLaunchKernelGGL((bn_bwd_kernel<1, 1>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, bcoef, dy, part, g.C, g.H, totalPx, ppb);
     else hipLaunchKernelGGL((bn_bwd_kernel<0, 1>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, bcoef, dy, part, g.C, g.H, totalPx, ppb);
     CVAE_CHECK_LAUNCH();
-    return launch_col_reduce(part, nblk, g.C, g.C, dbias, crws, st);
+    if (dbias) return launch_col_reduce(part, nblk, g.C, g.C, dbias, crws, st);   // else: the wgrad kernel provides it
+    return 0;
 }

@@ -69,7 +69,7 @@ int launch_conv_dgrad(int layer, int width, int B, const float* dout, const floa
 // conv_wgrad.hip
 int64_t wgrad_ws_floats(int layer, int width, int B);
 int launch_conv_wgrad(int layer, int width, int B, const float* in, const float* dout, float* dw,
-                      float* ws, hipStream_t st);
+                      float* dbias, float* ws, hipStream_t st);
 int launch_reduce_slabs(const float* slab, float* dst, int64_t n, int S, int64_t stride, hipStream_t st,
                         float* mid = nullptr);
 int launch_colsum(const float* src, int64_t rows, int C, float* dst, float* ws, hipStream_t st);
@@ -80,7 +80,7 @@ int launch_col_reduce(const float* in, int R, int W, int64_t stride, float* out,
 // conv_thin.hip (E1 / D4)
 int launch_e1_fwd(int width, int B, const float* x, const float* w, const float* bias, float* y,
                   float* bnpart, hipStream_t st);
-int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw, float* ws,
+int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw, float* dbias, float* ws,
                     hipStream_t st);
 int64_t e1_wgrad_ws_floats(int width, int B);
 int launch_d4_fwd(int width, int B, const float* in, const float* w, const float* bias, float* recon,

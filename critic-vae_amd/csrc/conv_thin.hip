@@ -73,7 +73,7 @@ struct ThinWgradArgs {
 };
 
 // sum acc[3] over the 4 waves (through LDS, fixed order) and write the block's slab
-__device__ __forceinline__ void thin_slab_out(f32x16 (&acc)[3], float* red, float* slab_blk) {
+__device__ __forceinline__ void thin_slab_out(f32x16 (&acc)[3], float* red, float* slab_blk, float bsum = 0.f, bool with_bias = false) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
     __syncthreads();
     if (wave > 0) {
@@ -92,8 +92,12 @@ __device__ __forceinline__ void thin_slab_out(f32x16 (&acc)[3], float* red, floa
 #pragma unroll
                 for (int w2 = 0; w2 < 3; ++w2) x += red[((w2 * 3 + mb) * 16 + v) * 64 + lane];
                 const int k = mb * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-                slab_blk[k * 32 + li] = x;
+                if (!(with_bias && k == 75)) slab_blk[k * 32 + li] = x;
             }
+        if (with_bias) {                       // row 75 of the slab carries the bias-gradient partial
+            bsum += __shfl_xor(bsum, 32, 64);
+            if (lh == 0) slab_blk[75 * 32 + li] = bsum;
+        }
     }
 }
 
@@ -114,6 +118,7 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
         aoff[mb] = k >= 75 ? 0 : (k % 3) * T::PS + ((k / 3) / 5) * T::HTW + (k / 3) % 5;
     }
     f32x16 acc[3];
+    float bsum = 0.f;
 #pragma unroll
     for (int mb = 0; mb < 3; ++mb)
 #pragma unroll
@@ -137,12 +142,19 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
             const int mm = wave * 32 + 2 * kk + lh;
             const int poff = (mm / T::TW) * T::HTW + mm % T::TW;
             const float bv = lds_d[mm * 32 + li];
+            bsum += bv;
 #pragma unroll
             for (int mb = 0; mb < 3; ++mb)
                 acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds_x[aoff[mb] + poff], bv, acc[mb], 0, 0, 0);
         }
     }
-    thin_slab_out(acc, smem, a.slab + (size_t)blockIdx.x * 96 * 32);
+    // each wave summed its own 32 pixels per tile: total over the 4 waves
+    __shared__ float bred[4][32];
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (lh == 0) bred[wave][li] = bsum;
+    __syncthreads();
+    bsum = 0.5f * ((bred[0][li] + bred[1][li]) + (bred[2][li] + bred[3][li]));   // thin_slab_out re-adds lane halves
+    thin_slab_out(acc, smem, a.slab + (size_t)blockIdx.x * 96 * 32, bsum, true);
 }
 
 // dst (W4 [tap][ci][co]) <- reduced slab row (k = tap*3+co, col ci)
@@ -172,14 +184,18 @@ int launch_e1_fwd(int width, int B, const float* x, const float* w, const float*
     return 0;
 }
 
-int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw, float* ws, hipStream_t st) {
+int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw, float* dbias, float* ws, hipStream_t st) {
     if (width != 64) { cvae_set_error("e1_wgrad: width %d unsupported", width); return -2; }
     int tps; const int tiles = B * Tile<64>::TILES_PER_IMG;
     const int S = thin_splits(tiles, &tps);
     ThinWgradArgs a{x, dy, nullptr, nullptr, ws, B, tiles, tps};
     hipLaunchKernelGGL(e1_wgrad_kernel<64>, dim3(S), dim3(256), 0, st, a);
     CVAE_CHECK_LAUNCH();
-    return launch_col_reduce(ws, S, 2400, 3072, dw, ws + (size_t)S * 3072, st);
+    if (dbias == dw + 2432)                   // flat buffer: enc0.b sits right after the 64-float-padded enc0.w
+        return launch_col_reduce(ws, S, 2432, 3072, dw, ws + (size_t)S * 3072, st);
+    int rc = launch_col_reduce(ws, S, 2400, 3072, dw, ws + (size_t)S * 3072, st);
+    if (rc || !dbias) return rc;
+    return launch_col_reduce(ws + 2400, S, 32, 3072, dbias, ws + (size_t)S * 3072, st);
 }
 
 // ------------------------------------------ D4 ------------------------------------------------

@@ -16,7 +16,7 @@
 struct WgradArgs {
     const float* in;
     const float* dout;
-    float* slab;        // [S][25][CIN][COUT]
+    float* slab;        // [S][25*CIN*COUT + COUT]  (weight gradient partials | bias gradient partials)
     int B;
     int numTiles;       // cdiv(B, IMGS) * TILES_PER_IMG
     int tilesPerSplit;
@@ -25,7 +25,7 @@ struct WgradArgs {
 // One wave's share of a staged tile: taps 6W..6W+5 over every pixel, plus tap 24 over rows
 // rho == W (mod 4) (the 25th tap is split over the 4 waves so all MFMA pipes carry 6.25 taps).
 template <int H, int W>
-__device__ __forceinline__ void wgrad_body(f32x16 (&acc)[7], const float* lds_in, const float* lds_d, int li, int lh) {
+__device__ __forceinline__ void wgrad_body(f32x16 (&acc)[7], float& bsum, const float* lds_in, const float* lds_d, int li, int lh) {
     using T = Tile<H>;
     constexpr int CS = 32, R = T::IMGS * T::TH;
     for (int rho = 0; rho < R; ++rho) {
@@ -36,9 +36,9 @@ __device__ __forceinline__ void wgrad_body(f32x16 (&acc)[7], const float* lds_in
 #pragma unroll
         for (int kk = 0; kk < T::TW / 2; ++kk) {
             const float bv = drow[(2 * kk) * 32];
+            if (W == 0) bsum += bv;          // column sums of dout = the conv's bias gradient, for free
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                constexpr int dummy = 0; (void)dummy;
                 const int tap = 6 * W + j, r = tap / 5, s = tap % 5;
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(inrow[(r * T::HTW + s + 2 * kk) * CS], bv, acc[j], 0, 0, 0);
             }
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5_wgrad_kernel(WgradArgs a) {
     constexpr int HS = UP ? H / 2 : H;
 
     f32x16 acc[7];
+    float bsum = 0.f;
 #pragma unroll
     for (int j = 0; j < 7; ++j)
 #pragma unroll
@@ -100,14 +101,18 @@ __global__ __launch_bounds__(256, 2) void conv5x5_wgrad_kernel(WgradArgs a) {
         }
         __syncthreads();
         switch (wave) {
-            case 0: wgrad_body<H, 0>(acc, lds_in, lds_d, li, lh); break;
-            case 1: wgrad_body<H, 1>(acc, lds_in, lds_d, li, lh); break;
-            case 2: wgrad_body<H, 2>(acc, lds_in, lds_d, li, lh); break;
-            default: wgrad_body<H, 3>(acc, lds_in, lds_d, li, lh); break;
+            case 0: wgrad_body<H, 0>(acc, bsum, lds_in, lds_d, li, lh); break;
+            case 1: wgrad_body<H, 1>(acc, bsum, lds_in, lds_d, li, lh); break;
+            case 2: wgrad_body<H, 2>(acc, bsum, lds_in, lds_d, li, lh); break;
+            default: wgrad_body<H, 3>(acc, bsum, lds_in, lds_d, li, lh); break;
         }
     }
 
-    float* out = a.slab + (size_t)split * 25 * CIN * COUT;
+    float* out = a.slab + (size_t)split * (25 * CIN * COUT + COUT);     // slab row: [25][CIN][COUT] | bias[COUT]
+    if (wave == 0 && blockIdx.y == 0) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lh == 0) out[(size_t)25 * CIN * COUT + n0 + li] = bsum;
+    }
 #pragma unroll
     for (int j = 0; j < 6; ++j)
 #pragma unroll
@@ -181,14 +186,14 @@ static int wgrad_splits(int B, int blocksPerSplit, int* tilesPerSplit) {
 }
 
 template <int CIN, int COUT, int H, bool UP>
-static int run_wgrad(int B, const float* in, const float* dout, float* dw, float* ws, hipStream_t st,
+static int run_wgrad(int B, const float* in, const float* dout, float* dw, float* dbias, float* ws, hipStream_t st,
                      int64_t* ws_need) {
     using T = Tile<H>;
     int tps;
     const int bps = (CIN / 32) * (COUT / 32);
     const int S = wgrad_splits<H>(B, bps, &tps);
-    const int64_t n = (int64_t)25 * CIN * COUT;
-    if (ws_need) { *ws_need = (int64_t)(S + 16) * n; return 0; }
+    const int64_t n = (int64_t)25 * CIN * COUT, row = n + COUT;
+    if (ws_need) { *ws_need = (int64_t)(S + 16) * row; return 0; }
     WgradArgs a{in, dout, ws, B, cdiv(B, T::IMGS) * T::TILES_PER_IMG, tps};
     constexpr int SMEM = (T::HP * 32 + 128 * 32) * 4;
     auto kern = conv5x5_wgrad_kernel<CIN, COUT, H, UP>;
@@ -199,20 +204,25 @@ static int run_wgrad(int B, const float* in, const float* dout, float* dw, float
     }
     hipLaunchKernelGGL(kern, dim3(S, CIN / 32, COUT / 32), dim3(256), SMEM, st, a);
     CVAE_CHECK_LAUNCH();
-    return launch_reduce_slabs(ws, dw, n, S, n, st, ws + (size_t)S * n);
+    float* mid = ws + (size_t)S * row;
+    if (dbias == dw + n)                      // flat gradient buffer: bias follows its weight -> one reduction
+        return launch_reduce_slabs(ws, dw, row, S, row, st, mid);
+    int rc = launch_reduce_slabs(ws, dw, n, S, row, st, mid);
+    if (rc || !dbias) return rc;
+    return launch_reduce_slabs(ws + n, dbias, COUT, S, row, st, nullptr);
 }
 
-static int dispatch_wgrad(int layer, int width, int B, const float* in, const float* dout, float* dw,
+static int dispatch_wgrad(int layer, int width, int B, const float* in, const float* dout, float* dw, float* dbias,
                           float* ws, hipStream_t st, int64_t* need) {
     if (width == 64) {
         switch (layer) {
-            case 1: return run_wgrad<32, 64, 32, false>(B, in, dout, dw, ws, st, need);
-            case 2: return run_wgrad<64, 128, 16, false>(B, in, dout, dw, ws, st, need);
-            case 3: return run_wgrad<128, 256, 8, false>(B, in, dout, dw, ws, st, need);
-            case 4: return run_wgrad<256, 128, 4, false>(B, in, dout, dw, ws, st, need);
-            case 5: return run_wgrad<128, 64, 8, true>(B, in, dout, dw, ws, st, need);
-            case 6: return run_wgrad<64, 32, 16, true>(B, in, dout, dw, ws, st, need);
-            case 7: return run_wgrad<32, 32, 32, true>(B, in, dout, dw, ws, st, need);
+            case 1: return run_wgrad<32, 64, 32, false>(B, in, dout, dw, dbias, ws, st, need);
+            case 2: return run_wgrad<64, 128, 16, false>(B, in, dout, dw, dbias, ws, st, need);
+            case 3: return run_wgrad<128, 256, 8, false>(B, in, dout, dw, dbias, ws, st, need);
+            case 4: return run_wgrad<256, 128, 4, false>(B, in, dout, dw, dbias, ws, st, need);
+            case 5: return run_wgrad<128, 64, 8, true>(B, in, dout, dw, dbias, ws, st, need);
+            case 6: return run_wgrad<64, 32, 16, true>(B, in, dout, dw, dbias, ws, st, need);
+            case 7: return run_wgrad<32, 32, 32, true>(B, in, dout, dw, dbias, ws, st, need);
         }
     }
     cvae_set_error("conv_wgrad: unsupported layer %d at width %d", layer, width);
@@ -221,13 +231,13 @@ static int dispatch_wgrad(int layer, int width, int B, const float* in, const fl
 
 int64_t wgrad_ws_floats(int layer, int width, int B) {
     int64_t need = 0;
-    if (dispatch_wgrad(layer, width, B, nullptr, nullptr, nullptr, nullptr, nullptr, &need) != 0) return 0;
+    if (dispatch_wgrad(layer, width, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &need) != 0) return 0;
     return need;
 }
 
-int launch_conv_wgrad(int layer, int width, int B, const float* in, const float* dout, float* dw,
+int launch_conv_wgrad(int layer, int width, int B, const float* in, const float* dout, float* dw, float* dbias,
                       float* ws, hipStream_t st) {
-    return dispatch_wgrad(layer, width, B, in, dout, dw, ws, st, nullptr);
+    return dispatch_wgrad(layer, width, B, in, dout, dw, dbias, ws, st, nullptr);
 }
 
 // --------------------------------------------------------------------------------------------

@@ -8,8 +8,11 @@
 One step = forward + vae_loss + backward + (one RCCL all-reduce of the flat gradient when N>1) +
 Adam, through the C-ABI (critic-vae_amd FusedTrainer), inputs resident in HBM.  Workload =
 BASELINE.json configs[1]: fp32, per-GPU batch 256 (weak scaling: global batch 256*N).
-Rank 0 prints ONE JSON line.  At N=1 it also (a) times the dominant kernel with HIP events on
-the stream it runs on (`roofline`) and (b) times the oracle on the host cores (`cpu_baseline`).
+Rank 0 prints ONE JSON line.  At N=1 it also reports
+  roofline     — the dominant kernel of the step, timed LIVE inside the timed region by a HIP event
+                 pair recorded around each of its launches on the stream it runs on
+                 (cvae_probe_*), priced at its algorithmic FLOPs against the fp32 MFMA peak;
+  cpu_baseline — the oracle's training step timed on the host cores (bounded sample).
 """
 import argparse
 import json
@@ -27,48 +30,18 @@ FLOP_PER_IMG = 1.43762e9          # fwd + dgrad + wgrad of 9 con
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, matrix fp32
 LAYERS = [(3, 32, 64, 0), (32, 64, 32, 0), (64, 128, 16, 0), (128, 256, 8, 0),
           (256, 128, 4, 0), (128, 64, 8, 1), (64, 32, 16, 1), (32, 32, 32, 1), (32, 3, 64, 1)]
+KINDS = ("conv_fwd", "conv_dgrad", "conv_wgrad")
+PROBE_IDS = [k * 9 + l for k in range(3) for l in range(1, 8)]
 
 
 def conv_flops(layer, B):
+    """Algorithmic FLOPs of one pass (forward, dgrad or wgrad) of conv `layer` on B images."""
     cin, cout, h, _ = LAYERS[layer]
     return 2.0 * 25 * cin * cout * h * h * B
 
 
-def time_op(fn, reps=20, warm=3):
-    for _ in range(warm):
-        fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e-3
-
-
-def kernel_probe(vae, B):
-    """HIP-event timing of every single-kernel conv op on the stream the library launches on
-    (torch's current stream).  Returns {name: (seconds, flops)}."""
-    H = vae.handle
-    dev = vae.theta.device
-    out = {}
-    for layer in range(1, 8):
-        cin, cout, h, up = LAYERS[layer]
-        hs = h // 2 if up else h
-        x = torch.rand(B * hs * hs * cin, device=dev)
-        w = torch.rand(25 * cin * cout, device=dev) * 0.01
-        b = torch.zeros(cout, device=dev)
-        y = torch.empty(B * h * h * cout, device=dev)
-        part = torch.empty(max(H.op_bn_partial_floats(min(layer, 3), B), 1), device=dev)
-        sc = torch.empty(H.op_scratch_floats(B), device=dev)
-        out[f"conv_fwd_L{layer}"] = (time_op(lambda: H.op_conv_fwd(layer, B, x, w, b, y, part if layer < 4 else None, sc)),
-                                     conv_flops(layer, B))
-        dy = torch.rand(B * h * h * cout, device=dev)
-        dx = torch.empty(B * hs * hs * cin, device=dev)
-        out[f"conv_dgrad_L{layer}"] = (time_op(lambda: H.op_conv_dgrad(layer, B, dy, w, x if up else None, dx)),
-                                       conv_flops(layer, B))
-        del x, w, y, dy, dx
-    return out
+def probe_name(pid):
+    return f"{KINDS[pid // 9]}_L{pid % 9}"
 
 
 def cpu_baseline(B, steps=5):
@@ -122,9 +95,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     B = args.batch
+    probing = rank == 0 and world == 1 and not args.no_probe
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     vae = VariationalAutoencoder(max_batch=B, seed=0).to(dev)
     tr = FusedTrainer(vae, world_size=world)
+    H = vae.handle
     # synthetic inputs, resident in HBM before the timed region; each rank its own shard
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     pool = [(torch.rand(B, 3, 64, 64, device=dev, generator=gen), torch.rand(B, 1, device=dev, generator=gen),
@@ -134,14 +113,23 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    def note(msg):
-        if rank == 0:
-            print(f"[bench] {msg}", file=sys.stderr, flush=True)
-
     note(f"model ready, batch {B}/GPU, world {world}")
+    dominant, survey = None, {}
+    n_survey = min(3, args.warmup) if probing else 0
     for i in range(args.warmup):
+        if probing and i == args.warmup - n_survey:
+            torch.cuda.synchronize()
+            H.probe_config(PROBE_IDS)                 # last warm-up steps: time every conv kernel in-step
         tr.step(*pool[i % len(pool)])
     torch.cuda.synchronize()
+    if probing and n_survey:
+        for pid in PROBE_IDS:
+            ms = H.probe_read(pid)
+            if ms:
+                survey[pid] = sum(ms) / len(ms)
+        dominant = max(survey, key=survey.get)
+        H.probe_config([dominant])                    # timed region: only the dominant kernel
+        note(f"dominant kernel {probe_name(dominant)} ({survey[dominant] * 1e3:.1f} us)")
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -166,18 +154,20 @@ def main():
                    "final_loss": loss, "loss_finite": bool(loss == loss and abs(loss) != float("inf"))},
     }
     if rank == 0 and world == 1:
-        tflops = B * args.steps / dt * FLOP_PER_IMG / 1e12
-        res["config"]["whole_step_algorithmic_TFLOPs"] = round(tflops, 2)
-        if not args.no_probe:
-            probe = kernel_probe(vae, B)
-            note("kernel probe done")
-            name = max(probe, key=lambda k: probe[k][0])
-            sec, fl = probe[name]
-            res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(fl / sec / 1e12, 2),
-                               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                               "avg_launch_us": round(sec * 1e6, 2),
-                               "all_kernels_TFLOPs": {k: round(f / s / 1e12, 1) for k, (s, f) in probe.items()}}
+        res["config"]["whole_step_algorithmic_TFLOPs"] = round(B * args.steps / dt * FLOP_PER_IMG / 1e12, 2)
+        if dominant is not None:
+            ms = H.probe_read(dominant)
+            H.probe_config([])
+            sec = sum(ms) / len(ms) * 1e-3
+            fl = conv_flops(dominant % 9, B)
+            res["roofline"] = {
+                "bound": "mfma", "kernel": probe_name(dominant), "achieved": round(fl / sec / 1e12, 2),
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "avg_launch_us": round(sec * 1e6, 2), "launches_timed": len(ms),
+                "algorithmic_flops_per_launch": fl,
+                "in_step_TFLOPs_all_conv_kernels": {probe_name(k): round(conv_flops(k % 9, B) / (v * 1e-3) / 1e12, 1)
+                                                    for k, v in sorted(survey.items())}}
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(B)
     if rank == 0:

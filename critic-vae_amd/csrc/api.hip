@@ -17,12 +17,27 @@ void cvae_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- in-step kernel probe: ids = kind*9 + layer, kind 0 fwd / 1 dgrad / 2 wgrad ----
+static constexpr int PROBE_IDS = 27, PROBE_CAP = 128;
+struct ProbeSlot { hipEvent_t e0[PROBE_CAP], e1[PROBE_CAP]; int n = 0; bool made = false; };
+struct ProbeState { uint32_t mask = 0; ProbeSlot slot[PROBE_IDS]; };
+static thread_local ProbeSlot* g_probe_cur = nullptr;
+void cvae_probe_begin(hipStream_t st) {
+    ProbeSlot* p = g_probe_cur;
+    if (p && p->n < PROBE_CAP) (void)hipEventRecord(p->e0[p->n], st);
+}
+void cvae_probe_end(hipStream_t st) {
+    ProbeSlot* p = g_probe_cur;
+    if (p && p->n < PROBE_CAP) { (void)hipEventRecord(p->e1[p->n], st); p->n++; }
+}
+
 struct ParamEntry { std::string name; int64_t offset, numel; };
 
 struct WsLayout {
     int64_t y[4], a[4], coef[4], bnpart[4];
     int64_t zcat, h, o[4];
     int64_t dout4, d_o[4], d_h, d_zcat, d_a[4], d_y[4];
+    int64_t wc[3];             // phase-collapsed weights of D1..D3 (rebuilt every forward)
     int64_t ms, scratch_w, scratch, total;     // scratch_w: wgrad slabs (side stream); scratch: everything else (last)
 };
 
@@ -37,6 +52,15 @@ struct cvae_handle_s {
     hipStream_t side = nullptr;
     hipEvent_t ev_ready[8] = {}, ev_side = nullptr;
     bool streams_ready = false;
+    ProbeState probe;
+};
+
+struct ProbeArm {      // RAII: arm the slot of (kind, layer) for the launches inside the scope
+    ProbeArm(cvae_handle_s* h, int kind, int layer) {
+        const int id = kind * 9 + layer;
+        g_probe_cur = (h->probe.mask >> id) & 1u ? &h->probe.slot[id] : nullptr;
+    }
+    ~ProbeArm() { g_probe_cur = nullptr; }
 };
 
 static int ensure_streams(cvae_handle_s* h) {
@@ -77,13 +101,15 @@ static WsLayout carve(const cvae_handle_s* h, int B) {
         w.d_o[i] = take(B * H * H * C);
     }
     w.dout4 = take((int64_t)B * 3 * W * W);
+    for (int i = 0; i < 3; ++i) w.wc[i] = take(conv_up_wc_floats(5 + i));
     w.ms = take(msssim_ws_floats(W, B));
     int64_t sc = 0, scw = 0;
     auto mx = [&](int64_t v) { if (v > sc) sc = v; };
-    for (int l = 1; l <= 7; ++l) { if (wgrad_ws_floats(l, W, B) > scw) scw = wgrad_ws_floats(l, W, B); mx(conv_fwd_ws_floats(l, W, B)); }
+    for (int l = 1; l <= 4; ++l) { if (wgrad_ws_floats(l, W, B) > scw) scw = wgrad_ws_floats(l, W, B); mx(conv_fwd_ws_floats(l, W, B)); }
+    for (int l = 5; l <= 7; ++l) { if (conv_up_wgrad_ws_floats(l, W, B) > scw) scw = conv_up_wgrad_ws_floats(l, W, B); mx(conv_up_ws_floats(l, W, B)); }
     if (e1_wgrad_ws_floats(W, B) > scw) scw = e1_wgrad_ws_floats(W, B);
     w.scratch_w = take(scw);
-    mx(scw);                                   // the per-op entry points use one scratch for everything
+    mx(scw + 36 * 128 * 64);                   // per-op entry points: one scratch = [collapsed W | everything else]
     mx(d4_bwd_ws_floats(W, B));
     for (int l = 0; l < 4; ++l) { mx(bn_bwd_ws_floats(l, W, B)); mx(bn_fwd_ws_floats(l, W)); }
     mx(fc_ws_floats(W, B));
@@ -194,7 +220,7 @@ int cvae_forward(cvae_handle h, int32_t B, const float* x, const float* pred, co
     const int W = h->cfg.width;
     for (int l = 0; l < 4; ++l) {
         if (l == 0) RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], ws + w.bnpart[0], st));
-        else RC(launch_conv_fwd(l, W, B, ws + w.a[l - 1], P_(h->enc_w[l]), P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st));
+        else { ProbeArm pa(h, 0, l); RC(launch_conv_fwd(l, W, B, ws + w.a[l - 1], P_(h->enc_w[l]), P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st)); }
         RC(launch_bn_fwd_finalize(l, W, B, ws + w.bnpart[l], P_(h->enc_g[l]), P_(h->enc_be[l]), bn_state + kBnOff[l],
                                   bn_state + 480 + kBnOff[l], ws + w.coef[l], ws + w.scratch, train, st));
         RC(launch_bn_pool_act_fwd(l, W, B, ws + w.y[l], ws + w.coef[l], ws + w.a[l], st));
@@ -217,8 +243,15 @@ int cvae_decode(cvae_handle h, int32_t B, const float* zcat, const float* params
         if (e != hipSuccess) { cvae_set_error("cvae_decode: copy failed: %s", hipGetErrorString(e)); return (int)e; }
     }
     RC(launch_decin_fwd(W, B, ws + w.zcat, P_(h->di_w), P_(h->di_b), ws + w.h, st));
-    for (int i = 0; i < 4; ++i)
-        RC(launch_conv_fwd(4 + i, W, B, i == 0 ? ws + w.h : ws + w.o[i - 1], P_(h->dec_w[i]), P_(h->dec_b[i]), ws + w.o[i], nullptr, ws + w.scratch, st));
+    for (int i = 0; i < 4; ++i) {
+        ProbeArm pa(h, 0, 4 + i);
+        if (i == 0) {
+            RC(launch_conv_fwd(4, W, B, ws + w.h, P_(h->dec_w[0]), P_(h->dec_b[0]), ws + w.o[0], nullptr, ws + w.scratch, st));
+        } else {          // Upsample -> Conv at the low resolution with phase-collapsed weights
+            RC(launch_collapse_w(4 + i, P_(h->dec_w[i]), ws + w.wc[i - 1], st));
+            RC(launch_conv_up_fwd(4 + i, W, B, ws + w.o[i - 1], ws + w.wc[i - 1], P_(h->dec_b[i]), ws + w.o[i], ws + w.scratch, st));
+        }
+    }
     RC(launch_d4_fwd(W, B, ws + w.o[3], P_(h->dec_w[4]), P_(h->dec_b[4]), recon, st));
     return 0;
 }
@@ -246,13 +279,21 @@ int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, c
     const int W = h->cfg.width;
     float* sc = ws + w.scratch;
     float* scw = ws + w.scratch_w;
-    RC(ensure_streams(h));
-    hipStream_t sd = h->side;
+    // cfg.reserved0 != 0: weight-gradient work on a lower-priority side stream (+3% at B=256, but
+    // per-kernel timings then overlap); default: everything in order on the caller's stream.
+    const bool overlap = h->cfg.reserved0 != 0;
+    if (overlap) RC(ensure_streams(h));
+    hipStream_t sd = overlap ? h->side : st;
 #define HIPRC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cvae_set_error("%s: %s", #call, hipGetErrorString(e_)); return (int)e_; } } while (0)
     // `ready k` = the gradient a weight-gradient kernel needs exists on the main stream; the side
     // stream picks it up from there, so dW/db never delay the dgrad chain.
     int k = 0;
-    auto fork = [&](int idx) -> int { HIPRC(hipEventRecord(h->ev_ready[idx], st)); HIPRC(hipStreamWaitEvent(sd, h->ev_ready[idx], 0)); return 0; };
+    auto fork = [&](int idx) -> int {
+        if (!overlap) return 0;
+        HIPRC(hipEventRecord(h->ev_ready[idx], st));
+        HIPRC(hipStreamWaitEvent(sd, h->ev_ready[idx], 0));
+        return 0;
+    };
     // decoder, last layer first
     RC(launch_d4_bwd(W, B, ws + w.o[3], d_recon, recon, P_(h->dec_w[4]), ws + w.dout4, ws + w.d_o[3],
                      G_(h->dec_w[4]), G_(h->dec_b[4]), sc, st));
@@ -260,9 +301,13 @@ int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, c
         const int l = 4 + i;
         const float* in = i == 0 ? ws + w.h : ws + w.o[i - 1];
         RC(fork(k++));
-        RC(launch_conv_wgrad(l, W, B, in, ws + w.d_o[i], G_(h->dec_w[i]), G_(h->dec_b[i]), scw, sd));
-        RC(launch_conv_dgrad(l, W, B, ws + w.d_o[i], P_(h->dec_w[i]), i == 0 ? nullptr : ws + w.o[i - 1],
-                             i == 0 ? ws + w.d_h : ws + w.d_o[i - 1], st));
+        if (i == 0) {
+            { ProbeArm pa(h, 2, l); RC(launch_conv_wgrad(l, W, B, in, ws + w.d_o[0], G_(h->dec_w[0]), G_(h->dec_b[0]), scw, sd)); }
+            { ProbeArm pa(h, 1, l); RC(launch_conv_dgrad(l, W, B, ws + w.d_o[0], P_(h->dec_w[0]), nullptr, ws + w.d_h, st)); }
+        } else {
+            { ProbeArm pa(h, 2, l); RC(launch_conv_up_wgrad(l, W, B, in, ws + w.d_o[i], G_(h->dec_w[i]), G_(h->dec_b[i]), scw, sd)); }
+            { ProbeArm pa(h, 1, l); RC(launch_conv_up_dgrad(l, W, B, ws + w.d_o[i], ws + w.wc[i - 1], ws + w.o[i - 1], ws + w.d_o[i - 1], sc, st)); }
+        }
     }
     // latent
     RC(launch_decin_bwd(W, B, ws + w.zcat, ws + w.d_h, P_(h->di_w), G_(h->di_w), G_(h->di_b), ws + w.d_zcat, sc, st));
@@ -276,12 +321,14 @@ int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, c
         if (l == 0) {
             RC(launch_e1_wgrad(W, B, x, ws + w.d_y[0], G_(h->enc_w[0]), G_(h->enc_b[0]), scw, sd));
         } else {
-            RC(launch_conv_wgrad(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd));
-            RC(launch_conv_dgrad(l, W, B, ws + w.d_y[l], P_(h->enc_w[l]), nullptr, ws + w.d_a[l - 1], st));
+            { ProbeArm pa(h, 2, l); RC(launch_conv_wgrad(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd)); }
+            { ProbeArm pa(h, 1, l); RC(launch_conv_dgrad(l, W, B, ws + w.d_y[l], P_(h->enc_w[l]), nullptr, ws + w.d_a[l - 1], st)); }
         }
     }
-    HIPRC(hipEventRecord(h->ev_side, sd));              // join: grads are complete on the caller's stream
-    HIPRC(hipStreamWaitEvent(st, h->ev_side, 0));
+    if (overlap) {                                      // join: grads are complete on the caller's stream
+        HIPRC(hipEventRecord(h->ev_side, sd));
+        HIPRC(hipStreamWaitEvent(st, h->ev_side, 0));
+    }
 #undef HIPRC
     return 0;
 }
@@ -292,17 +339,61 @@ int cvae_adam_step(cvae_handle h, float* params, const float* grads, float* exp_
     return launch_adam(params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream);
 }
 
+// ---- probe API: bracket chosen conv kernels of the real step with HIP events (bench.py roofline) ----
+int cvae_probe_config(cvae_handle h, uint32_t mask) {
+    if (!h) return CVAE_EINVAL;
+    for (int id = 0; id < PROBE_IDS; ++id) {
+        ProbeSlot& s = h->probe.slot[id];
+        s.n = 0;
+        if (((mask >> id) & 1u) && !s.made) {
+            for (int i = 0; i < PROBE_CAP; ++i) {
+                hipError_t e = hipEventCreate(&s.e0[i]);
+                if (e == hipSuccess) e = hipEventCreate(&s.e1[i]);
+                if (e != hipSuccess) { cvae_set_error("probe event create: %s", hipGetErrorString(e)); return (int)e; }
+            }
+            s.made = true;
+        }
+    }
+    h->probe.mask = mask;
+    return 0;
+}
+
+// elapsed ms of every recorded launch of slot `id` (synchronises on the events); returns the count
+int cvae_probe_read(cvae_handle h, int32_t id, float* ms_host, int32_t cap) {
+    if (!h || id < 0 || id >= PROBE_IDS) return 0;
+    ProbeSlot& s = h->probe.slot[id];
+    int n = 0;
+    for (int i = 0; i < s.n && n < cap; ++i) {
+        if (hipEventSynchronize(s.e1[i]) != hipSuccess) break;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.e0[i], s.e1[i]) != hipSuccess) break;
+        ms_host[n++] = ms;
+    }
+    s.n = 0;
+    return n;
+}
+
 // ------------------------------ per-op entry points ------------------------------
 int cvae_op_conv_fwd(cvae_handle h, int32_t layer, int32_t B, const float* in, const float* wt, const float* bias,
                      float* out, float* bn_partials, void* scratch, void* stream) {
     const int W = h->cfg.width;
     if (layer == 0) return launch_e1_fwd(W, B, in, wt, bias, out, bn_partials, (hipStream_t)stream);
     if (layer == 8) return launch_d4_fwd(W, B, in, wt, bias, out, (hipStream_t)stream);
+    if (layer >= 5) {
+        float* wc = (float*)scratch;
+        RC(launch_collapse_w(layer, wt, wc, (hipStream_t)stream));
+        return launch_conv_up_fwd(layer, W, B, in, wc, bias, out, wc + conv_up_wc_floats(layer), (hipStream_t)stream);
+    }
     return launch_conv_fwd(layer, W, B, in, wt, bias, out, bn_partials, (float*)scratch, (hipStream_t)stream);
 }
 
 int cvae_op_conv_dgrad(cvae_handle h, int32_t layer, int32_t B, const float* dout, const float* wt,
-                       const float* mask_src, float* din, void* stream) {
+                       const float* mask_src, float* din, void* scratch, void* stream) {
+    if (layer >= 5) {
+        float* wc = (float*)scratch;
+        RC(launch_collapse_w(layer, wt, wc, (hipStream_t)stream));
+        return launch_conv_up_dgrad(layer, h->cfg.width, B, dout, wc, mask_src, din, wc + conv_up_wc_floats(layer), (hipStream_t)stream);
+    }
     return launch_conv_dgrad(layer, h->cfg.width, B, dout, wt, mask_src, din, (hipStream_t)stream);
 }
 
@@ -317,6 +408,7 @@ int cvae_op_conv_wgrad(cvae_handle h, int32_t layer, int32_t B, const float* in,
     hipStream_t st = (hipStream_t)stream;
     float* sc = (float*)scratch;
     if (layer == 0) return launch_e1_wgrad(W, B, in, dout, dw, dbias, sc, st);
+    if (layer >= 5) return launch_conv_up_wgrad(layer, W, B, in, dout, dw, dbias, sc, st);
     return launch_conv_wgrad(layer, W, B, in, dout, dw, dbias, sc, st);
 }
 

@@ -47,6 +47,11 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// Optional in-step kernel probe (api.hip): the launchers bracket their MAIN kernel with a HIP event
+// pair on the stream it is launched on when the orchestration armed a slot (bench.py roofline).
+void cvae_probe_begin(hipStream_t st);
+void cvae_probe_end(hipStream_t st);
+
 // error plumbing (api.hip)
 void cvae_set_error(const char* fmt, ...);
 #define CVAE_CHECK_LAUNCH()                                                        \
@@ -89,6 +94,17 @@ int64_t d4_bwd_ws_floats(int width, int B);
 int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const float* recon,
                   const float* w, float* dout, float* d_o3, float* dw, float* db, float* ws,
                   hipStream_t st);
+// conv_up.hip (phase-collapsed Upsample->Conv blocks D1..D3, layers 5..7)
+int64_t conv_up_wc_floats(int layer);
+int launch_collapse_w(int layer, const float* w, float* wc, hipStream_t st);
+int64_t conv_up_ws_floats(int layer, int width, int B);
+int launch_conv_up_fwd(int layer, int width, int B, const float* in, const float* wc, const float* bias,
+                       float* out, float* ws, hipStream_t st);
+int launch_conv_up_dgrad(int layer, int width, int B, const float* dout, const float* wc, const float* aux,
+                         float* din, float* ws, hipStream_t st);
+int64_t conv_up_wgrad_ws_floats(int layer, int width, int B);
+int launch_conv_up_wgrad(int layer, int width, int B, const float* in, const float* dout, float* dw,
+                         float* dbias, float* ws, hipStream_t st);
 // bn.hip
 int bn_num_tiles(int layer, int width, int B);
 int launch_bn_fwd_finalize(int layer, int width, int B, const float* bnpart, const float* gamma,

@@ -187,7 +187,9 @@ static int run(const ConvArgs& a, hipStream_t st) {
     using T = Tile<H>;
     static_assert(KCH % KC == 0 && NCH % NT == 0, "channel tiling");
     dim3 grid(cdiv(a.B, T::IMGS) * T::TILES_PER_IMG, NCH / NT, KSPLIT);
+    cvae_probe_begin(st);
     hipLaunchKernelGGL((conv5x5_mfma_kernel<KCH, NCH, H, UP, DGRAD, NT, EPI, KSPLIT>), grid, dim3(256), 0, st, a);
+    cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();
     return 0;
 }

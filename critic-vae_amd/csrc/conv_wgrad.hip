@@ -202,7 +202,9 @@ static int run_wgrad(int B, const float* in, const float* dout, float* dw, float
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         attr_set = true;
     }
+    cvae_probe_begin(st);
     hipLaunchKernelGGL(kern, dim3(S, CIN / 32, COUT / 32), dim3(256), SMEM, st, a);
+    cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();
     float* mid = ws + (size_t)S * row;
     if (dbias == dw + n)                      // flat gradient buffer: bias follows its weight -> one reduction

@@ -53,11 +53,13 @@ _SIGS = {
     "cvae_loss": (C.c_int, [_p, _i32] + [_p] * 10),
     "cvae_backward": (C.c_int, [_p, _i32] + [_p] * 12),
     "cvae_adam_step": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _f, _f, _f, _f, _f, _p]),
+    "cvae_probe_config": (C.c_int, [_p, C.c_uint32]),
+    "cvae_probe_read": (C.c_int, [_p, _i32, C.POINTER(C.c_float), _i32]),
     "cvae_op_scratch_floats": (_i64, [_p, _i32]),
     "cvae_op_bn_partial_floats": (_i64, [_p, _i32, _i32]),
     "cvae_op_msssim_ws_floats": (_i64, [_p, _i32]),
     "cvae_op_conv_fwd": (C.c_int, [_p, _i32, _i32] + [_p] * 7),
-    "cvae_op_conv_dgrad": (C.c_int, [_p, _i32, _i32] + [_p] * 5),
+    "cvae_op_conv_dgrad": (C.c_int, [_p, _i32, _i32] + [_p] * 6),
     "cvae_op_conv_wgrad": (C.c_int, [_p, _i32, _i32] + [_p] * 6),
     "cvae_op_d4_bwd": (C.c_int, [_p, _i32] + [_p] * 10),
     "cvae_op_bn_pool_act_fwd": (C.c_int, [_p, _i32, _i32] + [_p] * 9 + [_i32, _p]),
@@ -100,9 +102,9 @@ def _stream():
 class Handle:
     """Opaque library handle + the flat-parameter layout it reports."""
 
-    def __init__(self, width=64, max_batch=256):
+    def __init__(self, width=64, max_batch=256, overlap_wgrad=False):
         self.lib = load()
-        cfg = _Config(width, max_batch, 0, 0)
+        cfg = _Config(width, max_batch, int(bool(overlap_wgrad)), 0)
         h = _p()
         rc = self.lib.cvae_create(C.byref(cfg), C.byref(h))
         self._check(rc)
@@ -157,6 +159,18 @@ class Handle:
         self._check(self.lib.cvae_adam_step(self.h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(),
                                             step, lr, b1, b2, eps, grad_scale, _stream()))
 
+    # ---- in-step kernel probe (bench.py roofline) ----
+    def probe_config(self, ids):
+        mask = 0
+        for i in ids:
+            mask |= 1 << i
+        self._check(self.lib.cvae_probe_config(self.h, mask))
+
+    def probe_read(self, pid, cap=128):
+        buf = (C.c_float * cap)()
+        n = self.lib.cvae_probe_read(self.h, pid, buf, cap)
+        return [buf[i] for i in range(n)]
+
     # ---- per-op entry points (tests, roofline probe) ----
     def op_scratch_floats(self, B):
         return self.lib.cvae_op_scratch_floats(self.h, B)
@@ -171,9 +185,9 @@ class Handle:
         self._check(self.lib.cvae_op_conv_fwd(self.h, layer, B, _ptr(inp), _ptr(w), _ptr(bias), _ptr(out),
                                               _ptr(bn_partials), _ptr(scratch), _stream()))
 
-    def op_conv_dgrad(self, layer, B, dout, w, mask_src, din):
+    def op_conv_dgrad(self, layer, B, dout, w, mask_src, din, scratch=None):
         self._check(self.lib.cvae_op_conv_dgrad(self.h, layer, B, _ptr(dout), _ptr(w), _ptr(mask_src), _ptr(din),
-                                                _stream()))
+                                                _ptr(scratch), _stream()))
 
     def op_conv_wgrad(self, layer, B, inp, dout, dw, dbias, scratch):
         self._check(self.lib.cvae_op_conv_wgrad(self.h, layer, B, _ptr(inp), _ptr(dout), _ptr(dw), _ptr(dbias),

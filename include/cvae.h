@@ -33,7 +33,7 @@ typedef struct cvae_handle_s* cvae_handle;
 typedef struct cvae_config {
     int32_t width;        /* frame width == height: 64 (vae_parameters.py:5); 128 planned      */
     int32_t max_batch;    /* largest per-call batch the workspace is sized for                 */
-    int32_t reserved0;
+    int32_t reserved0;    /* != 0: run weight-gradient kernels on an internal low-priority side stream */
     int32_t reserved1;
 } cvae_config;
 
@@ -111,6 +111,15 @@ int cvae_adam_step(cvae_handle h, float* params, const float* grads, float* exp_
  * "zcat", "h", "d_*" ...) for tests; -1 if unknown */
 int64_t cvae_ws_offset(cvae_handle h, int32_t batch, const char* name);
 
+/*
+ * In-step kernel probe (measurement only): bit (kind*9 + layer) of `mask` arms a HIP event pair
+ * around that conv kernel (kind 0 forward, 1 dgrad, 2 wgrad; layer 1..7) inside cvae_forward /
+ * cvae_backward, recorded on the stream the kernel is launched on.  cvae_probe_read returns the
+ * elapsed milliseconds of each recorded launch (host array) and clears the slot.
+ */
+int cvae_probe_config(cvae_handle h, uint32_t mask);
+int cvae_probe_read(cvae_handle h, int32_t id, float* ms_host, int32_t cap);
+
 /* ---------------------------------------------------------------------------------------- *
  * Per-op entry points (unit tests and the roofline probe in bench.py).  `layer`: 0..3 =
  * encoder conv blocks E1..E4 (vae_nets.py:69,74,79,84), 4..8 = decoder convs D0..D4
@@ -127,7 +136,7 @@ int cvae_op_conv_fwd(cvae_handle h, int32_t layer, int32_t batch, const float* i
 /* input gradient, layers 1..7; decoder layers 5..7 also fold Upsample backward (2x2 sum) and the
  * ReLU mask of the producing layer's output `mask_src` */
 int cvae_op_conv_dgrad(cvae_handle h, int32_t layer, int32_t batch, const float* dout,
-                       const float* w, const float* mask_src, float* din, void* stream);
+                       const float* w, const float* mask_src, float* din, void* scratch, void* stream);
 /* weight (+ optional bias) gradient, layers 0..7 */
 int cvae_op_conv_wgrad(cvae_handle h, int32_t layer, int32_t batch, const float* in,
                        const float* dout, float* dw, float* dbias, void* scratch, void* stream);

@@ -142,7 +142,8 @@ def test_conv_dgrad(H, layer, B):
     src = torch.relu(pre) if up else pre
     orc.conv5x5(src, w, None, upsample_input=bool(up)).backward(dout)
     din = torch.full((B * hs * hs * cin,), float("nan"), device="cuda")
-    H.op_conv_dgrad(layer, B, nhwc(dout), wnat(w), nhwc(src.detach()) if up else None, din)
+    sc = torch.empty(H.op_scratch_floats(B), device="cuda")
+    H.op_conv_dgrad(layer, B, nhwc(dout), wnat(w), nhwc(src.detach()) if up else None, din, sc)
     torch.cuda.synchronize()
     check(to_nchw(din, B, hs, cin), pre.grad, f"conv_dgrad L{layer}", rel=True)
 

@@ -58,17 +58,20 @@ __global__ __launch_bounds__(256) void bn_fwd_reduce_kernel(const float* __restr
     }
 }
 
-// stage B: merge the RA chunk sums (Chan, fp64), emit coef[c] = {scale, shift, mean, invstd}, update running stats
-__global__ void bn_fwd_finalize_kernel(const double* __restrict__ mid, int RA, int C, double N,
-                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                       float* __restrict__ run_mean, float* __restrict__ run_var,
-                                       float* __restrict__ coef, int train) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// stage B: merge the RA chunk sums (fp64), emit coef[c] = {scale, shift, mean, invstd}, update running
+// stats.  32 lanes per channel (RA <= 32), two channels per wave.
+__global__ __launch_bounds__(64) void bn_fwd_finalize_kernel(const double* __restrict__ mid, int RA, int C, double N,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                             float* __restrict__ coef, int train) {
+    const int c = blockIdx.x * 2 + (threadIdx.x >> 5), r = threadIdx.x & 31;
+    double S = 0.0, Q = 0.0, M = 0.0;
+    if (train && r < RA) { S = mid[(size_t)r * 3 * C + c]; Q = mid[(size_t)r * 3 * C + C + c]; M = mid[(size_t)r * 3 * C + 2 * C + c]; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { S += __shfl_xor(S, o, 64); Q += __shfl_xor(Q, o, 64); M += __shfl_xor(M, o, 64); }
+    if (r != 0) return;
     float mean, var;
     if (train) {
-        double S = 0.0, Q = 0.0, M = 0.0;
-        for (int r = 0; r < RA; ++r) { S += mid[(size_t)r * 3 * C + c]; Q += mid[(size_t)r * 3 * C + C + c]; M += mid[(size_t)r * 3 * C + 2 * C + c]; }
         const double mu = S / N;
         double v = (M + Q - S * S / N) / N;          // biased variance
         if (v < 0.0) v = 0.0;
@@ -205,7 +208,7 @@ int launch_bn_fwd_finalize(int layer, int width, int B, const float* bnpart, con
                            ppi, tpi, mid, tpb);
         CVAE_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(g.C, 64)), dim3(64), 0, st, mid, RA, g.C,
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(g.C / 2), dim3(64), 0, st, mid, RA, g.C,
                        (double)B * g.H * g.H, gamma, beta, run_mean, run_var, coef, train);
     CVAE_CHECK_LAUNCH();
     return 0;

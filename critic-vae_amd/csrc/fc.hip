@@ -75,23 +75,32 @@ __global__ __launch_bounds__(256) void decin_fwd_kernel(const float* __restrict_
     *reinterpret_cast<float4*>(h + (size_t)b * K + j) = acc;
 }
 
-// dzcat[b][i] = sum_j dh[b][j] * Wd[i][j]     (one workgroup per image)
+// dzcat[b][i] = sum_j dh[b][j] * Wd[i][j].  One wave = 2 images x all 33 rows of Wd: lanes split K,
+// 66 per-lane partial sums, one shuffle reduction per output at the end (no LDS, no barriers).
 __global__ __launch_bounds__(256) void decin_bwd_dz_kernel(const float* __restrict__ dh, const float* __restrict__ wd,
-                                                           float* __restrict__ dzcat, int K) {
-    __shared__ float red[33][4];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = 0; i < 33; ++i) {
-        float acc = 0.f;
-        for (int j = threadIdx.x * 4; j < K; j += 1024) {
-            const float4 g = *reinterpret_cast<const float4*>(dh + (size_t)b * K + j);
+                                                           float* __restrict__ dzcat, int B, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b0 = (blockIdx.x * 4 + wave) * 2;
+    if (b0 >= B) return;
+    const bool two = b0 + 1 < B;
+    float acc0[33], acc1[33];
+#pragma unroll
+    for (int i = 0; i < 33; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    for (int j = lane * 4; j < K; j += 256) {
+        const float4 g0 = *reinterpret_cast<const float4*>(dh + (size_t)b0 * K + j);
+        const float4 g1 = two ? *reinterpret_cast<const float4*>(dh + (size_t)(b0 + 1) * K + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 33; ++i) {
             const float4 w = *reinterpret_cast<const float4*>(wd + (size_t)i * K + j);
-            acc += (g.x * w.x + g.y * w.y) + (g.z * w.z + g.w * w.w);
+            acc0[i] += (g0.x * w.x + g0.y * w.y) + (g0.z * w.z + g0.w * w.w);
+            acc1[i] += (g1.x * w.x + g1.y * w.y) + (g1.z * w.z + g1.w * w.w);
         }
-        acc = wave_sum(acc);
-        if (lane == 0) red[i][wave] = acc;
     }
-    __syncthreads();
-    if (threadIdx.x < 33) dzcat[b * 33 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+#pragma unroll
+    for (int i = 0; i < 33; ++i) {
+        const float s0 = wave_sum(acc0[i]), s1 = wave_sum(acc1[i]);
+        if (lane == 0) { dzcat[b0 * 33 + i] = s0; if (two) dzcat[(b0 + 1) * 33 + i] = s1; }
+    }
 }
 
 // slab[bs][i][j] (i<33: dWd, i==33: dbd) = sum over the batch slice bs
@@ -194,7 +203,7 @@ int launch_decin_fwd(int width, int B, const float* zcat, const float* wd, const
 int launch_decin_bwd(int width, int B, const float* zcat, const float* dh, const float* wd, float* dwd, float* dbd,
                      float* dzcat, float* ws, hipStream_t st) {
     const int K = bott(width);
-    hipLaunchKernelGGL(decin_bwd_dz_kernel, dim3(B), dim3(256), 0, st, dh, wd, dzcat, K);
+    hipLaunchKernelGGL(decin_bwd_dz_kernel, dim3(cdiv(B, 8)), dim3(256), 0, st, dh, wd, dzcat, B, K);
     CVAE_CHECK_LAUNCH();
     const int S = decin_splits(B), bps = cdiv(B, S);
     hipLaunchKernelGGL(decin_bwd_dw_kernel, dim3(K / 256, S), dim3(256), 0, st, zcat, dh, ws, B, K, bps);

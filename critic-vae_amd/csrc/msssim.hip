@@ -165,35 +165,37 @@ struct MsFinArgs {
     float* d_mu; float* d_logvar;
 };
 
-__device__ __forceinline__ double block_sum_d(double v, double* red) {
-    v = wave_sum_d(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-}
-
-__global__ __launch_bounds__(256) void msssim_finalize_kernel(MsFinArgs a) {
-    __shared__ double red[4];
-    double ssim[5], cs[5];
-    for (int l = 0; l < 5; ++l) {
-        double s0 = 0.0, s1 = 0.0;
-        for (int i = threadIdx.x; i < a.nblk[l]; i += 256) {
-            s0 += (double)a.part[a.partOff[l] + i * 2];
-            s1 += (double)a.part[a.partOff[l] + i * 2 + 1];
+__global__ __launch_bounds__(1024) void msssim_finalize_kernel(MsFinArgs a) {
+    __shared__ double red[11][16];
+    // every thread accumulates all 11 sums (5 x ssim, 5 x cs, KLD) over its strided share, then ONE
+    // block reduction (wave shuffles + 16 wave partials), all in a fixed order
+    double acc[11];
+#pragma unroll
+    for (int q = 0; q < 11; ++q) acc[q] = 0.0;
+#pragma unroll
+    for (int l = 0; l < 5; ++l)
+        for (int i = threadIdx.x; i < a.nblk[l]; i += 1024) {
+            acc[l] += (double)a.part[a.partOff[l] + i * 2];
+            acc[5 + l] += (double)a.part[a.partOff[l] + i * 2 + 1];
         }
-        ssim[l] = block_sum_d(s0, red) / a.count[l];
-        cs[l] = block_sum_d(s1, red) / a.count[l];
-    }
-    double k = 0.0;
-    const float kw = 0.001f, invB = 1.0f / (float)a.B;
-    for (int i = threadIdx.x; i < a.B * 32; i += 256) {
+    const float kw = 0.001f, invB = a.B > 0 ? 1.0f / (float)a.B : 0.f;
+    for (int i = threadIdx.x; i < a.B * 32; i += 1024) {
         const float m = a.mu[i], lv = a.logvar[i], e = expf(lv);
-        k += (double)(1.0f + lv - m * m - e);
+        acc[10] += (double)(1.0f + lv - m * m - e);
         if (a.d_mu) { a.d_mu[i] = kw * m * invB; a.d_logvar[i] = kw * 0.5f * (e - 1.0f) * invB; }
     }
-    k = block_sum_d(k, red);
+#pragma unroll
+    for (int q = 0; q < 11; ++q) {
+        const double v = wave_sum_d(acc[q]);
+        if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        double tot[11];
+        for (int q = 0; q < 11; ++q) { double t = 0.0; for (int wv = 0; wv < 16; ++wv) t += red[q][wv]; tot[q] = t; }
+        double ssim[5], cs[5];
+        for (int l = 0; l < 5; ++l) { ssim[l] = tot[l] / a.count[l]; cs[l] = tot[5 + l] / a.count[l]; }
+        const double k = tot[10];
         const float wts[5] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
         const float p2 = powf((float)ssim[4], wts[4]);
         float out = 1.0f;
@@ -333,7 +335,7 @@ int launch_msssim(int width, int B, const float* img1, const float* img2, const 
     }
     f.mu = mu; f.logvar = logvar; f.B = mu ? B : 0; f.scalars = scalars; f.coef = ws + w.coef;
     f.d_mu = d_mu; f.d_logvar = d_logvar;
-    hipLaunchKernelGGL(msssim_finalize_kernel, dim3(1), dim3(256), 0, st, f);
+    hipLaunchKernelGGL(msssim_finalize_kernel, dim3(1), dim3(1024), 0, st, f);
     CVAE_CHECK_LAUNCH();
     if (!grad) return 0;
     for (int l = 4; l >= 0; --l) {

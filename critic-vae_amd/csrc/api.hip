@@ -132,7 +132,7 @@ const char* cvae_last_error(void) { return g_err; }
 
 int cvae_create(const cvae_config* cfg, cvae_handle* out) {
     if (!cfg || !out) { cvae_set_error("cvae_create: null argument"); return CVAE_EINVAL; }
-    if (cfg->width != 64) { cvae_set_error("cvae_create: width %d not supported yet (64 only)", cfg->width); return CVAE_EUNSUPPORTED; }
+    if (cfg->width != 64 && cfg->width != 128) { cvae_set_error("cvae_create: width %d not supported (64 or 128)", cfg->width); return CVAE_EUNSUPPORTED; }
     cvae_handle_s* h = new cvae_handle_s();
     h->cfg = *cfg;
     h->param_total = 0;

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void splitk_bias_relu_kernel(const float* __re
 
 static constexpr int D0_KSPLIT = 4;
 int64_t conv_fwd_ws_floats(int layer, int width, int B) {
-    if (layer != 4) return 0;
+    if (layer != 4 || width != 64) return 0;
     const int64_t h = kLayers[4].h * (width / 64);
     return (int64_t)D0_KSPLIT * B * h * h * kLayers[4].cout;
 }
@@ -233,9 +233,14 @@ int launch_conv_fwd(int layer, int width, int B, const float* in, const float* w
                 CVAE_CHECK_LAUNCH();
                 return 0;
             }
-            case 5: return run<128, 64, 8, true, false, 32, EPI_BIAS_RELU>(a, st);
-            case 6: return run<64, 32, 16, true, false, 32, EPI_BIAS_RELU>(a, st);
-            case 7: return run<32, 32, 32, true, false, 32, EPI_BIAS_RELU>(a, st);
+        }
+    }
+    if (width == 128) {
+        switch (layer) {
+            case 1: return run<32, 64, 64, false, false, 64, EPI_BIAS_BNSTAT>(a, st);
+            case 2: return run<64, 128, 32, false, false, 64, EPI_BIAS_BNSTAT>(a, st);
+            case 3: return run<128, 256, 16, false, false, 64, EPI_BIAS_BNSTAT>(a, st);
+            case 4: return run<256, 128, 8, false, false, 64, EPI_BIAS_RELU>(a, st);
         }
     }
     cvae_set_error("conv_fwd: unsupported layer %d at width %d", layer, width);
@@ -252,9 +257,14 @@ int launch_conv_dgrad(int layer, int width, int B, const float* dout, const floa
             case 2: return run<128, 64, 16, false, true, 64, EPI_PLAIN>(a, st);
             case 3: return run<256, 128, 8, false, true, 64, EPI_PLAIN>(a, st);
             case 4: return run<128, 256, 4, false, true, 32, EPI_PLAIN>(a, st);
-            case 5: return run<64, 128, 8, false, true, 64, EPI_POOLSUM_MASK>(a, st);
-            case 6: return run<32, 64, 16, false, true, 64, EPI_POOLSUM_MASK>(a, st);
-            case 7: return run<32, 32, 32, false, true, 32, EPI_POOLSUM_MASK>(a, st);
+        }
+    }
+    if (width == 128) {
+        switch (layer) {
+            case 1: return run<64, 32, 64, false, true, 32, EPI_PLAIN>(a, st);
+            case 2: return run<128, 64, 32, false, true, 64, EPI_PLAIN>(a, st);
+            case 3: return run<256, 128, 16, false, true, 64, EPI_PLAIN>(a, st);
+            case 4: return run<128, 256, 8, false, true, 64, EPI_PLAIN>(a, st);
         }
     }
     cvae_set_error("conv_dgrad: unsupported layer %d at width %d", layer, width);

@@ -178,18 +178,20 @@ int64_t e1_wgrad_ws_floats(int width, int B) {
 
 int launch_e1_fwd(int width, int B, const float* x, const float* w, const float* bias, float* y,
                   float* bnpart, hipStream_t st) {
-    if (width != 64) { cvae_set_error("e1_fwd: width %d unsupported", width); return -2; }
-    hipLaunchKernelGGL(e1_fwd_kernel<64>, dim3(B * Tile<64>::TILES_PER_IMG), dim3(256), 0, st, x, w, bias, y, bnpart, B);
+    if (width == 64) hipLaunchKernelGGL(e1_fwd_kernel<64>, dim3(B * Tile<64>::TILES_PER_IMG), dim3(256), 0, st, x, w, bias, y, bnpart, B);
+    else if (width == 128) hipLaunchKernelGGL(e1_fwd_kernel<128>, dim3(B * Tile<128>::TILES_PER_IMG), dim3(256), 0, st, x, w, bias, y, bnpart, B);
+    else { cvae_set_error("e1_fwd: width %d unsupported", width); return -2; }
     CVAE_CHECK_LAUNCH();
     return 0;
 }
 
 int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw, float* dbias, float* ws, hipStream_t st) {
-    if (width != 64) { cvae_set_error("e1_wgrad: width %d unsupported", width); return -2; }
-    int tps; const int tiles = B * Tile<64>::TILES_PER_IMG;
+    if (width != 64 && width != 128) { cvae_set_error("e1_wgrad: width %d unsupported", width); return -2; }
+    int tps; const int tiles = B * (width / 4) * (width / 32);
     const int S = thin_splits(tiles, &tps);
     ThinWgradArgs a{x, dy, nullptr, nullptr, ws, B, tiles, tps};
-    hipLaunchKernelGGL(e1_wgrad_kernel<64>, dim3(S), dim3(256), 0, st, a);
+    if (width == 64) hipLaunchKernelGGL(e1_wgrad_kernel<64>, dim3(S), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(e1_wgrad_kernel<128>, dim3(S), dim3(256), 0, st, a);
     CVAE_CHECK_LAUNCH();
     if (dbias == dw + 2432)                   // flat buffer: enc0.b sits right after the 64-float-padded enc0.w
         return launch_col_reduce(ws, S, 2432, 3072, dw, ws + (size_t)S * 3072, st);
@@ -384,8 +386,9 @@ int64_t d4_bwd_ws_floats(int width, int B) {
 }
 
 int launch_d4_fwd(int width, int B, const float* in, const float* w, const float* bias, float* recon, hipStream_t st) {
-    if (width != 64) { cvae_set_error("d4_fwd: width %d unsupported", width); return -2; }
-    hipLaunchKernelGGL(d4_fwd_kernel<64>, dim3(B * 16), dim3(256), 0, st, in, w, bias, recon, B);
+    if (width == 64) hipLaunchKernelGGL(d4_fwd_kernel<64>, dim3(B * 16), dim3(256), 0, st, in, w, bias, recon, B);
+    else if (width == 128) hipLaunchKernelGGL(d4_fwd_kernel<128>, dim3(B * 64), dim3(256), 0, st, in, w, bias, recon, B);
+    else { cvae_set_error("d4_fwd: width %d unsupported", width); return -2; }
     CVAE_CHECK_LAUNCH();
     return 0;
 }
@@ -393,7 +396,7 @@ int launch_d4_fwd(int width, int B, const float* in, const float* w, const float
 // Fused D4 backward: Tanh backward -> dout planes (B,3,W,W), then d_o3 (ReLU-masked), dW4, db4.
 int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const float* recon, const float* w,
                   float* dout, float* d_o3, float* dw, float* db, float* ws, hipStream_t st) {
-    if (width != 64) { cvae_set_error("d4_bwd: width %d unsupported", width); return -2; }
+    if (width != 64 && width != 128) { cvae_set_error("d4_bwd: width %d unsupported", width); return -2; }
     int tps;
     const int tiles = B * (width / 16) * (width / 32);
     const int S = d4_splits(width, B, &tps);
@@ -405,9 +408,12 @@ int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(d4_bwd_kernel<64>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, D4_BWD_SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(d4_bwd_kernel<128>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, D4_BWD_SMEM);
         attr_set = true;
     }
-    hipLaunchKernelGGL(d4_bwd_kernel<64>, dim3(S), dim3(256), D4_BWD_SMEM, st, a);
+    if (width == 64) hipLaunchKernelGGL(d4_bwd_kernel<64>, dim3(S), dim3(256), D4_BWD_SMEM, st, a);
+    else hipLaunchKernelGGL(d4_bwd_kernel<128>, dim3(S), dim3(256), D4_BWD_SMEM, st, a);
     CVAE_CHECK_LAUNCH();
     float* red = plane_sums + align_up((int64_t)B * 3, 64);
     { int rc = launch_col_reduce(ws, S, 3072, 3072, red, red + 3072, st); if (rc) return rc; }

@@ -449,6 +449,13 @@ int launch_conv_up_fwd(int layer, int width, int B, const float* in, const float
             case 7: return run_up_fwd<32, 32, 16, 1>(B, in, wc, bias, out, ws, st);
         }
     }
+    if (width == 128) {
+        switch (layer) {
+            case 5: return run_up_fwd<128, 64, 8, UP_KS5>(B, in, wc, bias, out, ws, st);
+            case 6: return run_up_fwd<64, 32, 16, UP_KS6>(B, in, wc, bias, out, ws, st);
+            case 7: return run_up_fwd<32, 32, 32, 1>(B, in, wc, bias, out, ws, st);
+        }
+    }
     cvae_set_error("conv_up_fwd: unsupported layer %d at width %d", layer, width);
     return -2;
 }
@@ -460,6 +467,13 @@ int launch_conv_up_dgrad(int layer, int width, int B, const float* dout, const f
             case 5: return run_up_dgrad<128, 64, 4, 64, UP_KS5>(B, dout, wc, aux, din, ws, st);
             case 6: return run_up_dgrad<64, 32, 8, 64, UP_KS6>(B, dout, wc, aux, din, ws, st);
             case 7: return run_up_dgrad<32, 32, 16, 32, 1>(B, dout, wc, aux, din, ws, st);
+        }
+    }
+    if (width == 128) {
+        switch (layer) {
+            case 5: return run_up_dgrad<128, 64, 8, 64, UP_KS5>(B, dout, wc, aux, din, ws, st);
+            case 6: return run_up_dgrad<64, 32, 16, 64, UP_KS6>(B, dout, wc, aux, din, ws, st);
+            case 7: return run_up_dgrad<32, 32, 32, 32, 1>(B, dout, wc, aux, din, ws, st);
         }
     }
     cvae_set_error("conv_up_dgrad: unsupported layer %d at width %d", layer, width);
@@ -505,6 +519,13 @@ static int dispatch_up_wgrad(int layer, int width, int B, const float* in, const
             case 5: return run_up_wgrad<128, 64, 4>(B, in, dout, dw, dbias, ws, st, need);
             case 6: return run_up_wgrad<64, 32, 8>(B, in, dout, dw, dbias, ws, st, need);
             case 7: return run_up_wgrad<32, 32, 16>(B, in, dout, dw, dbias, ws, st, need);
+        }
+    }
+    if (width == 128) {
+        switch (layer) {
+            case 5: return run_up_wgrad<128, 64, 8>(B, in, dout, dw, dbias, ws, st, need);
+            case 6: return run_up_wgrad<64, 32, 16>(B, in, dout, dw, dbias, ws, st, need);
+            case 7: return run_up_wgrad<32, 32, 32>(B, in, dout, dw, dbias, ws, st, need);
         }
     }
     cvae_set_error("conv_up_wgrad: unsupported layer %d at width %d", layer, width);

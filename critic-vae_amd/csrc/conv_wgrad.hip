@@ -222,9 +222,14 @@ static int dispatch_wgrad(int layer, int width, int B, const float* in, const fl
             case 2: return run_wgrad<64, 128, 16, false>(B, in, dout, dw, dbias, ws, st, need);
             case 3: return run_wgrad<128, 256, 8, false>(B, in, dout, dw, dbias, ws, st, need);
             case 4: return run_wgrad<256, 128, 4, false>(B, in, dout, dw, dbias, ws, st, need);
-            case 5: return run_wgrad<128, 64, 8, true>(B, in, dout, dw, dbias, ws, st, need);
-            case 6: return run_wgrad<64, 32, 16, true>(B, in, dout, dw, dbias, ws, st, need);
-            case 7: return run_wgrad<32, 32, 32, true>(B, in, dout, dw, dbias, ws, st, need);
+        }
+    }
+    if (width == 128) {
+        switch (layer) {
+            case 1: return run_wgrad<32, 64, 64, false>(B, in, dout, dw, dbias, ws, st, need);
+            case 2: return run_wgrad<64, 128, 32, false>(B, in, dout, dw, dbias, ws, st, need);
+            case 3: return run_wgrad<128, 256, 16, false>(B, in, dout, dw, dbias, ws, st, need);
+            case 4: return run_wgrad<256, 128, 8, false>(B, in, dout, dw, dbias, ws, st, need);
         }
     }
     cvae_set_error("conv_wgrad: unsupported layer %d at width %d", layer, width);

@@ -71,7 +71,7 @@ template <int S>
 __global__ __launch_bounds__(256) void msssim_fwd_kernel(MsFwdArgs a) {
     using G = MsGeom<S>;
     constexpr int PER_IN = G::PPB * G::HR * G::HC, PER_T = G::PPB * G::HR * S;
-    __shared__ float smem[2 * PER_IN + 5 * PER_T];
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // 2*PER_IN + 5*PER_T floats
     __shared__ float red[8];
     float* lin = smem;
     float* tmp = smem + 2 * PER_IN;
@@ -223,7 +223,7 @@ template <int S>
 __global__ __launch_bounds__(256) void msssim_bwd_kernel(MsBwdArgs a) {
     using G = MsGeom<S>;
     constexpr int PER_IN = G::PPB * G::HR * G::HC, PER_T = G::PPB * G::HR * S;
-    __shared__ float smem[3 * PER_IN + 3 * PER_T];
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // 3*PER_IN + 3*PER_T floats
     float* lin = smem;
     float* tmp = smem + 3 * PER_IN;
     const int plane0 = (blockIdx.x / G::STRIPS) * G::PPB, r0 = (blockIdx.x % G::STRIPS) * G::RS;
@@ -279,9 +279,15 @@ static MsWs ms_carve(int width, int B) {
         if (l > 0) { w.pyrx[l] = take(n); w.pyry[l] = take(n); w.gp[l] = take(n); }
         w.um[l] = take(n); w.u11[l] = take(n); w.u12[l] = take(n);
     }
-    if (width == 64) {
-        w.nblk[0] = ms_blocks<64>(P); w.nblk[1] = ms_blocks<32>(P); w.nblk[2] = ms_blocks<16>(P);
-        w.nblk[3] = ms_blocks<8>(P); w.nblk[4] = ms_blocks<4>(P);
+    for (int l = 0; l < 5; ++l) {
+        switch (width >> l) {
+            case 128: w.nblk[l] = ms_blocks<128>(P); break;
+            case 64: w.nblk[l] = ms_blocks<64>(P); break;
+            case 32: w.nblk[l] = ms_blocks<32>(P); break;
+            case 16: w.nblk[l] = ms_blocks<16>(P); break;
+            case 8: w.nblk[l] = ms_blocks<8>(P); break;
+            default: w.nblk[l] = ms_blocks<4>(P); break;
+        }
     }
     for (int l = 0; l < 5; ++l) w.part[l] = take((int64_t)w.nblk[l] * 2);
     w.coef = take(8);
@@ -292,20 +298,52 @@ int64_t msssim_ws_floats(int width, int B) { return ms_carve(width, B).total; }
 
 template <int S>
 static int ms_fwd(const MsFwdArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(msssim_fwd_kernel<S>, dim3(ms_blocks<S>(a.P)), dim3(256), 0, st, a);
+    using G = MsGeom<S>;
+    constexpr int SMEM = (2 * G::PPB * G::HR * G::HC + 5 * G::PPB * G::HR * S) * 4;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msssim_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); attr = true; }
+    hipLaunchKernelGGL(msssim_fwd_kernel<S>, dim3(ms_blocks<S>(a.P)), dim3(256), SMEM, st, a);
     CVAE_CHECK_LAUNCH();
     return 0;
 }
 template <int S>
 static int ms_bwd(const MsBwdArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(msssim_bwd_kernel<S>, dim3(ms_blocks<S>(a.P)), dim3(256), 0, st, a);
+    using G = MsGeom<S>;
+    constexpr int SMEM = (3 * G::PPB * G::HR * G::HC + 3 * G::PPB * G::HR * S) * 4;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msssim_bwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); attr = true; }
+    hipLaunchKernelGGL(msssim_bwd_kernel<S>, dim3(ms_blocks<S>(a.P)), dim3(256), SMEM, st, a);
     CVAE_CHECK_LAUNCH();
     return 0;
+}
+static int ms_fwd_size(int S, const MsFwdArgs& a, hipStream_t st) {
+    switch (S) {
+        case 128: return ms_fwd<128>(a, st);
+        case 64: return ms_fwd<64>(a, st);
+        case 32: return ms_fwd<32>(a, st);
+        case 16: return ms_fwd<16>(a, st);
+        case 8: return ms_fwd<8>(a, st);
+        case 4: return ms_fwd<4>(a, st);
+    }
+    cvae_set_error("msssim: level size %d unsupported", S);
+    return -2;
+}
+static int ms_bwd_size(int S, const MsBwdArgs& a, hipStream_t st) {
+    switch (S) {
+        case 128: return ms_bwd<128>(a, st);
+        case 64: return ms_bwd<64>(a, st);
+        case 32: return ms_bwd<32>(a, st);
+        case 16: return ms_bwd<16>(a, st);
+        case 8: return ms_bwd<8>(a, st);
+        case 4: return ms_bwd<4>(a, st);
+    }
+    cvae_set_error("msssim: level size %d unsupported", S);
+    return -2;
 }
 
 int launch_msssim(int width, int B, const float* img1, const float* img2, const float* mu, const float* logvar,
                   float* ws, float* scalars, float* d_img1, float* d_mu, float* d_logvar, hipStream_t st) {
-    if (width != 64) { cvae_set_error("msssim: width %d unsupported", width); return -2; }
+    if (width != 64 && width != 128) { cvae_set_error("msssim: width %d unsupported", width); return -2; }
     int rc = ensure_window();
     if (rc) return rc;
     const MsWs w = ms_carve(width, B);
@@ -318,13 +356,7 @@ int launch_msssim(int width, int B, const float* img1, const float* img2, const 
         MsFwdArgs a{lx[l], ly[l], l < 4 ? ws + w.pyrx[l + 1] : nullptr, l < 4 ? ws + w.pyry[l + 1] : nullptr,
                     grad ? ws + w.um[l] : nullptr, grad ? ws + w.u11[l] : nullptr, grad ? ws + w.u12[l] : nullptr,
                     ws + w.part[l], P, l == 4};
-        switch (l) {
-            case 0: rc = ms_fwd<64>(a, st); break;
-            case 1: rc = ms_fwd<32>(a, st); break;
-            case 2: rc = ms_fwd<16>(a, st); break;
-            case 3: rc = ms_fwd<8>(a, st); break;
-            default: rc = ms_fwd<4>(a, st); break;
-        }
+        rc = ms_fwd_size(width >> l, a, st);
         if (rc) return rc;
     }
     MsFinArgs f{};
@@ -341,13 +373,7 @@ int launch_msssim(int width, int B, const float* img1, const float* img2, const 
     for (int l = 4; l >= 0; --l) {
         MsBwdArgs a{ws + w.um[l], ws + w.u11[l], ws + w.u12[l], lx[l], ly[l], l < 4 ? ws + w.gp[l + 1] : nullptr,
                     ws + w.coef + l, l == 0 ? d_img1 : ws + w.gp[l], P};
-        switch (l) {
-            case 0: rc = ms_bwd<64>(a, st); break;
-            case 1: rc = ms_bwd<32>(a, st); break;
-            case 2: rc = ms_bwd<16>(a, st); break;
-            case 3: rc = ms_bwd<8>(a, st); break;
-            default: rc = ms_bwd<4>(a, st); break;
-        }
+        rc = ms_bwd_size(width >> l, a, st);
         if (rc) return rc;
     }
     return 0;

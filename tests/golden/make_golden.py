@@ -30,8 +30,24 @@ from oracle import cvae_oracle as orc           # noqa: E402
 N_SAMPLES = 64
 
 
-def load_reference(params_np):
-    v = vae_nets.VariationalAutoencoder()
+def load_reference(params_np, width=64):
+    """The reference model with the generator's weights.  width 128 (BASELINE.json config 5) is not
+    supported by the unmodified reference (bottleneck=4096 and view(-1,256,4,4) are hard-coded,
+    vae_parameters.py:15, vae_nets.py:144): patch the module constant and the one view()."""
+    if width == 64:
+        v = vae_nets.VariationalAutoencoder()
+    else:
+        side, old = width // 16, vae_nets.bottleneck
+        vae_nets.bottleneck = 256 * side * side
+        try:
+            class Dec(vae_nets.Decoder):
+                def forward(self, z, pred, evalu=False, dim=1):
+                    X = self.decoder_input(torch.cat((z, pred), dim=dim))
+                    return self.model(X.view(-1, 256, side, side))
+            v = vae_nets.VariationalAutoencoder()
+            v.decoder = Dec([32, 64, 128, 256])
+        finally:
+            vae_nets.bottleneck = old
     enc = {k[len("encoder."):]: torch.from_numpy(a.copy()) for k, a in params_np.items()
            if k.startswith("encoder.")}
     dec = {k[len("decoder."):]: torch.from_numpy(a.copy()) for k, a in params_np.items()
@@ -83,12 +99,12 @@ def sample_idx(name, n):
     return np.minimum((u.astype(np.float64) * n).astype(np.int64), n - 1)
 
 
-def step_case(tag, batch, wseed=0, dseed=1234, step=0):
-    params_np = synth.make_params(wseed)
-    x_np, pred_np, eps_np = synth.make_batch(dseed, step, batch)
+def step_case(tag, batch, wseed=0, dseed=1234, step=0, width=64):
+    params_np = synth.make_params(wseed, width)
+    x_np, pred_np, eps_np = synth.make_batch(dseed, step, batch, width)
     x, pred, eps = map(torch.from_numpy, (x_np, pred_np, eps_np))
 
-    v = load_reference(params_np)
+    v = load_reference(params_np, width)
     out, losses = run_reference_step(v, x, pred, eps)
     _, mu, logvar, recon = out
     sims, css = ref_levels(v, recon, x)
@@ -98,7 +114,7 @@ def step_case(tag, batch, wseed=0, dseed=1234, step=0):
     bn = orc.new_bn_state(op)
     o = orc.train_step(op, x, pred, eps, bn_state=bn)
 
-    fx = {"batch": batch, "wseed": wseed, "dseed": dseed, "step": step, "width": 64,
+    fx = {"batch": batch, "wseed": wseed, "dseed": dseed, "step": step, "width": width,
           "mu": mu.detach().numpy(), "logvar": logvar.detach().numpy(),
           "recon_sample": recon.detach().numpy().reshape(-1)[::16].copy(),
           "recon_stats": np.array([recon.min().item(), recon.max().item(),
@@ -202,6 +218,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     step_case("b2", 2)
     step_case("b32", 32)
+    step_case("w128_b2", 2, width=128)
     msssim_cases()
     trajectory_case()
     print("goldens written to", HERE)

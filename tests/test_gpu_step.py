@@ -16,15 +16,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _inputs(dseed, step, B, first=0):
-    x, pred, eps = synth.make_batch(dseed, step, B, first_index=first)
+def _inputs(dseed, step, B, first=0, width=64):
+    x, pred, eps = synth.make_batch(dseed, step, B, width, first_index=first)
     return torch.from_numpy(x), torch.from_numpy(pred), torch.from_numpy(eps)
 
 
-def _model(B, wseed=0):
+def _model(B, wseed=0, width=64):
     assert torch.cuda.is_available()
-    vae = VariationalAutoencoder(max_batch=B, seed=wseed).cuda()
-    vae.load_reference_params(synth.make_params(wseed))
+    vae = VariationalAutoencoder(max_batch=B, seed=wseed, width=width).cuda()
+    vae.load_reference_params(synth.make_params(wseed, width))
     return vae
 
 
@@ -51,12 +51,13 @@ def _grad_check(name, g, want, tol=TOL):
         assert err <= 10 * tol * scale, f"{name}: err {err:.3e} vs max|g| {scale:.3e}"
 
 
-@pytest.mark.parametrize("tag", ["b2", "b32"])
+@pytest.mark.parametrize("tag", ["b2", "b32", "w128_b2"])
 def test_step_matches_reference_fixture_and_oracle(golden_dir, tag):
+    """w128_b2 = BASELINE.json config 5 frame size (128x128; reference patched as in make_golden.py)."""
     fx = np.load(os.path.join(golden_dir, f"step_{tag}.npz"))
-    B = int(fx["batch"])
-    x, pred, eps = _inputs(int(fx["dseed"]), int(fx["step"]), B)
-    vae = _model(B, int(fx["wseed"]))
+    B, W = int(fx["batch"]), int(fx["width"])
+    x, pred, eps = _inputs(int(fx["dseed"]), int(fx["step"]), B, width=W)
+    vae = _model(B, int(fx["wseed"]), W)
     (_, mu, logvar, recon), losses = _step(vae, x, pred, eps)
     # --- against the reference-generated fixture ---
     mu, logvar, recon = mu.detach(), logvar.detach(), recon.detach()
@@ -76,7 +77,7 @@ def test_step_matches_reference_fixture_and_oracle(golden_dir, tag):
         assert np.abs(sd[f"model.{bi}.running_mean"].cpu().numpy() - fx[f"bn_running_mean/{bi}"]).max() < 1e-5
         assert np.abs(sd[f"model.{bi}.running_var"].cpu().numpy() - fx[f"bn_running_var/{bi}"]).max() < 1e-5
     # --- against the oracle, every element of every gradient ---
-    p = orc.to_torch(synth.make_params(int(fx["wseed"])), requires_grad=True)
+    p = orc.to_torch(synth.make_params(int(fx["wseed"]), W), requires_grad=True)
     o = orc.train_step(p, x, pred, eps, bn_state=orc.new_bn_state(p))
     assert (recon.cpu() - o["recon"]).abs().max().item() < TOL
     for name, g in ref_g.items():

@@ -15,15 +15,16 @@ TOL = 2e-6   # same ATen CPU kernels as the reference -> bit-equal here; slack f
 
 
 def _run(fx):
-    params_np = synth.make_params(int(fx["wseed"]))
+    W = int(fx["width"])
+    params_np = synth.make_params(int(fx["wseed"]), W)
     x, pred, eps = map(torch.from_numpy, synth.make_batch(int(fx["dseed"]), int(fx["step"]),
-                                                          int(fx["batch"])))
+                                                          int(fx["batch"]), W))
     p = orc.to_torch(params_np, requires_grad=True)
     bn = orc.new_bn_state(p)
     return p, bn, orc.train_step(p, x, pred, eps, bn_state=bn)
 
 
-@pytest.mark.parametrize("tag", ["b2", "b32"])
+@pytest.mark.parametrize("tag", ["b2", "b32", "w128_b2"])
 def test_step_matches_reference_fixture(golden_dir, tag):
     fx = np.load(os.path.join(golden_dir, f"step_{tag}.npz"))
     p, bn, o = _run(fx)

@@ -22,27 +22,33 @@ struct WgradArgs {
     int tilesPerSplit;
 };
 
-// One wave's share of a staged tile: taps 6W..6W+5 over every pixel, plus tap 24 over rows
+// One wave's share of a staged tile: taps W, W+4, .., W+20 over every pixel, plus tap 24 over rows
 // rho == W (mod 4) (the 25th tap is split over the 4 waves so all MFMA pipes carry 6.25 taps).
+// MFMAs whose two input pixels both fall into the zero padding are skipped (wave-uniform test):
+// at 8x8 / 4x4 images that is 23% / 44% of the work; the interleaved tap assignment keeps the
+// four waves' remaining work balanced.
 template <int H, int W>
-__device__ __forceinline__ void wgrad_body(f32x16 (&acc)[7], float& bsum, const float* lds_in, const float* lds_d, int li, int lh) {
+__device__ __forceinline__ void wgrad_body(f32x16 (&acc)[7], float& bsum, const float* lds_in, const float* lds_d, int li,
+                                           int lh, int ty0, int tx0) {
     using T = Tile<H>;
     constexpr int CS = 32, R = T::IMGS * T::TH;
     for (int rho = 0; rho < R; ++rho) {
-        const int img = rho / T::TH, ty = rho % T::TH;
+        const int img = rho / T::TH, ty = rho % T::TH, gy = ty0 + ty;
         const float* inrow = lds_in + ((img * T::HTH + ty) * T::HTW + lh) * CS + li;
         const float* drow = lds_d + (rho * T::TW + lh) * 32 + li;
-        const bool extra = (rho & 3) == W;
+        const bool extra = (rho & 3) == W && gy + 2 < H;
 #pragma unroll
         for (int kk = 0; kk < T::TW / 2; ++kk) {
             const float bv = drow[(2 * kk) * 32];
+            const int gx = tx0 + 2 * kk;                     // this k-step covers pixels gx, gx+1
             if (W == 0) bsum += bv;          // column sums of dout = the conv's bias gradient, for free
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                const int tap = 6 * W + j, r = tap / 5, s = tap % 5;
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(inrow[(r * T::HTW + s + 2 * kk) * CS], bv, acc[j], 0, 0, 0);
+                const int tap = 4 * j + W, r = tap / 5, s = tap % 5;
+                if ((unsigned)(gy + r - 2) < (unsigned)H && gx + s - 1 >= 0 && gx + s - 2 < H)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(inrow[(r * T::HTW + s + 2 * kk) * CS], bv, acc[j], 0, 0, 0);
             }
-            if (extra)
+            if (extra && gx + 2 < H)
                 acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(inrow[(4 * T::HTW + 4 + 2 * kk) * CS], bv, acc[6], 0, 0, 0);
         }
     }
@@ -101,10 +107,10 @@ __global__ __launch_bounds__(256, 2) void conv5x5_wgrad_kernel(WgradArgs a) {
         }
         __syncthreads();
         switch (wave) {
-            case 0: wgrad_body<H, 0>(acc, bsum, lds_in, lds_d, li, lh); break;
-            case 1: wgrad_body<H, 1>(acc, bsum, lds_in, lds_d, li, lh); break;
-            case 2: wgrad_body<H, 2>(acc, bsum, lds_in, lds_d, li, lh); break;
-            default: wgrad_body<H, 3>(acc, bsum, lds_in, lds_d, li, lh); break;
+            case 0: wgrad_body<H, 0>(acc, bsum, lds_in, lds_d, li, lh, ty0, tx0); break;
+            case 1: wgrad_body<H, 1>(acc, bsum, lds_in, lds_d, li, lh, ty0, tx0); break;
+            case 2: wgrad_body<H, 2>(acc, bsum, lds_in, lds_d, li, lh, ty0, tx0); break;
+            default: wgrad_body<H, 3>(acc, bsum, lds_in, lds_d, li, lh, ty0, tx0); break;
         }
     }
 
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int ci = ci0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-            out[((size_t)(6 * wave + j) * CIN + ci) * COUT + n0 + li] = acc[j][v];
+            out[((size_t)(4 * j + wave) * CIN + ci) * COUT + n0 + li] = acc[j][v];
         }
     // tap 24: sum the four waves' partial tiles through LDS, fixed order
     __syncthreads();

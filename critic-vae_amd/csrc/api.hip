@@ -339,6 +339,19 @@ int cvae_adam_step(cvae_handle h, float* params, const float* grads, float* exp_
     return launch_adam(params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream);
 }
 
+// ---- critic inference + uint8 frame pre-processing (vae.py:46-50) ----
+int32_t cvae_critic_param_count(void) { return critic_param_count(); }
+
+int cvae_critic_forward(cvae_handle h, int32_t B, const float* x, const float* critic_params, float* pred, void* stream) {
+    if (!h || B < 1) { cvae_set_error("cvae_critic_forward: bad handle/batch"); return CVAE_EINVAL; }
+    return launch_critic_fwd(h->cfg.width, B, x, critic_params, pred, (hipStream_t)stream);
+}
+
+int cvae_preprocess_u8(cvae_handle h, int32_t B, const uint8_t* frames_hwc, float* x, void* stream) {
+    if (!h || B < 1) { cvae_set_error("cvae_preprocess_u8: bad handle/batch"); return CVAE_EINVAL; }
+    return launch_preprocess_u8(h->cfg.width, B, frames_hwc, x, (hipStream_t)stream);
+}
+
 // ---- probe API: bracket chosen conv kernels of the real step with HIP events (bench.py roofline) ----
 int cvae_probe_config(cvae_handle h, uint32_t mask) {
     if (!h) return CVAE_EINVAL;

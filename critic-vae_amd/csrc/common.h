@@ -135,6 +135,10 @@ int64_t msssim_ws_floats(int width, int B);
 int launch_msssim(int width, int B, const float* img1, const float* img2, const float* mu,
                   const float* logvar, float* ws, float* scalars, float* d_img1, float* d_mu,
                   float* d_logvar, hipStream_t st);
+// critic.hip
+int critic_param_count();
+int launch_critic_fwd(int width, int B, const float* x, const float* critic_params, float* pred, hipStream_t st);
+int launch_preprocess_u8(int width, int B, const uint8_t* u8, float* x, hipStream_t st);
 // adam.hip
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1,
                 float b2, float eps, float gscale, hipStream_t st);

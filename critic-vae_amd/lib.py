@@ -53,6 +53,9 @@ _SIGS = {
     "cvae_loss": (C.c_int, [_p, _i32] + [_p] * 10),
     "cvae_backward": (C.c_int, [_p, _i32] + [_p] * 12),
     "cvae_adam_step": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _f, _f, _f, _f, _f, _p]),
+    "cvae_critic_param_count": (_i32, []),
+    "cvae_critic_forward": (C.c_int, [_p, _i32, _p, _p, _p, _p]),
+    "cvae_preprocess_u8": (C.c_int, [_p, _i32, _p, _p, _p]),
     "cvae_probe_config": (C.c_int, [_p, C.c_uint32]),
     "cvae_probe_read": (C.c_int, [_p, _i32, C.POINTER(C.c_float), _i32]),
     "cvae_op_scratch_floats": (_i64, [_p, _i32]),
@@ -158,6 +161,14 @@ class Handle:
     def adam_step(self, params, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0):
         self._check(self.lib.cvae_adam_step(self.h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(),
                                             step, lr, b1, b2, eps, grad_scale, _stream()))
+
+    # ---- critic + input pipeline ----
+    def critic_forward(self, B, x, critic_params, pred):
+        self._check(self.lib.cvae_critic_forward(self.h, B, _ptr(x), _ptr(critic_params), _ptr(pred), _stream()))
+
+    def preprocess_u8(self, B, frames_u8, x):
+        assert frames_u8.is_cuda and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous()
+        self._check(self.lib.cvae_preprocess_u8(self.h, B, frames_u8.data_ptr(), _ptr(x), _stream()))
 
     # ---- in-step kernel probe (bench.py roofline) ----
     def probe_config(self, ids):

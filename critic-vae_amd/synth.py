@@ -120,3 +120,23 @@ def _rows(seed, name, rows, per):
 
 def _rows_normal(seed, name, rows, per):
     return np.stack([normal(seed, f"{name}/{r}", (per,)) for r in rows])
+
+
+CRITIC_SHAPES = (("features.0.weight", (8, 3, 3, 3)), ("features.0.bias", (8,)),
+                 ("features.3.weight", (8, 8, 3, 3)), ("features.3.bias", (8,)),
+                 ("features.6.weight", (8, 8, 3, 3)), ("features.6.bias", (8,)),
+                 ("features.10.weight", (16, 8, 3, 3)), ("features.10.bias", (16,)),
+                 ("features.14.weight", (32, 16, 4, 4)), ("features.14.bias", (32,)),
+                 ("crit.1.weight", (32, 32)), ("crit.1.bias", (32,)),
+                 ("crit.4.weight", (1, 32)), ("crit.4.bias", (1,)))
+
+
+def make_critic_params(seed=0):
+    """Generator-defined critic weights (critic_net.py:15-41 shapes, PyTorch-default init bounds)."""
+    shapes = dict(CRITIC_SHAPES)
+    out = {}
+    for name, shape in CRITIC_SHAPES:
+        wshape = shapes[name[:-4] + "weight"] if name.endswith("bias") else shape
+        bound = 1.0 / np.sqrt(int(np.prod(wshape[1:])))
+        out[name] = uniform(seed, "critic." + name, shape, -bound, bound)
+    return out

@@ -102,6 +102,8 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=P.batch_size)
     ap.add_argument("--epochs", type=int, default=1)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--critic", default="random", help="'random' scalars (BASELINE config 1), 'synth' = the HIP "
+                    "critic with generator weights, or a path to a reference critic checkpoint (.pt)")
     args = ap.parse_args(argv)
     if not args.train:
         ap.error("only -train is implemented (the hot path); see SURVEY.md §8 for scope")
@@ -112,8 +114,17 @@ def main(argv=None):
     device = torch.device("cuda:0")
     vae = VariationalAutoencoder(max_batch=args.batch, seed=args.seed).to(device)
     dset = synthetic_dataset(args.synthetic)
+    if args.critic == "random":
+        critic_fn = lambda im: torch.rand(im.shape[0], 1, device=im.device)      # noqa: E731
+    else:                                  # critic.evaluate(images), vae.py:50 / vae_utility.py:363-370
+        from .critic import Critic
+        critic = Critic(handle=vae.handle).to(device)
+        sd = {k: torch.from_numpy(v) for k, v in synth.make_critic_params(args.seed).items()} \
+            if args.critic == "synth" else torch.load(args.critic, map_location="cpu")
+        critic.load_state_dict(sd)
+        critic_fn = critic.evaluate
     t0 = time.time()
-    _, hist = train(vae, dset, lambda im: torch.rand(im.shape[0], 1, device=im.device), device,
+    _, hist = train(vae, dset, critic_fn, device,
                     epochs=args.epochs, batch_size=args.batch, log_n=args.batch * 8)
     torch.cuda.synchronize()
     dt = time.time() - t0

@@ -107,6 +107,20 @@ int cvae_adam_step(cvae_handle h, float* params, const float* grads, float* exp_
                    float* exp_avg_sq, int64_t n, int32_t step, float lr, float beta1, float beta2,
                    float eps, float grad_scale, void* stream);
 
+/*
+ * Critic.evaluate (critic_net.py:66-69; eval mode) on frames x (B,3,64,64) in [0,1] -> pred (B,1),
+ * the `preds` of vae.py:50.  critic_params: cvae_critic_param_count() (= 11 873) floats in the
+ * reference's own state_dict order and layouts (features.{0,3,6,10,14}.{weight,bias},
+ * crit.{1,4}.{weight,bias}); the critic is frozen, the library never writes it.
+ */
+int32_t cvae_critic_param_count(void);
+int cvae_critic_forward(cvae_handle h, int32_t batch, const float* x, const float* critic_params,
+                        float* pred, void* stream);
+
+/* adjust_values + HWC->CHW of preprocess_observation (vae_utility.py:324-343): uint8 frames
+ * (B,W,W,3) -> float (B,3,W,W) / 255, so that only 1 byte per value crosses PCIe. */
+int cvae_preprocess_u8(cvae_handle h, int32_t batch, const uint8_t* frames_hwc, float* x, void* stream);
+
 /* float offset of a named saved tensor in the workspace ("y0".."y3", "a0".."a3", "o0".."o3",
  * "zcat", "h", "d_*" ...) for tests; -1 if unknown */
 int64_t cvae_ws_offset(cvae_handle h, int32_t batch, const char* name);

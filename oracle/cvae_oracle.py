@@ -12,6 +12,7 @@ What it restates (reference = /root/reference, PyTorch ATen on CPU, fp32):
   * VariationalAutoencoder.vae_loss       vae_nets.py:53-62
   * loss.backward()                       vae.py:57 (torch autograd over the ops above)
   * Adam.step()                           vae.py:36,58 (torch.optim.Adam defaults)
+  * Critic.evaluate (eval mode)           critic_net.py:5-69, and preprocess_observation vae_utility.py:324-343
 
 It is written as table-driven functional code over a flat {name: tensor} parameter dict (names
 = the reference's state_dict keys, prefixed encoder./decoder.), not as nn.Modules.
@@ -218,6 +219,31 @@ def adam_step(params, state, lr=5e-5, betas=(0.9, 0.999), eps=1e-8):
 def zero_grad(params):
     for p in params.values():
         p.grad = None
+
+
+# --------------------------------------------------------------------------------------------
+# the frozen critic that supplies `preds` (vae.py:50) and the frame pre-processing
+# --------------------------------------------------------------------------------------------
+CRITIC_CONVS = ((0, 1, True), (3, 1, True), (6, 1, True), (10, 1, True), (14, 0, False))   # (index, pad, pool)
+
+
+def critic_forward(cp, x):
+    """Critic.forward / evaluate in eval mode (critic_net.py:15-41, 43-69): 4 x [Conv3x3(p=1) -> ReLU ->
+    MaxPool2] -> Conv4x4 -> ReLU -> Flatten -> Linear -> ReLU -> Linear -> Sigmoid; Dropout is identity.
+    `cp`: {reference state_dict key: tensor}."""
+    h = x
+    for idx, pad, pool in CRITIC_CONVS:
+        h = torch.relu(F.conv2d(h, cp[f"features.{idx}.weight"], cp[f"features.{idx}.bias"], stride=1, padding=pad))
+        if pool:
+            h = F.max_pool2d(h, 2)
+    h = torch.flatten(h, 1)
+    h = torch.relu(F.linear(h, cp["crit.1.weight"], cp["crit.1.bias"]))
+    return torch.sigmoid(F.linear(h, cp["crit.4.weight"], cp["crit.4.bias"]))
+
+
+def preprocess_frames(u8_hwc):
+    """adjust_values + HWC->CHW of preprocess_observation (vae_utility.py:324-343), batched."""
+    return (u8_hwc.to(torch.float32) / 255.0).permute(0, 3, 1, 2).contiguous()
 
 
 # --------------------------------------------------------------------------------------------

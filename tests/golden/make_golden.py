@@ -214,11 +214,38 @@ def msssim_cases():
     np.savez_compressed(os.path.join(HERE, "msssim_ops.npz"), **fx)
 
 
+def critic_case(batch=8):
+    """Critic.evaluate of the reference (critic_net.py) on generator-defined weights and frames, plus
+    the real local checkpoint as a sanity check of the restatement (not stored)."""
+    import critic_net
+    cp_np = synth.make_critic_params(0)
+    c = critic_net.Critic()
+    c.load_state_dict({k: torch.from_numpy(v) for k, v in cp_np.items()})
+    c.eval()
+    x_np, _, _ = synth.make_batch(1234, 7, batch)
+    x = torch.from_numpy(x_np)
+    ref = c.evaluate(x)
+    mine = orc.critic_forward({k: torch.from_numpy(v) for k, v in cp_np.items()}, x)
+    assert (ref - mine).abs().max().item() < 1e-7, (ref - mine).abs().max()
+    ck = [f for f in os.listdir("/root/reference/saved-networks") if f.startswith("critic")]
+    if ck:
+        sd = torch.load(os.path.join("/root/reference/saved-networks", ck[0]), map_location="cpu")
+        c2 = critic_net.Critic(); c2.load_state_dict(sd); c2.eval()
+        d = (c2.evaluate(x) - orc.critic_forward(sd, x)).abs().max().item()
+        print(f"[critic] real checkpoint {ck[0][:40]}...: oracle-vs-reference max diff {d:.2e}")
+        assert d < 1e-7
+    u8 = (synth.uniform(3, "u8frames", (4, 64, 64, 3)) * 256).astype(np.uint8)
+    np.savez_compressed(os.path.join(HERE, "critic_b8.npz"), batch=batch, wseed=0, dseed=1234, step=7,
+                        pred=ref.numpy(), u8=u8, u8_pre=orc.preprocess_frames(torch.from_numpy(u8)).numpy()[:, :, ::8, ::8].copy())
+    print(f"[critic] preds {ref.numpy().reshape(-1)[:4]}")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     step_case("b2", 2)
     step_case("b32", 32)
     step_case("w128_b2", 2, width=128)
     msssim_cases()
+    critic_case()
     trajectory_case()
     print("goldens written to", HERE)

@@ -239,3 +239,30 @@ def test_adam_matches_torch(H):
         H.adam_step(p, dev(gs * 2.0), m, v, step, 5e-5, grad_scale=0.5)
     torch.cuda.synchronize()
     check(p, p_ref, "adam params", 1e-7)
+
+
+@pytest.mark.parametrize("scale", [1.0, 2.0])
+def test_critic_forward_and_preprocess(H, golden_dir, scale):
+    """cvae_critic_forward / cvae_preprocess_u8 vs the oracle (and the reference-generated fixture)."""
+    import os
+    from critic_vae_amd.critic import Critic
+    fx = np.load(os.path.join(golden_dir, "critic_b8.npz"))
+    cp = {k: torch.from_numpy(v) * scale for k, v in synth.make_critic_params(int(fx["wseed"])).items()}
+    x, _, _ = synth.make_batch(int(fx["dseed"]), int(fx["step"]), int(fx["batch"]))
+    x = torch.from_numpy(x)
+    want = orc.critic_forward(cp, x)
+    crit = Critic(handle=H).cuda()
+    crit.load_state_dict(cp)
+    got = crit.evaluate(x.cuda())
+    torch.cuda.synchronize()
+    check(got, want, "critic pred", 2e-6)
+    if scale == 1.0:
+        check(got, torch.from_numpy(fx["pred"]), "critic pred vs reference fixture", 2e-6)
+    else:
+        assert want.std().item() > 1e-3          # the scaled weights really exercise the network
+    sd = crit.state_dict()
+    assert all(torch.equal(sd[k].cpu(), cp[k]) for k in cp)
+    u8 = torch.from_numpy(fx["u8"])
+    pre = crit.preprocess(u8.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(pre.cpu(), orc.preprocess_frames(u8))

@@ -95,3 +95,14 @@ def test_generator_is_stable():
     x2, _, eps2 = synth.make_batch(1234, 0, 2, first_index=2)
     assert np.array_equal(x[2:], x2) and np.array_equal(eps[2:], eps2)      # shardable by row
     assert 0.0 <= x.min() and x.max() < 1.0 and abs(float(eps.mean())) < 0.5
+
+
+def test_critic_matches_reference_fixture(golden_dir):
+    """Critic.evaluate (critic_net.py:66-69) restated; fixture from the reference's own Critic class."""
+    fx = np.load(os.path.join(golden_dir, "critic_b8.npz"))
+    cp = {k: torch.from_numpy(v) for k, v in synth.make_critic_params(int(fx["wseed"])).items()}
+    x, _, _ = synth.make_batch(int(fx["dseed"]), int(fx["step"]), int(fx["batch"]))
+    pred = orc.critic_forward(cp, torch.from_numpy(x))
+    assert pred.shape == (int(fx["batch"]), 1) and np.abs(pred.numpy() - fx["pred"]).max() < 1e-6
+    pre = orc.preprocess_frames(torch.from_numpy(fx["u8"]))
+    assert pre.shape == (4, 3, 64, 64) and np.array_equal(pre.numpy()[:, :, ::8, ::8], fx["u8_pre"])

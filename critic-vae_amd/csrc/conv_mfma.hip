@@ -222,7 +222,7 @@ int launch_conv_fwd(int layer, int width, int B, const float* in, const float* w
         switch (layer) {
             case 1: return run<32, 64, 32, false, false, 64, EPI_BIAS_BNSTAT>(a, st);
             case 2: return run<64, 128, 16, false, false, 64, EPI_BIAS_BNSTAT>(a, st);
-            case 3: return run<128, 256, 8, false, false, 64, EPI_BIAS_BNSTAT>(a, st);
+            case 3: return run<128, 256, 8, false, false, 32, EPI_BIAS_BNSTAT>(a, st);
             case 4: {     // D0: 4x4 images, K = 6400 -> split-K over channel chunks to fill the chip
                 const int64_t slice = (int64_t)B * 4 * 4 * 128;
                 a.out = ws; a.sliceFloats = slice;
@@ -255,7 +255,7 @@ int launch_conv_dgrad(int layer, int width, int B, const float* dout, const floa
         switch (layer) {
             case 1: return run<64, 32, 32, false, true, 32, EPI_PLAIN>(a, st);
             case 2: return run<128, 64, 16, false, true, 64, EPI_PLAIN>(a, st);
-            case 3: return run<256, 128, 8, false, true, 64, EPI_PLAIN>(a, st);
+            case 3: return run<256, 128, 8, false, true, 32, EPI_PLAIN>(a, st);
             case 4: return run<128, 256, 4, false, true, 32, EPI_PLAIN>(a, st);
         }
     }

@@ -25,10 +25,16 @@ static inline void tile_geom(int H, int* imgs, int* pxPerImg, int* tilesPerImg) 
     *pxPerImg = TW * TH;
     *tilesPerImg = (H / TW) * (H / TH);
 }
+// geometry of the BatchNorm partials a layer's conv kernel emits: E1 (layer 0) reports one partial per
+// 16x32-pixel strip (conv_thin.hip), the others one per 128-pixel tile (conv_epilogue.h)
+static inline void part_geom(int layer, int H, int* imgs, int* pxPerImg, int* tilesPerImg) {
+    if (layer == 0) { *imgs = 1; *pxPerImg = 512; *tilesPerImg = (H / 16) * (H / 32); return; }
+    tile_geom(H, imgs, pxPerImg, tilesPerImg);
+}
 int bn_num_tiles(int layer, int width, int B) {
     const BnGeom g = bn_geom(layer, width);
     int imgs, ppi, tpi;
-    tile_geom(g.H, &imgs, &ppi, &tpi);
+    part_geom(layer, g.H, &imgs, &ppi, &tpi);
     return cdiv(B, imgs) * tpi;
 }
 
@@ -197,7 +203,7 @@ int launch_bn_fwd_finalize(int layer, int width, int B, const float* bnpart, con
                            float* run_mean, float* run_var, float* coef, float* ws, int train, hipStream_t st) {
     const BnGeom g = bn_geom(layer, width);
     int imgs, ppi, tpi;
-    tile_geom(g.H, &imgs, &ppi, &tpi);
+    part_geom(layer, g.H, &imgs, &ppi, &tpi);
     const int numTiles = cdiv(B, imgs) * tpi;
     double* mid = reinterpret_cast<double*>(ws);
     int RA = 0;

@@ -9,7 +9,7 @@ enum { EPI_BIAS_BNSTAT = 0, EPI_BIAS_RELU = 1, EPI_PLAIN = 2, EPI_POOLSUM_MASK =
 // NHWC tensor, adding the bias (and ReLU), and — for the encoder convs — emit the per-tile,
 // per-channel BatchNorm partials (sum, M2 about the tile mean) that bn_fwd_finalize merges
 // (train-mode batch statistics of nn.BatchNorm2d, vae_nets.py:70,75,80,85).
-// `smem` must be free for reuse (the caller's main loop is done) and hold >= 8*NT floats.
+// `smem` is reused (a barrier precedes the first write) and must hold >= max(8*NT, 4*32*36) floats.
 template <int H, int NT, int NCH, int EPI>
 __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[NT / 32], const float* bias, float* out,
                                                float* bnpart, float* smem, int B, int mt, int n0,
@@ -21,18 +21,31 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[NT / 32], const flo
     float bv[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) bv[nb] = (EPI == EPI_PLAIN) ? 0.f : bias[n0 + nb * 32 + li];
+    // Stores are issue-bound (one instruction per accumulator register moves only 4 B per lane), so each
+    // wave transposes its 32x32 tile through a private LDS patch and writes 16 B per lane: 4 store
+    // instructions per tile instead of 16 (cdna guide T21: the store tail is bound by instruction count).
+    __syncthreads();                                   // every wave is done with the staging buffers
+    float* patch = smem + wave * (32 * 36);            // [32 pixels][36] floats, rows 16-byte aligned
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             float x = acc[nb][v] + bv[nb];
             if (EPI == EPI_BIAS_RELU) x = fmaxf(x, 0.f);
             acc[nb][v] = x;
-            const int mm = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            patch[((v & 3) + 8 * (v >> 2) + 4 * lh) * 36 + li] = x;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * 64 + lane, px = idx >> 3, c4 = idx & 7;
+            const float4 val = *reinterpret_cast<const float4*>(patch + px * 36 + c4 * 4);
+            const int mm = wave * 32 + px;
             const int im = mm / (T::TH * T::TW), rem = mm % (T::TH * T::TW);
             const int gy = ty0 + rem / T::TW, gx = tx0 + rem % T::TW, ib = img0 + im;
-            if (ib < B) out[((size_t)(ib * H + gy) * H + gx) * NCH + n0 + nb * 32 + li] = x;
+            if (ib < B)
+                *reinterpret_cast<float4*>(out + ((size_t)(ib * H + gy) * H + gx) * NCH + n0 + nb * 32 + c4 * 4) = val;
         }
+    }
     if (EPI == EPI_BIAS_BNSTAT) {
         __syncthreads();
         float* red = smem;                       // [2][4][NT]

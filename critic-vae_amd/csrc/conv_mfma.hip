@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
     constexpr int NB = NT / 32;
     constexpr int IN_FLOATS = KC * T::PS;
     constexpr int W_FLOATS = DGRAD ? 5 * NT * KCP : 5 * KC * NT;
-    constexpr int EPI_FLOATS = (EPI == EPI_POOLSUM_MASK) ? 128 * (NT + 1) : 8 * NT;
+    constexpr int EPI_FLOATS = (EPI == EPI_POOLSUM_MASK) ? 128 * (NT + 1) : 4 * 32 * 36;
     constexpr int SMEM = (IN_FLOATS + W_FLOATS) > EPI_FLOATS ? (IN_FLOATS + W_FLOATS) : EPI_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float* lds_in = smem;

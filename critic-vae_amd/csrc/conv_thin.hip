@@ -33,34 +33,85 @@ __device__ __forceinline__ void e1_stage_x(const float* x, float* lds_x, int B, 
     }
 }
 
+// E1 forward.  WG = a 16-row x 32-column strip (512 pixels) of one image; wave w owns rows 4w..4w+3
+// (four 32-pixel accumulator tiles).  The whole B operand (76 x 32 weights) lives in 38 registers per
+// lane, read once from global; the x halo (3 planes) is staged once per strip.  Epilogue: bias,
+// NHWC store, and the strip's BatchNorm partial (sum, M2 about the strip mean).
 template <int H>
 __global__ __launch_bounds__(256) void e1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ y,
                                                      float* __restrict__ bnpart, int B) {
-    using T = Tile<H>;
-    static_assert(T::IMGS == 1 && T::TW == 32, "E1 runs on >=32-wide frames");
-    __shared__ __attribute__((aligned(16))) float smem[3 * T::PS + 76 * 32];
-    float* lds_x = smem;
-    float* lds_w = smem + 3 * T::PS;
+    constexpr int SR = 16, SW = 32, HW_ = SW + 4, HR_ = SR + 4, PS = ((3 * 0 + HW_ * HR_ + 5) / 8) * 8 + 2;
+    constexpr int SX = H / SW, SY = H / SR;
+    __shared__ float lds_x[3 * PS];
+    __shared__ __attribute__((aligned(16))) float patch_all[4 * 32 * 36];
+    __shared__ float red[2][4][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int mt = blockIdx.x, ib = mt / T::TILES_PER_IMG, tileInImg = mt % T::TILES_PER_IMG;
-    const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;
-    e1_stage_x<H>(x, lds_x, B, ib, ty0, tx0);
-    for (int q = tid; q < 76 * 32; q += 256) lds_w[q] = q < 2400 ? w[q] : 0.f;
-    __syncthreads();
-    f32x16 acc[1];
+    const int ib = blockIdx.x / (SX * SY), t = blockIdx.x % (SX * SY);
+    const int ty0 = (t / SX) * SR, tx0 = (t % SX) * SW;
+    float bw[38];
 #pragma unroll
-    for (int v = 0; v < 16; ++v) acc[0][v] = 0.f;
-    const int aBase = wave * T::HTW + li;           // pixel (row wave, col li) of the 4x32 tile
-#pragma unroll
-    for (int j = 0; j < 38; ++j) {
-        const int off = lh ? e1_off<T::PS, T::HTW>(2 * j + 1) : e1_off<T::PS, T::HTW>(2 * j);
-        const float av = lds_x[aBase + off];
-        const float bv = lds_w[(2 * j + lh) * 32 + li];
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0], 0, 0, 0);
+    for (int j = 0; j < 38; ++j) bw[j] = (2 * j + lh < 75) ? w[(2 * j + lh) * 32 + li] : 0.f;
+    for (int q = tid; q < 3 * HW_ * HR_; q += 256) {
+        const int c = q / (HW_ * HR_), hp = q % (HW_ * HR_);
+        const int gy = ty0 + hp / HW_ - 2, gx = tx0 + hp % HW_ - 2;
+        float v = 0.f;
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H) v = x[((size_t)(ib * 3 + c) * H + gy) * H + gx];
+        lds_x[c * PS + hp] = v;
     }
     __syncthreads();
-    epilogue_store<H, 32, 32, EPI_BIAS_BNSTAT>(acc, bias, y, bnpart, smem, B, mt, 0, ib, ty0, tx0);
+    f32x16 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[r][v] = 0.f;
+    const int aBase = (wave * 4) * HW_ + li;
+#pragma unroll
+    for (int j = 0; j < 38; ++j) {
+        const int off = lh ? e1_off<PS, HW_>(2 * j + 1) : e1_off<PS, HW_>(2 * j);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds_x[aBase + r * HW_ + off], bw[j], acc[r], 0, 0, 0);
+    }
+    // epilogue: element v of lane (li, lh) in tile r = pixel column (v&3)+8*(v>>2)+4*lh of row 4*wave+r, channel li
+    const float bv = bias[li];
+    float s = 0.f;
+    float* patch = patch_all + wave * (32 * 36);       // per-wave transpose patch -> 16-byte stores
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float val = acc[r][v] + bv;
+            acc[r][v] = val;
+            s += val;
+            patch[((v & 3) + 8 * (v >> 2) + 4 * lh) * 36 + li] = val;
+        }
+        const int gy = ty0 + wave * 4 + r;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * 64 + lane, px = idx >> 3, c4 = idx & 7;
+            const float4 val = *reinterpret_cast<const float4*>(patch + px * 36 + c4 * 4);
+            *reinterpret_cast<float4*>(y + ((size_t)(ib * H + gy) * H + tx0 + px) * 32 + c4 * 4) = val;
+        }
+    }
+    s += __shfl_xor(s, 32, 64);
+    if (lh == 0) red[0][wave][li] = s;
+    __syncthreads();
+    const float mean = ((red[0][0][li] + red[0][1][li]) + (red[0][2][li] + red[0][3][li])) * (1.0f / (SR * SW));
+    float m2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { const float d = acc[r][v] - mean; m2 += d * d; }
+    m2 += __shfl_xor(m2, 32, 64);
+    if (lh == 0) red[1][wave][li] = m2;
+    __syncthreads();
+    if (tid < 32) {
+        const size_t nt = gridDim.x;
+        bnpart[(size_t)blockIdx.x * 32 + tid] = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
+        bnpart[(nt + blockIdx.x) * 32 + tid] = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+    }
+    (void)B;
 }
 
 struct ThinWgradArgs {
@@ -178,8 +229,8 @@ int64_t e1_wgrad_ws_floats(int width, int B) {
 
 int launch_e1_fwd(int width, int B, const float* x, const float* w, const float* bias, float* y,
                   float* bnpart, hipStream_t st) {
-    if (width == 64) hipLaunchKernelGGL(e1_fwd_kernel<64>, dim3(B * Tile<64>::TILES_PER_IMG), dim3(256), 0, st, x, w, bias, y, bnpart, B);
-    else if (width == 128) hipLaunchKernelGGL(e1_fwd_kernel<128>, dim3(B * Tile<128>::TILES_PER_IMG), dim3(256), 0, st, x, w, bias, y, bnpart, B);
+    if (width == 64) hipLaunchKernelGGL(e1_fwd_kernel<64>, dim3(B * 8), dim3(256), 0, st, x, w, bias, y, bnpart, B);
+    else if (width == 128) hipLaunchKernelGGL(e1_fwd_kernel<128>, dim3(B * 32), dim3(256), 0, st, x, w, bias, y, bnpart, B);
     else { cvae_set_error("e1_fwd: width %d unsupported", width); return -2; }
     CVAE_CHECK_LAUNCH();
     return 0;

@@ -352,6 +352,12 @@ int cvae_preprocess_u8(cvae_handle h, int32_t B, const uint8_t* frames_hwc, floa
     return launch_preprocess_u8(h->cfg.width, B, frames_hwc, x, (hipStream_t)stream);
 }
 
+// |recon_zero - recon_one| -> greyscale difference mask (get_diff_image, vae_utility.py:256-277), batched
+int cvae_diff_grey(cvae_handle h, int32_t B, const float* recon_one, const float* recon_zero, float* diff, void* stream) {
+    if (!h || B < 1) { cvae_set_error("cvae_diff_grey: bad handle/batch"); return CVAE_EINVAL; }
+    return launch_diff_grey(h->cfg.width, B, recon_one, recon_zero, diff, (hipStream_t)stream);
+}
+
 // ---- probe API: bracket chosen conv kernels of the real step with HIP events (bench.py roofline) ----
 int cvae_probe_config(cvae_handle h, uint32_t mask) {
     if (!h) return CVAE_EINVAL;

@@ -139,6 +139,7 @@ int launch_msssim(int width, int B, const float* img1, const float* img2, const 
 int critic_param_count();
 int launch_critic_fwd(int width, int B, const float* x, const float* critic_params, float* pred, hipStream_t st);
 int launch_preprocess_u8(int width, int B, const uint8_t* u8, float* x, hipStream_t st);
+int launch_diff_grey(int width, int B, const float* a, const float* b, float* diff, hipStream_t st);
 // adam.hip
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1,
                 float b2, float eps, float gscale, hipStream_t st);

@@ -129,4 +129,21 @@ int launch_preprocess_u8(int width, int B, const uint8_t* u8, float* x, hipStrea
     return 0;
 }
 
+// diff[b][y][x] = grey(|a - b|) with the reference's luma weights (get_diff_image, vae_utility.py:256-277)
+__global__ __launch_bounds__(256) void diff_grey_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ diff, int64_t npix_total, int hw) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix_total) return;
+    const int64_t img = i / hw, p = i % hw, o = img * 3 * hw + p;
+    const float r = fabsf(b[o] - a[o]), g = fabsf(b[o + hw] - a[o + hw]), bl = fabsf(b[o + 2 * (int64_t)hw] - a[o + 2 * (int64_t)hw]);
+    diff[i] = r * 0.2989f + g * 0.5870f + bl * 0.1140f;
+}
+
+int launch_diff_grey(int width, int B, const float* a, const float* b, float* diff, hipStream_t st) {
+    const int64_t n = (int64_t)B * width * width;
+    hipLaunchKernelGGL(diff_grey_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, diff, n, width * width);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}
+
 int critic_param_count() { return CRITIC_PARAMS; }

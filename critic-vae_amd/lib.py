@@ -56,6 +56,7 @@ _SIGS = {
     "cvae_critic_param_count": (_i32, []),
     "cvae_critic_forward": (C.c_int, [_p, _i32, _p, _p, _p, _p]),
     "cvae_preprocess_u8": (C.c_int, [_p, _i32, _p, _p, _p]),
+    "cvae_diff_grey": (C.c_int, [_p, _i32, _p, _p, _p, _p]),
     "cvae_probe_config": (C.c_int, [_p, C.c_uint32]),
     "cvae_probe_read": (C.c_int, [_p, _i32, C.POINTER(C.c_float), _i32]),
     "cvae_op_scratch_floats": (_i64, [_p, _i32]),
@@ -169,6 +170,9 @@ class Handle:
     def preprocess_u8(self, B, frames_u8, x):
         assert frames_u8.is_cuda and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous()
         self._check(self.lib.cvae_preprocess_u8(self.h, B, frames_u8.data_ptr(), _ptr(x), _stream()))
+
+    def diff_grey(self, B, recon_one, recon_zero, diff):
+        self._check(self.lib.cvae_diff_grey(self.h, B, _ptr(recon_one), _ptr(recon_zero), _ptr(diff), _stream()))
 
     # ---- in-step kernel probe (bench.py roofline) ----
     def probe_config(self, ids):

@@ -258,3 +258,17 @@ class VariationalAutoencoder(nn.Module):
         """vae_nets.py:42-46."""
         mu, _ = self.encoder(x)
         return self.decoder(mu, pred.view(1), evalu=True)
+
+    def diff_images(self, x, pred, one=False):
+        """get_diff_image (vae_utility.py:256-277) for a whole batch at once: the encoder runs once,
+        the decoder twice (critic value `pred` — or 1 if `one` — against 0); returns
+        (recon_one, recon_zero, diff (B,w,w), per-image max of diff)."""
+        x = self._prep(x)
+        B = x.shape[0]
+        mu, _ = self.encoder(x)
+        hi = torch.ones(B, 1, device=x.device) if one else pred.to(torch.float32).reshape(B, 1)
+        recon_one = self.decoder(mu, hi)
+        recon_zero = self.decoder(mu, torch.zeros(B, 1, device=x.device))
+        diff = torch.empty(B, self.width, self.width, device=x.device)
+        self.handle.diff_grey(B, recon_one, recon_zero, diff)
+        return recon_one, recon_zero, diff, diff.flatten(1).max(dim=1).values

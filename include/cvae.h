@@ -121,6 +121,11 @@ int cvae_critic_forward(cvae_handle h, int32_t batch, const float* x, const floa
  * (B,W,W,3) -> float (B,3,W,W) / 255, so that only 1 byte per value crosses PCIe. */
 int cvae_preprocess_u8(cvae_handle h, int32_t batch, const uint8_t* frames_hwc, float* x, void* stream);
 
+/* Difference mask of the inference path (get_diff_image, vae_utility.py:256-277), batched:
+ * diff (B,W,W) = 0.2989|dR| + 0.5870|dG| + 0.1140|dB| of recon_zero - recon_one (both (B,3,W,W)). */
+int cvae_diff_grey(cvae_handle h, int32_t batch, const float* recon_one, const float* recon_zero,
+                   float* diff, void* stream);
+
 /* float offset of a named saved tensor in the workspace ("y0".."y3", "a0".."a3", "o0".."o3",
  * "zcat", "h", "d_*" ...) for tests; -1 if unknown */
 int64_t cvae_ws_offset(cvae_handle h, int32_t batch, const char* name);

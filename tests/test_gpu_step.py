@@ -193,3 +193,40 @@ def test_state_dict_round_trip_reference_layout():
     vae2.encoder.load_state_dict(enc)
     vae2.decoder.load_state_dict(dec)
     assert torch.equal(vae2.theta, vae.theta)
+
+
+def test_inference_path_eval_mode():
+    """evaluate / inject / diff-mask (vae_nets.py:31-46, vae_utility.py:256-277) in
+    eval mode (BatchNorm running statistics, mu instead of a sample), batched, vs the oracle."""
+    B = 5
+    x, pred, eps = _inputs(1234, 9, B)
+    vae = _model(B)
+    # a few training steps give non-trivial running statistics on both sides
+    p = orc.to_torch(synth.make_params(0), requires_grad=True)
+    bn = orc.new_bn_state(p)
+    for s in range(3):
+        xs, ps, es = _inputs(1234, 20 + s, B)
+        _step(vae, xs, ps, es)
+        orc.zero_grad(p)
+        orc.train_step(p, xs, ps, es, bn_state=bn)
+    vae.eval()
+    with torch.no_grad():
+        mu, logvar = vae.encoder(x.cuda())
+        mu_o, lv_o = orc.encoder(p, x, bn, train=False)
+        assert (mu.cpu() - mu_o).abs().max() < TOL and (logvar.cpu() - lv_o).abs().max() < TOL
+        r1, r0, diff, mx = vae.diff_images(x.cuda(), pred.cuda())
+        r1_o = orc.decoder(p, mu_o, pred)
+        r0_o = orc.decoder(p, mu_o, torch.zeros(B, 1))
+        assert (r1.cpu() - r1_o).abs().max() < TOL and (r0.cpu() - r0_o).abs().max() < TOL
+        d_o = ((r0_o - r1_o).abs() * torch.tensor([0.2989, 0.5870, 0.1140]).view(1, 3, 1, 1)).sum(1)
+        assert (diff.cpu() - d_o).abs().max() < TOL and (mx.cpu() - d_o.flatten(1).max(1).values).abs().max() < TOL
+        # single-image API exactly as the reference calls it (batch of one, pred.view(1))
+        one = vae.evaluate(x[:1].cuda(), pred[0].cuda())
+        assert one.shape == (1, 3, 64, 64) and (one.cpu() - r1_o[:1]).abs().max() < TOL
+        inj = vae.inject(x[:1].cuda())
+        assert len(inj) == 6 and (inj[0].cpu() - r0_o[:1]).abs().max() < TOL
+    # eval mode must not touch the running statistics
+    before = vae.bn_state.clone()
+    with torch.no_grad():
+        vae.encoder(x.cuda())
+    assert torch.equal(before, vae.bn_state)

@@ -230,3 +230,23 @@ def test_inference_path_eval_mode():
     with torch.no_grad():
         vae.encoder(x.cuda())
     assert torch.equal(before, vae.bn_state)
+
+
+@pytest.mark.parametrize("B", [1, 7])
+def test_ragged_batches_against_oracle(B):
+    """Tail batches of any size are kept by the reference loop (vae.py:44-46): B=1 (BatchNorm over one
+    image), B=7 (partial 2- and 8-image tiles), with a workspace sized for a larger max_batch."""
+    x, pred, eps = _inputs(1234, 40 + B, B)
+    assert torch.cuda.is_available()
+    vae = VariationalAutoencoder(max_batch=16, seed=0).cuda()
+    vae.load_reference_params(synth.make_params(0))
+    (_, mu, logvar, recon), losses = _step(vae, x, pred, eps)
+    p = orc.to_torch(synth.make_params(0), requires_grad=True)
+    o = orc.train_step(p, x, pred, eps, bn_state=orc.new_bn_state(p))
+    if not torch.isfinite(o["total_loss"]):
+        assert not torch.isfinite(losses["total_loss"]).item()      # NaN propagates identically
+        return
+    assert (mu.detach().cpu() - o["mu"]).abs().max() < TOL and (recon.detach().cpu() - o["recon"]).abs().max() < TOL
+    assert abs(losses["total_loss"].item() - o["total_loss"].item()) < TOL
+    for name, g in vae.reference_grads().items():
+        _grad_check(name, g, p[name].grad)

@@ -92,8 +92,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs MI355X GPUs (the HIP library has no CPU fallback)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dp.device_index(local))
+    dev = torch.device("cuda", dp.device_index(local))
     B = args.batch
     probing = rank == 0 and world == 1 and not args.no_probe
 

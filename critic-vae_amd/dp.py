@@ -23,14 +23,20 @@ def init(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:      # CVAE_DIST_BACKEND=gloo: rehearse the multi-rank path without RCCL (e.g. 2 ranks, 1 GPU)
+            backend = os.environ.get("CVAE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
-            torch.cuda.set_device(local)
-            kw["device_id"] = torch.device("cuda", local)
+            torch.cuda.set_device(device_index(local))
+            kw["device_id"] = torch.device("cuda", device_index(local))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return world, rank, local
+
+
+def device_index(local_rank):
+    """GPU of this rank: LOCAL_RANK, unless CVAE_DEVICE pins every rank to one device (rehearsals)."""
+    forced = os.environ.get("CVAE_DEVICE")
+    return int(forced) if forced is not None else local_rank
 
 
 def shard_rows(global_batch, world, rank):

@@ -187,6 +187,52 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ y
     }
 }
 
+// ReLU blocks: the two backward sums need only the POOLED tensors.  g = da*[a>0]; at the window argmax
+// the normalised value is n = a (ReLU passed it through), and xhat = (n - beta)/gamma, so
+// sum(g) and sum(g*xhat) never touch the full-resolution y (3x less traffic than bn_bwd_kernel<0,0>).
+__global__ __launch_bounds__(256) void bn_bwd_stats_relu_kernel(const float* __restrict__ a, const float* __restrict__ da,
+                                                                const float* __restrict__ coef, float* __restrict__ part,
+                                                                int C, int64_t totalPx, int64_t pxPerBlk) {
+    __shared__ float red[2][256][4];
+    const int C4 = C / 4, c4 = threadIdx.x % C4, sub = threadIdx.x / C4, NSUB = 256 / C4;
+    float gam[4], bet[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = c4 * 4 + e;
+        const float scale = coef[c * 4], shift = coef[c * 4 + 1], mean = coef[c * 4 + 2], invstd = coef[c * 4 + 3];
+        const float g = scale / invstd;                       // gamma
+        gam[e] = fabsf(g) > 1e-30f ? 1.0f / g : 0.f;
+        bet[e] = shift + mean * scale;                        // beta
+    }
+    const int64_t p0 = blockIdx.x * pxPerBlk;
+    int64_t p1 = p0 + pxPerBlk; if (p1 > totalPx) p1 = totalPx;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t pp = p0 + sub; pp < p1; pp += NSUB) {
+        const float4 av = *reinterpret_cast<const float4*>(a + pp * C + c4 * 4);
+        const float4 gv = *reinterpret_cast<const float4*>(da + pp * C + c4 * 4);
+        const float aa[4] = {av.x, av.y, av.z, av.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float g = aa[e] > 0.f ? gg[e] : 0.f;
+            s1[e] += g;
+            s2[e] += g * ((aa[e] - bet[e]) * gam[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
+    __syncthreads();
+    if (sub == 0) {
+        for (int k = 1; k < NSUB; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1[e] += red[0][k * C4 + c4][e]; s2[e] += red[1][k * C4 + c4][e]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            part[((size_t)blockIdx.x * 2) * C + c4 * 4 + e] = s1[e];
+            part[((size_t)blockIdx.x * 2 + 1) * C + c4 * 4 + e] = s2[e];
+        }
+    }
+}
+
 // after launch_col_reduce: red = [sum g | sum g*xhat] -> dgamma, dbeta, bcoef = (s1/N, s2/N)
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ red, int C, float invN, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ bcoef) {
@@ -257,7 +303,7 @@ int launch_bn_pool_act_bwd(int layer, int width, int B, const float* y, const fl
     float* crws = red + 2 * g.C;
     const float invN = 1.0f / (float)((double)B * g.H * g.H);
     if (g.act) hipLaunchKernelGGL((bn_bwd_kernel<1, 0>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, nullptr, nullptr, part, g.C, g.H, totalPx, ppb);
-    else hipLaunchKernelGGL((bn_bwd_kernel<0, 0>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, nullptr, nullptr, part, g.C, g.H, totalPx, ppb);
+    else hipLaunchKernelGGL(bn_bwd_stats_relu_kernel, dim3(nblk), dim3(256), 0, st, a, da, coef, part, g.C, totalPx, ppb);
     CVAE_CHECK_LAUNCH();
     { int rc = launch_col_reduce(part, nblk, 2 * g.C, 2 * g.C, red, crws, st); if (rc) return rc; }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(g.C, 64)), dim3(64), 0, st, red, g.C, invN, dgamma, dbeta, bcoef);

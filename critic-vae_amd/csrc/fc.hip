@@ -10,6 +10,76 @@
 static constexpr int FC_KS = 32;         // K splits of the fc_mu|fc_var GEMM
 static constexpr int FC_IMGS = 16;       // images per workgroup
 
+// slab[ks][m][64] = sum_{k in K-slice ks} A[m][k] * Bm(k, n)   on v_mfma_f32_32x32x2_f32.
+// A is [M][K] row-major.  B_KMAJOR == false: Bm(k,n) = Bp[k*64 + n] (fc_mu|fc_var weights, N = 64);
+// B_KMAJOR == true : Bm(k,n) = Bp[n*K + k] for n < NV, 0 otherwise (decoder_input transposed, NV = 33).
+// WG = 128 rows x 64 columns x one K-slice; wave w owns rows 32w..32w+31 and both 32-column tiles.
+template <bool B_KMAJOR>
+__global__ __launch_bounds__(256) void latent_gemm_kernel(const float* __restrict__ A, const float* __restrict__ Bp,
+                                                          float* __restrict__ slab, int M, int K, int kslice, int NV) {
+    __shared__ float lds_a[128 * 33];
+    __shared__ float lds_b[32 * 65];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * 128, k0 = blockIdx.y * kslice;
+    f32x16 acc[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[nb][v] = 0.f;
+    for (int kc = k0; kc < k0 + kslice; kc += 32) {
+        __syncthreads();
+        for (int q = tid; q < 128 * 8; q += 256) {
+            const int c4 = q & 7, r = q >> 3;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + r < M) v = *reinterpret_cast<const float4*>(A + (size_t)(m0 + r) * K + kc + c4 * 4);
+            float* d = lds_a + r * 33 + c4 * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        if (!B_KMAJOR) {
+            for (int q = tid; q < 32 * 16; q += 256) {
+                const int c4 = q & 15, kk = q >> 4;
+                const float4 v = *reinterpret_cast<const float4*>(Bp + (size_t)(kc + kk) * 64 + c4 * 4);
+                float* d = lds_b + kk * 65 + c4 * 4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (int q = tid; q < 64 * 8; q += 256) {
+                const int c4 = q & 7, n = q >> 3;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < NV) v = *reinterpret_cast<const float4*>(Bp + (size_t)n * K + kc + c4 * 4);
+                lds_b[(c4 * 4 + 0) * 65 + n] = v.x; lds_b[(c4 * 4 + 1) * 65 + n] = v.y;
+                lds_b[(c4 * 4 + 2) * 65 + n] = v.z; lds_b[(c4 * 4 + 3) * 65 + n] = v.w;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float av = lds_a[(wave * 32 + li) * 33 + 2 * j + lh];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, lds_b[(2 * j + lh) * 65 + nb * 32 + li], acc[nb], 0, 0, 0);
+        }
+    }
+    float* out = slab + (size_t)blockIdx.y * M * 64;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int m = m0 + wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            if (m < M) out[(size_t)m * 64 + nb * 32 + li] = acc[nb][v];
+        }
+}
+
+// dzcat[b][i] = sum_ks slab[ks][b][i], i < 33
+__global__ __launch_bounds__(256) void decin_dz_finish_kernel(const float* __restrict__ slab, float* __restrict__ dzcat, int B, int KS) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * 33) return;
+    const int b = idx / 33, i = idx % 33;
+    float acc = 0.f;
+    for (int ks = 0; ks < KS; ++ks) acc += slab[((size_t)ks * B + b) * 64 + i];
+    dzcat[idx] = acc;
+}
+
 // part[ks][b][64] = sum_{k in split ks} flat[b][k] * Wfc[k][n]
 __global__ __launch_bounds__(256) void fc_fwd_partial_kernel(const float* __restrict__ flat, const float* __restrict__ wfc,
                                                              float* __restrict__ part, int B, int K) {
@@ -185,8 +255,7 @@ int64_t fc_ws_floats(int width, int B) {
 int launch_fc_fwd(int width, int B, const float* flat, const float* wfc, const float* bfc, const float* eps,
                   const float* pred, float* mu, float* logvar, float* zcat, float* ws, hipStream_t st) {
     const int K = bott(width);
-    const int smem = FC_IMGS * (K / FC_KS) * 4;
-    hipLaunchKernelGGL(fc_fwd_partial_kernel, dim3(cdiv(B, FC_IMGS), FC_KS), dim3(256), smem, st, flat, wfc, ws, B, K);
+    hipLaunchKernelGGL(latent_gemm_kernel<false>, dim3(cdiv(B, 128), FC_KS), dim3(256), 0, st, flat, wfc, ws, B, K, K / FC_KS, 64);
     CVAE_CHECK_LAUNCH();
     hipLaunchKernelGGL(fc_finish_kernel, dim3(cdiv(B * 32, 256)), dim3(256), 0, st, ws, bfc, eps, pred, mu, logvar, zcat, B);
     CVAE_CHECK_LAUNCH();
@@ -203,7 +272,9 @@ int launch_decin_fwd(int width, int B, const float* zcat, const float* wd, const
 int launch_decin_bwd(int width, int B, const float* zcat, const float* dh, const float* wd, float* dwd, float* dbd,
                      float* dzcat, float* ws, hipStream_t st) {
     const int K = bott(width);
-    hipLaunchKernelGGL(decin_bwd_dz_kernel, dim3(cdiv(B, 8)), dim3(256), 0, st, dh, wd, dzcat, B, K);
+    hipLaunchKernelGGL(latent_gemm_kernel<true>, dim3(cdiv(B, 128), FC_KS), dim3(256), 0, st, dh, wd, ws, B, K, K / FC_KS, 33);
+    CVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(decin_dz_finish_kernel, dim3(cdiv(B * 33, 256)), dim3(256), 0, st, ws, dzcat, B, FC_KS);
     CVAE_CHECK_LAUNCH();
     const int S = decin_splits(B), bps = cdiv(B, S);
     hipLaunchKernelGGL(decin_bwd_dw_kernel, dim3(K / 256, S), dim3(256), 0, st, zcat, dh, ws, B, K, bps);

@@ -233,12 +233,14 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_relu_kernel(const float* __r
     }
 }
 
-// after launch_col_reduce: red = [sum g | sum g*xhat] -> dgamma, dbeta, bcoef = (s1/N, s2/N)
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ red, int C, float invN, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ bcoef) {
+// rows[r] = [sum g | sum g*xhat] partials (R <= 64 rows left by launch_col_reduce_partial), summed
+// here in fixed order -> dgamma, dbeta, bcoef = (s1/N, s2/N)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ rows, int R, int64_t stride, int C, float invN,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ bcoef) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float s1 = red[c], s2 = red[C + c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < R; ++r) { s1 += rows[(size_t)r * stride + c]; s2 += rows[(size_t)r * stride + C + c]; }
     dgamma[c] = s2; dbeta[c] = s1; bcoef[c * 2] = s1 * invN; bcoef[c * 2 + 1] = s2 * invN;
 }
 
@@ -305,8 +307,9 @@ int launch_bn_pool_act_bwd(int layer, int width, int B, const float* y, const fl
     if (g.act) hipLaunchKernelGGL((bn_bwd_kernel<1, 0>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, nullptr, nullptr, part, g.C, g.H, totalPx, ppb);
     else hipLaunchKernelGGL(bn_bwd_stats_relu_kernel, dim3(nblk), dim3(256), 0, st, a, da, coef, part, g.C, totalPx, ppb);
     CVAE_CHECK_LAUNCH();
-    { int rc = launch_col_reduce(part, nblk, 2 * g.C, 2 * g.C, red, crws, st); if (rc) return rc; }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(g.C, 64)), dim3(64), 0, st, red, g.C, invN, dgamma, dbeta, bcoef);
+    const float* rows; int R; int64_t rstride;
+    { int rc = launch_col_reduce_partial(part, nblk, 2 * g.C, 2 * g.C, crws, st, &rows, &R, &rstride); if (rc) return rc; }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(g.C, 64)), dim3(64), 0, st, rows, R, rstride, g.C, invN, dgamma, dbeta, bcoef);
     CVAE_CHECK_LAUNCH();
     if (g.act) hipLaunchKernelGGL((bn_bwd_kernel<1, 1>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, bcoef, dy, part, g.C, g.H, totalPx, ppb);
     else hipLaunchKernelGGL((bn_bwd_kernel<0, 1>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, bcoef, dy, part, g.C, g.H, totalPx, ppb);

@@ -81,6 +81,8 @@ int launch_colsum(const float* src, int64_t rows, int C, float* dst, float* ws, 
 int64_t colsum_ws_floats(int64_t rows, int C);
 // reduce.hip
 int64_t col_reduce_ws_floats(int W);
+int launch_col_reduce_partial(const float* in, int R, int W, int64_t stride, float* ws, hipStream_t st,
+                              const float** rows_out, int* R_out, int64_t* stride_out);
 int launch_col_reduce(const float* in, int R, int W, int64_t stride, float* out, float* ws, hipStream_t st);
 // conv_thin.hip (E1 / D4)
 int launch_e1_fwd(int width, int B, const float* x, const float* w, const float* bias, float* y,

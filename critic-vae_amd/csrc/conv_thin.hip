@@ -20,19 +20,6 @@ __device__ __forceinline__ constexpr int e1_off(int k) {
     return k >= 75 ? 0 : (k % 3) * PS + ((k / 3) / 5) * HTW + (k / 3) % 5;
 }
 
-template <int H>
-__device__ __forceinline__ void e1_stage_x(const float* x, float* lds_x, int B, int ib, int ty0, int tx0) {
-    using T = Tile<H>;
-    for (int q = threadIdx.x; q < 3 * T::HPI; q += 256) {
-        const int c = q / T::HPI, hp = q % T::HPI;
-        const int gy = ty0 + hp / T::HTW - 2, gx = tx0 + hp % T::HTW - 2;
-        float v = 0.f;
-        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < B)
-            v = x[((size_t)(ib * 3 + c) * H + gy) * H + gx];
-        lds_x[c * T::PS + hp] = v;
-    }
-}
-
 // E1 forward.  WG = a 16-row x 32-column strip (512 pixels) of one image; wave w owns rows 4w..4w+3
 // (four 32-pixel accumulator tiles).  The whole B operand (76 x 32 weights) lives in 38 registers per
 // lane, read once from global; the x halo (3 planes) is staged once per strip.  Epilogue: bias,
@@ -152,6 +139,32 @@ __device__ __forceinline__ void thin_slab_out(f32x16 (&acc)[3], float* red, floa
     }
 }
 
+// tile mt of E1 wgrad into registers: x halo (3 planes, zero padded) and the 128x32 dy tile
+template <int H>
+__device__ __forceinline__ void e1_wgrad_fetch(const ThinWgradArgs& a, int mt, float (&rx)[(3 * Tile<H>::HPI + 255) / 256],
+                                               float4 (&rd)[4]) {
+    using T = Tile<H>;
+    const int tid = threadIdx.x;
+    const int ib = mt / T::TILES_PER_IMG, tileInImg = mt % T::TILES_PER_IMG;
+    const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;
+#pragma unroll
+    for (int i = 0; i < (3 * T::HPI + 255) / 256; ++i) {
+        const int q = tid + i * 256;
+        const int c = q / T::HPI, hp = q % T::HPI;
+        const int gy = ty0 + hp / T::HTW - 2, gx = tx0 + hp % T::HTW - 2;
+        float v = 0.f;
+        if (q < 3 * T::HPI && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H)
+            v = a.a0[((size_t)(ib * 3 + c) * H + gy) * H + gx];
+        rx[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + i * 256, c4 = q & 7, mm = q >> 3;
+        const int gy = ty0 + mm / T::TW, gx = tx0 + mm % T::TW;
+        rd[i] = *reinterpret_cast<const float4*>(a.a1 + ((size_t)(ib * H + gy) * H + gx) * 32 + c4 * 4);
+    }
+}
+
 template <int H>
 __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
     using T = Tile<H>;
@@ -176,18 +189,26 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
         for (int v = 0; v < 16; ++v) acc[mb][v] = 0.f;
     const int t0 = blockIdx.x * a.tilesPerSplit;
     int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
+    // software pipeline: the next tile's x halo and dy tile are fetched into registers while the
+    // MFMAs of the current tile run; LDS is refilled between two barriers
+    constexpr int XQ = (3 * T::HPI + 255) / 256;
+    float rx[XQ];
+    float4 rd[4];
+    if (t0 < t1) e1_wgrad_fetch<H>(a, t0, rx, rd);
     for (int mt = t0; mt < t1; ++mt) {
-        const int ib = mt / T::TILES_PER_IMG, tileInImg = mt % T::TILES_PER_IMG;
-        const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;
         __syncthreads();
-        e1_stage_x<H>(a.a0, lds_x, a.B, ib, ty0, tx0);
-        for (int q = tid; q < 128 * 8; q += 256) {
-            const int c4 = q & 7, mm = q >> 3;
-            const int gy = ty0 + mm / T::TW, gx = tx0 + mm % T::TW;
-            *reinterpret_cast<float4*>(lds_d + mm * 32 + c4 * 4) = *reinterpret_cast<const float4*>(
-                a.a1 + ((size_t)(ib * H + gy) * H + gx) * 32 + c4 * 4);
+#pragma unroll
+        for (int i = 0; i < XQ; ++i) {
+            const int q = tid + i * 256;
+            if (q < 3 * T::HPI) lds_x[(q / T::HPI) * T::PS + q % T::HPI] = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + i * 256;
+            *reinterpret_cast<float4*>(lds_d + (q >> 3) * 32 + (q & 7) * 4) = rd[i];
         }
         __syncthreads();
+        if (mt + 1 < t1) e1_wgrad_fetch<H>(a, mt + 1, rx, rd);
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const int mm = wave * 32 + 2 * kk + lh;
@@ -253,69 +274,91 @@ int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw
 
 // ------------------------------------------ D4 ------------------------------------------------
 
+// tanh through one exp: |error| ~1e-7 absolute (the reference's tanh differs from this by less than
+// the fp32 rounding of its own input sum)
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f); }
+
+// Persistent over 16x16 output tiles (10x10 source window -> 128 GEMM rows, 100 used): the permuted
+// weights B[ci][tap*3+co] live in 48 registers per lane, the next tile's window is fetched into
+// registers while the MFMAs of the current one run, and the tap gather + Tanh + NCHW store of one
+// workgroup overlaps the MFMAs of the other workgroup on the CU.
 template <int H>   // H = output size (64); source o3 is (H/2)^2 x 32 NHWC
 __global__ __launch_bounds__(256) void d4_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ recon, int B) {
-    constexpr int HS = H / 2, TPI = (H / 16) * (H / 16);
-    constexpr int A_FLOATS = 128 * 33, B_FLOATS = 32 * 96, Q_FLOATS = 128 * 97;
-    constexpr int SM = (A_FLOATS + B_FLOATS) > Q_FLOATS ? (A_FLOATS + B_FLOATS) : Q_FLOATS;
-    __shared__ __attribute__((aligned(16))) float smem[SM];
-    float* lds_a = smem;
-    float* lds_b = smem + A_FLOATS;
+    constexpr int HS = H / 2, TX = H / 16, TPI = TX * TX;
+    __shared__ __attribute__((aligned(16))) float lds_a[128 * 33];
+    __shared__ float lds_q[128 * 97];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int ib = blockIdx.x / TPI, t = blockIdx.x % TPI;
-    const int ty0 = (t / (H / 16)) * 16, tx0 = (t % (H / 16)) * 16;
-    const int sy0 = ty0 / 2 - 1, sx0 = tx0 / 2 - 1;           // 10x10 source window
-    for (int q = tid; q < 128 * 8; q += 256) {
-        const int c4 = q & 7, sp = q >> 3;
-        const int sy = sy0 + sp / 10, sx = sx0 + sp % 10;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (sp < 100 && (unsigned)sy < (unsigned)HS && (unsigned)sx < (unsigned)HS)
-            v = *reinterpret_cast<const float4*>(in + ((size_t)(ib * HS + sy) * HS + sx) * 32 + c4 * 4);
-        float* d = lds_a + sp * 33 + c4 * 4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-    for (int q = tid; q < 32 * 96; q += 256) {
-        const int ci = q / 96, n = q % 96;
-        lds_b[q] = n < 75 ? w[((n / 3) * 32 + ci) * 3 + n % 3] : 0.f;
-    }
-    __syncthreads();
-    f32x16 acc[3];
+    float bwr[16][3];
 #pragma unroll
-    for (int nb = 0; nb < 3; ++nb)
+    for (int j = 0; j < 16; ++j)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[nb][v] = 0.f;
+        for (int nb = 0; nb < 3; ++nb) {
+            const int n = nb * 32 + li, ci = 2 * j + lh;
+            bwr[j][nb] = n < 75 ? w[((n / 3) * 32 + ci) * 3 + n % 3] : 0.f;
+        }
+    const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
+    const int numTiles = B * TPI;
+    float4 ra[4];
+    auto fetch = [&](int tile) {
+        const int ib = tile / TPI, t = tile % TPI;
+        const int sy0 = (t / TX) * 8 - 1, sx0 = (t % TX) * 8 - 1;           // 10x10 source window
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const float av = lds_a[(wave * 32 + li) * 33 + 2 * j + lh];
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + i * 256, c4 = q & 7, sp = q >> 3;
+            const int sy = sy0 + sp / 10, sx = sx0 + sp % 10;
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sp < 100 && (unsigned)sy < (unsigned)HS && (unsigned)sx < (unsigned)HS)
+                ra[i] = *reinterpret_cast<const float4*>(in + ((size_t)(ib * HS + sy) * HS + sx) * 32 + c4 * 4);
+        }
+    };
+    if ((int)blockIdx.x < numTiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+        const int ib = tile / TPI, t = tile % TPI;
+        const int ty0 = (t / TX) * 16, tx0 = (t % TX) * 16, sy0 = ty0 / 2 - 1, sx0 = tx0 / 2 - 1;
+        // lds_a was last read before the previous tile's second barrier: free to refill
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + i * 256;
+            float* d = lds_a + (q >> 3) * 33 + (q & 7) * 4;
+            d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+        }
+        __syncthreads();       // also: every thread is past the previous tile's gather, lds_q is free
+        if (tile + (int)gridDim.x < numTiles) fetch(tile + gridDim.x);
+        f32x16 acc[3];
 #pragma unroll
         for (int nb = 0; nb < 3; ++nb)
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, lds_b[(2 * j + lh) * 96 + nb * 32 + li], acc[nb], 0, 0, 0);
-    }
-    __syncthreads();
-    float* lds_q = smem;                                         // [128][97]
 #pragma unroll
-    for (int nb = 0; nb < 3; ++nb)
+            for (int v = 0; v < 16; ++v) acc[nb][v] = 0.f;
 #pragma unroll
-        for (int v = 0; v < 16; ++v)
-            lds_q[(wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh) * 97 + nb * 32 + li] = acc[nb][v];
-    __syncthreads();
-    const int oy = tid >> 4, ox = tid & 15;
-    float s0 = bias[0], s1 = bias[1], s2 = bias[2];
+        for (int j = 0; j < 16; ++j) {
+            const float av = lds_a[(wave * 32 + li) * 33 + 2 * j + lh];
 #pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        const int sr = ((ty0 + oy + r - 2) >> 1) - sy0;
-#pragma unroll
-        for (int s = 0; s < 5; ++s) {
-            const int sc = ((tx0 + ox + s - 2) >> 1) - sx0;
-            const float* qv = lds_q + (sr * 10 + sc) * 97 + (r * 5 + s) * 3;
-            s0 += qv[0]; s1 += qv[1]; s2 += qv[2];
+            for (int nb = 0; nb < 3; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bwr[j][nb], acc[nb], 0, 0, 0);
         }
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                lds_q[(wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh) * 97 + nb * 32 + li] = acc[nb][v];
+        __syncthreads();
+        const int oy = tid >> 4, ox = tid & 15;
+        float s0 = b0, s1 = b1, s2 = b2;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const int sr = ((ty0 + oy + r - 2) >> 1) - sy0;
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                const int sc = ((tx0 + ox + s - 2) >> 1) - sx0;
+                const float* qv = lds_q + (sr * 10 + sc) * 97 + (r * 5 + s) * 3;
+                s0 += qv[0]; s1 += qv[1]; s2 += qv[2];
+            }
+        }
+        const size_t o = ((size_t)(ib * 3) * H + ty0 + oy) * H + tx0 + ox;
+        recon[o] = fast_tanh(s0);
+        recon[o + (size_t)H * H] = fast_tanh(s1);
+        recon[o + 2 * (size_t)H * H] = fast_tanh(s2);
     }
-    const size_t o = ((size_t)(ib * 3) * H + ty0 + oy) * H + tx0 + ox;
-    recon[o] = tanhf(s0);
-    recon[o + (size_t)H * H] = tanhf(s1);
-    recon[o + 2 * (size_t)H * H] = tanhf(s2);
 }
 
 // dOut = d_recon * (1 - recon^2) (Tanh backward, vae_nets.py:134) + per-plane sums for db
@@ -347,6 +390,30 @@ __global__ void d4_dbias_kernel(const float* __restrict__ part, float* __restric
     if (lane == 0) db[co] = acc;
 }
 
+// tile mt of the D4 backward into registers: dOut halo planes [3][20][36] (zero padded) and the o3 tile
+template <int H>
+__device__ __forceinline__ void d4_bwd_fetch(const ThinWgradArgs& a, int mt, float (&rg)[(3 * 720 + 255) / 256], float4 (&ro)[4]) {
+    constexpr int HS = H / 2, TPI = (HS / 8) * (HS / 16), G0 = 3 * 720;
+    const int tid = threadIdx.x;
+    const int ib = mt / TPI, t = mt % TPI;
+    const int sy0 = (t / (HS / 16)) * 8, sx0 = (t % (HS / 16)) * 16;
+#pragma unroll
+    for (int i = 0; i < (G0 + 255) / 256; ++i) {
+        const int q = tid + i * 256, c = q / 720, rem = q % 720;
+        const int uy = 2 * sy0 - 2 + rem / 36, ux = 2 * sx0 - 2 + rem % 36;
+        float v = 0.f;
+        if (q < G0 && (unsigned)uy < (unsigned)H && (unsigned)ux < (unsigned)H)
+            v = a.a0[((size_t)(ib * 3 + c) * H + uy) * H + ux];
+        rg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + i * 256, c4 = q & 7, sp = q >> 3;
+        ro[i] = *reinterpret_cast<const float4*>(
+            a.a1 + ((size_t)(ib * HS + sy0 + sp / 16) * HS + sx0 + sp % 16) * 32 + c4 * 4);
+    }
+}
+
 template <int H>   // H = output size (64); src tiles of 8 rows x 16 cols at HS = H/2
 __global__ __launch_bounds__(256) void d4_bwd_kernel(ThinWgradArgs a) {
     constexpr int HS = H / 2, TPI = (HS / 8) * (HS / 16);
@@ -362,6 +429,7 @@ __global__ __launch_bounds__(256) void d4_bwd_kernel(ThinWgradArgs a) {
         lds_wr[q] = k < 75 ? a.w[((k / 3) * 32 + ci) * 3 + k % 3] : 0.f;
     }
     for (int q = tid; q < 32; q += 256) lds_G[128 * 77 + q] = 0.f;
+    if (tid < 128) lds_G[tid * 77 + 75] = 0.f;               // K = 75 padded to 76: the pad column stays zero
     f32x16 accw[3];
 #pragma unroll
     for (int mb = 0; mb < 3; ++mb)
@@ -369,33 +437,48 @@ __global__ __launch_bounds__(256) void d4_bwd_kernel(ThinWgradArgs a) {
         for (int v = 0; v < 16; ++v) accw[mb][v] = 0.f;
     const int t0 = blockIdx.x * a.tilesPerSplit;
     int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
+    // software pipeline: the next tile's dOut halo and o3 tile travel through registers while this
+    // tile's G build and MFMAs run
+    constexpr int GQ = (G0 + 255) / 256;
+    float rg[GQ];
+    float4 ro[4];
+    if (t0 < t1) d4_bwd_fetch<H>(a, t0, rg, ro);
+    const int gsp = tid & 127, ghalf = tid >> 7, gsy = gsp >> 4, gsx = gsp & 15;
     for (int mt = t0; mt < t1; ++mt) {
         const int ib = mt / TPI, t = mt % TPI;
         const int sy0 = (t / (HS / 16)) * 8, sx0 = (t % (HS / 16)) * 16;
         __syncthreads();
-        for (int q = tid; q < G0; q += 256) {
-            const int c = q / 720, rem = q % 720;
-            const int uy = 2 * sy0 - 2 + rem / 36, ux = 2 * sx0 - 2 + rem % 36;
-            float v = 0.f;
-            if ((unsigned)uy < (unsigned)H && (unsigned)ux < (unsigned)H)
-                v = a.a0[((size_t)(ib * 3 + c) * H + uy) * H + ux];
-            lds_g0[q] = v;
+#pragma unroll
+        for (int i = 0; i < GQ; ++i) {
+            const int q = tid + i * 256;
+            if (q < G0) lds_g0[q] = rg[i];
         }
-        for (int q = tid; q < 128 * 8; q += 256) {
-            const int c4 = q & 7, sp = q >> 3;
-            *reinterpret_cast<float4*>(lds_o + sp * 32 + c4 * 4) = *reinterpret_cast<const float4*>(
-                a.a1 + ((size_t)(ib * HS + sy0 + sp / 16) * HS + sx0 + sp % 16) * 32 + c4 * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + i * 256;
+            *reinterpret_cast<float4*>(lds_o + (q >> 3) * 32 + (q & 7) * 4) = ro[i];
         }
         __syncthreads();
-        for (int e = tid; e < 128 * 76; e += 256) {
-            const int sp = e / 76, k = e % 76;
-            float g = 0.f;
-            if (k < 75) {
-                const int tap = k / 3, co = k % 3, r = tap / 5, s = tap % 5;
-                const float* p = lds_g0 + co * 720 + (2 * (sp / 16) - r + 4) * 36 + 2 * (sp % 16) - s + 4;
-                g = (p[0] + p[1]) + (p[36] + p[37]);
+        if (mt + 1 < t1) d4_bwd_fetch<H>(a, mt + 1, rg, ro);
+        // G[src][(r*5+s)*3+co] = sum of dOut over the 2x2 block of src shifted by the tap: thread =
+        // (src pixel, half of the 15 (co, r) pairs); the five s taps of a pair share six column sums
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pr = ghalf * 8 + i;                     // wave-uniform
+            if (pr < 15) {
+                const int co = pr / 5, r = pr % 5;
+                const float* p = lds_g0 + co * 720 + (2 * gsy - r + 4) * 36 + 2 * gsx;
+                float cs[6];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float2 u = *reinterpret_cast<const float2*>(p + 2 * j);
+                    const float2 d = *reinterpret_cast<const float2*>(p + 36 + 2 * j);
+                    cs[2 * j] = u.x + d.x; cs[2 * j + 1] = u.y + d.y;
+                }
+                float* g = lds_G + gsp * 77 + r * 15 + co;
+#pragma unroll
+                for (int sI = 0; sI < 5; ++sI) g[sI * 3] = cs[4 - sI] + cs[5 - sI];
             }
-            lds_G[sp * 77 + k] = g;
         }
         __syncthreads();
         // dgrad: d_o3[src][ci] = relu'(o3) * sum_k G[src][k] * W4r[k][ci]
@@ -437,8 +520,10 @@ int64_t d4_bwd_ws_floats(int width, int B) {
 }
 
 int launch_d4_fwd(int width, int B, const float* in, const float* w, const float* bias, float* recon, hipStream_t st) {
-    if (width == 64) hipLaunchKernelGGL(d4_fwd_kernel<64>, dim3(B * 16), dim3(256), 0, st, in, w, bias, recon, B);
-    else if (width == 128) hipLaunchKernelGGL(d4_fwd_kernel<128>, dim3(B * 64), dim3(256), 0, st, in, w, bias, recon, B);
+    // 66 KB of LDS -> two workgroups per CU, each looping over its share of the 16x16 tiles
+    const int tiles = B * (width / 16) * (width / 16), grid = tiles < 512 ? tiles : 512;
+    if (width == 64) hipLaunchKernelGGL(d4_fwd_kernel<64>, dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
+    else if (width == 128) hipLaunchKernelGGL(d4_fwd_kernel<128>, dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
     else { cvae_set_error("d4_fwd: width %d unsupported", width); return -2; }
     CVAE_CHECK_LAUNCH();
     return 0;

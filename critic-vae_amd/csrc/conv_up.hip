@@ -46,14 +46,28 @@ __global__ __launch_bounds__(256) void collapse_w_kernel(const float* __restrict
     wc[(size_t)t * n + i] = acc;
 }
 
-// dw[(r*5+s)*n + i] = sum_{py,px} dwc[((py*2+px)*9 + a(py,r)*3 + b(px,s))*n + i]
-__global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict__ dwc, float* __restrict__ dw, int n) {
+// dw[(r*5+s)*n + i] = sum_{py,px} dwc[((py*2+px)*9 + a(py,r)*3 + b(px,s))*n + i], where dwc is the sum
+// of the R (<= 32) partial rows left by the slab reduction; the bias gradient (the 36*n.. tail of
+// each row) is summed by the first workgroup.  Fixed order throughout.
+__global__ __launch_bounds__(256) void expand_dw_kernel(const float* __restrict__ rows, int R, int64_t stride,
+                                                        float* __restrict__ dw, int n, float* __restrict__ dbias,
+                                                        int cout) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (dbias != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < cout) {
+        float b = 0.f;
+        for (int q = 0; q < R; ++q) b += rows[(size_t)q * stride + (size_t)36 * n + threadIdx.x];
+        dbias[threadIdx.x] = b;
+    }
     if (i >= n) return;
     const int r = blockIdx.y / 5, s = blockIdx.y % 5;
     float acc = 0.f;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) acc += dwc[(size_t)(p * 9 + phase_of(p >> 1, r) * 3 + phase_of(p & 1, s)) * n + i];
+    for (int p = 0; p < 4; ++p) {
+        const float* src = rows + (size_t)(p * 9 + phase_of(p >> 1, r) * 3 + phase_of(p & 1, s)) * n + i;
+        float a = 0.f;
+        for (int q = 0; q < R; ++q) a += src[(size_t)q * stride];
+        acc += a;
+    }
     dw[(size_t)blockIdx.y * n + i] = acc;
 }
 
@@ -490,7 +504,7 @@ static int run_up_wgrad(int B, const float* in, const float* dout, float* dw, fl
     if (S > numTiles) S = numTiles;
     const int tps = cdiv(numTiles, S);
     S = cdiv(numTiles, tps);
-    const int64_t nc = (int64_t)36 * CIN * COUT, row = nc + COUT, n = (int64_t)25 * CIN * COUT;
+    const int64_t nc = (int64_t)36 * CIN * COUT, row = nc + COUT;
     // ws = [S slabs | 16 mid rows | reduced row]
     if (need) { *need = (int64_t)(S + 17) * row; return 0; }
     UpWgradArgs a{in, dout, ws, B, numTiles, tps};
@@ -500,15 +514,12 @@ static int run_up_wgrad(int B, const float* in, const float* dout, float* dw, fl
     CVAE_CHECK_LAUNCH();
     float* mid = ws + (size_t)S * row;
     float* red = mid + (size_t)16 * row;
-    int rc = launch_reduce_slabs(ws, red, row, S, row, st, mid);
-    if (rc) return rc;
-    hipLaunchKernelGGL(expand_dw_kernel, dim3(cdiv(CIN * COUT, 256), 25), dim3(256), 0, st, red, dw, CIN * COUT);
+    { int rc = launch_reduce_slabs(ws, red, row, S, row, st, mid); if (rc) return rc; }
+    const float* rows = red;
+    const int R = 1;
+    static_assert(COUT <= 256, "expand_dw_kernel sums the bias gradient in one workgroup");
+    hipLaunchKernelGGL(expand_dw_kernel, dim3(cdiv(CIN * COUT, 256), 25), dim3(256), 0, st, rows, R, row, dw, CIN * COUT, dbias, COUT);
     CVAE_CHECK_LAUNCH();
-    if (dbias) {
-        hipError_t e = hipMemcpyAsync(dbias, red + nc, COUT * sizeof(float), hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) { cvae_set_error("conv_up_wgrad: bias copy failed: %s", hipGetErrorString(e)); return (int)e; }
-    }
-    (void)n;
     return 0;
 }
 

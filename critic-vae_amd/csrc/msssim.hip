@@ -190,23 +190,28 @@ __global__ __launch_bounds__(1024) void msssim_finalize_kernel(MsFinArgs a) {
         if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = v;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double tot[11];
-        for (int q = 0; q < 11; ++q) { double t = 0.0; for (int wv = 0; wv < 16; ++wv) t += red[q][wv]; tot[q] = t; }
-        double ssim[5], cs[5];
-        for (int l = 0; l < 5; ++l) { ssim[l] = tot[l] / a.count[l]; cs[l] = tot[5 + l] / a.count[l]; }
-        const double k = tot[10];
+    if (threadIdx.x < 64) {
+        // lanes 0-4: ssim_l, lanes 5-9: cs_l, lane 10: KLD sum — every lane finishes its own scalar
+        // (same operations and order as a serial evaluation), shuffles bring them together
+        const int lane = threadIdx.x, l = lane % 5;
         const float wts[5] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
-        const float p2 = powf((float)ssim[4], wts[4]);
+        double t = 0.0;
+        if (lane < 11) for (int wv = 0; wv < 16; ++wv) t += red[lane][wv];
+        const double cnt = a.count[l];
+        const float meanf = (float)(t / cnt);
+        const float pw = powf(meanf, wts[l]);
+        const float p2 = __shfl(pw, 4, 64);
         float out = 1.0f;
-        for (int l = 0; l < 4; ++l) out *= powf((float)cs[l], wts[l]) * p2;     // vae_nets.py:243-246
+        for (int q = 0; q < 4; ++q) out *= __shfl(pw, 5 + q, 64) * p2;              // vae_nets.py:243-246
         const float recon = 1.0f - out;
+        const double k = __shfl(t, 10, 64);
         const float kld = a.B > 0 ? (float)(-0.5 * k / (double)a.B) * kw : 0.0f;
-        a.scalars[0] = recon + kld; a.scalars[1] = recon; a.scalars[2] = kld;
-        for (int l = 0; l < 5; ++l) { a.scalars[3 + l] = (float)ssim[l]; a.scalars[8 + l] = (float)cs[l]; }
-        a.scalars[13] = a.scalars[14] = a.scalars[15] = 0.f;
-        for (int l = 0; l < 4; ++l) a.coef[l] = (float)((double)(-out * wts[l] / (float)cs[l]) / a.count[l]);
-        a.coef[4] = (float)((double)(-out * 4.0f * wts[4] / (float)ssim[4]) / a.count[4]);
+        if (lane == 0) { a.scalars[0] = recon + kld; a.scalars[1] = recon; a.scalars[2] = kld; }
+        if (lane < 5) a.scalars[3 + lane] = meanf;
+        else if (lane < 10) a.scalars[8 + l] = meanf;
+        else if (lane < 13) a.scalars[13 + lane - 10] = 0.f;
+        if (lane >= 5 && lane < 9) a.coef[l] = (float)((double)(-out * wts[l] / meanf) / cnt);
+        if (lane == 4) a.coef[4] = (float)((double)(-out * 4.0f * wts[4] / meanf) / cnt);
     }
 }
 

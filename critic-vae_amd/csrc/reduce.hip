@@ -28,6 +28,20 @@ __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__
 
 int64_t col_reduce_ws_floats(int W) { return (int64_t)32 * W; }
 
+// First half of launch_col_reduce for callers whose next kernel can add up <= 64 rows itself:
+// returns the rows still to be summed through (*rows_out, *R_out, *stride_out).
+int launch_col_reduce_partial(const float* in, int R, int W, int64_t stride, float* ws, hipStream_t st,
+                              const float** rows_out, int* R_out, int64_t* stride_out) {
+    if (R > 64) {
+        const int RA = 32, rpb = cdiv(R, RA);
+        hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(W, 32), cdiv(R, rpb)), dim3(256), 0, st, in, R, W, stride, ws, rpb);
+        CVAE_CHECK_LAUNCH();
+        in = ws; R = cdiv(R, rpb); stride = W;
+    }
+    *rows_out = in; *R_out = R; *stride_out = stride;
+    return 0;
+}
+
 // out[w] = sum_r in[r*stride + w].  ws: col_reduce_ws_floats(W) floats (used when R > 64).
 int launch_col_reduce(const float* in, int R, int W, int64_t stride, float* out, float* ws, hipStream_t st) {
     if (R > 64) {

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
 
     constexpr int WQ = 5 * KC * NT / 4;              // float4 per weight slab
     constexpr int WPT = (WQ + 255) / 256;
-    float4 wreg[WPT];
+    f32x4 wreg[WPT];
 
     auto load_w = [&](int st) {
         const int cc = st / 5, r = st % 5;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
                     const int n = rown % NT, s = rown / NT;
                     src = a.w + (size_t)((24 - (r * 5 + s)) * NCH + n0 + n) * KCH + cc * KC + c4 * 4;
                 }
-                wreg[i] = *reinterpret_cast<const float4*>(src);
+                wreg[i] = *reinterpret_cast<const f32x4*>(src);
             }
         }
     };
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
             const int q = tid + i * 256;
             if (WQ % 256 == 0 || q < WQ) {
                 if (!DGRAD) {
-                    *reinterpret_cast<float4*>(lds_w + q * 4) = wreg[i];
+                    *reinterpret_cast<f32x4*>(lds_w + q * 4) = wreg[i];
                 } else {
                     const int c4 = q & 3, rown = q >> 2;
                     float* d = lds_w + rown * KCP + c4 * 4;   // rown = s*NT + n

@@ -142,7 +142,7 @@ __device__ __forceinline__ void thin_slab_out(f32x16 (&acc)[3], float* red, floa
 // tile mt of E1 wgrad into registers: x halo (3 planes, zero padded) and the 128x32 dy tile
 template <int H>
 __device__ __forceinline__ void e1_wgrad_fetch(const ThinWgradArgs& a, int mt, float (&rx)[(3 * Tile<H>::HPI + 255) / 256],
-                                               float4 (&rd)[4]) {
+                                               f32x4 (&rd)[4]) {
     using T = Tile<H>;
     const int tid = threadIdx.x;
     const int ib = mt / T::TILES_PER_IMG, tileInImg = mt % T::TILES_PER_IMG;
@@ -161,7 +161,7 @@ __device__ __forceinline__ void e1_wgrad_fetch(const ThinWgradArgs& a, int mt, f
     for (int i = 0; i < 4; ++i) {
         const int q = tid + i * 256, c4 = q & 7, mm = q >> 3;
         const int gy = ty0 + mm / T::TW, gx = tx0 + mm % T::TW;
-        rd[i] = *reinterpret_cast<const float4*>(a.a1 + ((size_t)(ib * H + gy) * H + gx) * 32 + c4 * 4);
+        rd[i] = *reinterpret_cast<const f32x4*>(a.a1 + ((size_t)(ib * H + gy) * H + gx) * 32 + c4 * 4);
     }
 }
 
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
     // MFMAs of the current tile run; LDS is refilled between two barriers
     constexpr int XQ = (3 * T::HPI + 255) / 256;
     float rx[XQ];
-    float4 rd[4];
+    f32x4 rd[4];
     if (t0 < t1) e1_wgrad_fetch<H>(a, t0, rx, rd);
     for (int mt = t0; mt < t1; ++mt) {
         __syncthreads();
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int q = tid + i * 256;
-            *reinterpret_cast<float4*>(lds_d + (q >> 3) * 32 + (q & 7) * 4) = rd[i];
+            *reinterpret_cast<f32x4*>(lds_d + (q >> 3) * 32 + (q & 7) * 4) = rd[i];
         }
         __syncthreads();
         if (mt + 1 < t1) e1_wgrad_fetch<H>(a, mt + 1, rx, rd);
@@ -392,7 +392,7 @@ __global__ void d4_dbias_kernel(const float* __restrict__ part, float* __restric
 
 // tile mt of the D4 backward into registers: dOut halo planes [3][20][36] (zero padded) and the o3 tile
 template <int H>
-__device__ __forceinline__ void d4_bwd_fetch(const ThinWgradArgs& a, int mt, float (&rg)[(3 * 720 + 255) / 256], float4 (&ro)[4]) {
+__device__ __forceinline__ void d4_bwd_fetch(const ThinWgradArgs& a, int mt, float (&rg)[(3 * 720 + 255) / 256], f32x4 (&ro)[4]) {
     constexpr int HS = H / 2, TPI = (HS / 8) * (HS / 16), G0 = 3 * 720;
     const int tid = threadIdx.x;
     const int ib = mt / TPI, t = mt % TPI;
@@ -409,7 +409,7 @@ __device__ __forceinline__ void d4_bwd_fetch(const ThinWgradArgs& a, int mt, flo
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int q = tid + i * 256, c4 = q & 7, sp = q >> 3;
-        ro[i] = *reinterpret_cast<const float4*>(
+        ro[i] = *reinterpret_cast<const f32x4*>(
             a.a1 + ((size_t)(ib * HS + sy0 + sp / 16) * HS + sx0 + sp % 16) * 32 + c4 * 4);
     }
 }
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void d4_bwd_kernel(ThinWgradArgs a) {
     // tile's G build and MFMAs run
     constexpr int GQ = (G0 + 255) / 256;
     float rg[GQ];
-    float4 ro[4];
+    f32x4 ro[4];
     if (t0 < t1) d4_bwd_fetch<H>(a, t0, rg, ro);
     const int gsp = tid & 127, ghalf = tid >> 7, gsy = gsp >> 4, gsx = gsp & 15;
     for (int mt = t0; mt < t1; ++mt) {
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void d4_bwd_kernel(ThinWgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int q = tid + i * 256;
-            *reinterpret_cast<float4*>(lds_o + (q >> 3) * 32 + (q & 7) * 4) = ro[i];
+            *reinterpret_cast<f32x4*>(lds_o + (q >> 3) * 32 + (q & 7) * 4) = ro[i];
         }
         __syncthreads();
         if (mt + 1 < t1) d4_bwd_fetch<H>(a, mt + 1, rg, ro);

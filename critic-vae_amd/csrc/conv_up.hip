@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void conv_up_fwd_kernel(UpArgs a) {
         for (int v = 0; v < 16; ++v) acc[p][v] = 0.f;
 
     constexpr int WQ = 12 * KC * NT / 4, WPT = WQ / 256;      // 1536 float4, 6 per thread
-    float4 wreg[WPT];
+    f32x4 wreg[WPT];
     auto load_w = [&](int st) {
         const int cc = st / 3, ar = st % 3;
 #pragma unroll
@@ -116,13 +116,13 @@ __global__ __launch_bounds__(256) void conv_up_fwd_kernel(UpArgs a) {
             const int q = tid + i * 256;
             const int row = q / (NT / 4), c4 = q % (NT / 4);      // row = (p*3+b)*KC + kc
             const int pb = row / KC, kc = row % KC, p = pb / 3, b = pb % 3;
-            wreg[i] = *reinterpret_cast<const float4*>(
+            wreg[i] = *reinterpret_cast<const f32x4*>(
                 a.wc + ((size_t)(p * 9 + ar * 3 + b) * CIN + cc * KC + kc) * COUT + n0 + c4 * 4);
         }
     };
     auto store_w = [&]() {
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) *reinterpret_cast<float4*>(lds_w + (tid + i * 256) * 4) = wreg[i];
+        for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(lds_w + (tid + i * 256) * 4) = wreg[i];
     };
     auto stage_input = [&](int cc) {
         for (int q = tid; q < T::HP * (KC / 4); q += 256) {
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void conv_up_dgrad_kernel(UpArgs a) {
         for (int v = 0; v < 16; ++v) acc[nb][v] = 0.f;
 
     constexpr int WQ = 9 * NT * KC / 4, WPT = (WQ + 255) / 256;
-    float4 wreg[WPT];
+    f32x4 wreg[WPT];
     auto load_w = [&](int st) {
         const int cc = st / 4, p = st % 4;
 #pragma unroll
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_up_dgrad_kernel(UpArgs a) {
             const int q = tid + i * 256;
             if (WQ % 256 == 0 || q < WQ) {
                 const int c4 = q & 3, rown = q >> 2, n = rown % NT, t = rown / NT;
-                wreg[i] = *reinterpret_cast<const float4*>(
+                wreg[i] = *reinterpret_cast<const f32x4*>(
                     a.wc + ((size_t)(p * 9 + t) * CIN + n0 + n) * COUT + cc * KC + c4 * 4);
             }
         }

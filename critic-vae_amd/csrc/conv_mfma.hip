@@ -104,21 +104,34 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
             }
         }
     };
-    auto stage_input = [&](int cc) {
-        constexpr int NQ = T::HP * (KC / 4);
-        for (int q = tid; q < NQ; q += 256) {
+    // input halo chunk: global -> registers (issued one chunk ahead, in flight while five stages of
+    // MFMAs run) -> LDS channel planes
+    constexpr int NQ = T::HP * (KC / 4), IPT = (NQ + 255) / 256;
+    f32x4 ireg[IPT];
+    auto load_input = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int q = tid + i * 256;
             const int c4 = q & 3, hp = q >> 2;
             const int img = hp / T::HPI, rem = hp - img * T::HPI;
             const int hy = rem / T::HTW, hx = rem - hy * T::HTW;
             const int gy = ty0 + hy - 2, gx = tx0 + hx - 2, ib = img0 + img;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((NQ % 256 == 0 || q < NQ) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B) {
                 const int sy = UP ? (gy >> 1) : gy, sx = UP ? (gx >> 1) : gx;
-                v = *reinterpret_cast<const float4*>(
-                    a.in + ((size_t)(ib * HS + sy) * HS + sx) * KCH + cc * KC + c4 * 4);
+                v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(ib * HS + sy) * HS + sx) * KCH + cc * KC + c4 * 4);
             }
-            float* d = lds_in + (c4 * 4) * T::PS + hp;
-            d[0] = v.x; d[T::PS] = v.y; d[2 * T::PS] = v.z; d[3 * T::PS] = v.w;
+            ireg[i] = v;
+        }
+    };
+    auto store_input = [&]() {
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int q = tid + i * 256;
+            if (NQ % 256 == 0 || q < NQ) {
+                float* d = lds_in + ((q & 3) * 4) * T::PS + (q >> 2);
+                d[0] = ireg[i].x; d[T::PS] = ireg[i].y; d[2 * T::PS] = ireg[i].z; d[3 * T::PS] = ireg[i].w;
+            }
         }
     };
 
@@ -127,14 +140,19 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
     constexpr int NST = (KCH / KC) / KSPLIT * 5;
     const int st0 = blockIdx.z * NST, st1 = st0 + NST;
     load_w(st0);
+    load_input(st0 / 5);
     for (int st = st0; st < st1; ++st) {
         const int r = st % 5;
         __syncthreads();                       // everyone finished reading the previous stage
-        if (r == 0) stage_input(st / 5);
+        if (r == 0) store_input();
         store_w();
+        // issue order matters: vmcnt retires in order, so the (older) halo loads must not sit
+        // between a weight load and the store_w that waits for it
+        if (r == 0 && st + 5 < st1) load_input(st / 5 + 1);     // lands during this stage's MFMAs
         if (st + 1 < st1) load_w(st + 1);      // in flight while this stage computes
         __syncthreads();
         const float* ap = lds_in + aBase + r * T::HTW;
+        __builtin_amdgcn_iglp_opt(0);
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
 #pragma unroll

@@ -78,34 +78,54 @@ __global__ __launch_bounds__(256, 2) void conv5x5_wgrad_kernel(WgradArgs a) {
     const int t0 = split * a.tilesPerSplit;
     int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
 
-    for (int mt = t0; mt < t1; ++mt) {
+    // software pipeline: tile mt+1 travels global -> registers while the MFMAs of tile mt run
+    constexpr int IQ = (T::HP * 8 + 255) / 256;
+    f32x4 rin[IQ], rdo[4];
+    auto fetch = [&](int mt) {
         const int tileInImg = mt % T::TILES_PER_IMG;
         const int img0 = (mt / T::TILES_PER_IMG) * T::IMGS;
         const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;
-        __syncthreads();
-        for (int q = tid; q < T::HP * 8; q += 256) {
+#pragma unroll
+        for (int i = 0; i < IQ; ++i) {
+            const int q = tid + i * 256;
             const int c4 = q & 7, hp = q >> 3;
             const int img = hp / T::HPI, rem = hp % T::HPI;
             const int gy = ty0 + rem / T::HTW - 2, gx = tx0 + rem % T::HTW - 2, ib = img0 + img;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (((T::HP * 8) % 256 == 0 || q < T::HP * 8) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B) {
                 const int sy = UP ? (gy >> 1) : gy, sx = UP ? (gx >> 1) : gx;
-                v = *reinterpret_cast<const float4*>(
-                    a.in + ((size_t)(ib * HS + sy) * HS + sx) * CIN + ci0 + c4 * 4);
+                v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(ib * HS + sy) * HS + sx) * CIN + ci0 + c4 * 4);
             }
-            *reinterpret_cast<float4*>(lds_in + hp * CS + c4 * 4) = v;
+            rin[i] = v;
         }
-        for (int q = tid; q < 128 * 8; q += 256) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + i * 256;
             const int c4 = q & 7, mm = q >> 3;
             const int im = mm / (T::TH * T::TW), rem = mm % (T::TH * T::TW);
             const int gy = ty0 + rem / T::TW, gx = tx0 + rem % T::TW, ib = img0 + im;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ib < a.B)
-                v = *reinterpret_cast<const float4*>(
-                    a.dout + ((size_t)(ib * H + gy) * H + gx) * COUT + n0 + c4 * 4);
-            *reinterpret_cast<float4*>(lds_d + mm * 32 + c4 * 4) = v;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ib < a.B) v = *reinterpret_cast<const f32x4*>(a.dout + ((size_t)(ib * H + gy) * H + gx) * COUT + n0 + c4 * 4);
+            rdo[i] = v;
+        }
+    };
+    if (t0 < t1) fetch(t0);
+    for (int mt = t0; mt < t1; ++mt) {
+        const int tileInImg = mt % T::TILES_PER_IMG;
+        const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < IQ; ++i) {
+            const int q = tid + i * 256;
+            if ((T::HP * 8) % 256 == 0 || q < T::HP * 8) *reinterpret_cast<f32x4*>(lds_in + (q >> 3) * CS + (q & 7) * 4) = rin[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + i * 256;
+            *reinterpret_cast<f32x4*>(lds_d + (q >> 3) * 32 + (q & 7) * 4) = rdo[i];
         }
         __syncthreads();
+        if (mt + 1 < t1) fetch(mt + 1);
         switch (wave) {
             case 0: wgrad_body<H, 0>(acc, bsum, lds_in, lds_d, li, lh, ty0, tx0); break;
             case 1: wgrad_body<H, 1>(acc, bsum, lds_in, lds_d, li, lh, ty0, tx0); break;

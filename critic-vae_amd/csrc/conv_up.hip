@@ -124,16 +124,30 @@ __global__ __launch_bounds__(256) void conv_up_fwd_kernel(UpArgs a) {
 #pragma unroll
         for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(lds_w + (tid + i * 256) * 4) = wreg[i];
     };
-    auto stage_input = [&](int cc) {
-        for (int q = tid; q < T::HP * (KC / 4); q += 256) {
+    // low-res input halo chunk: global -> registers one chunk ahead -> LDS channel planes
+    constexpr int NQ = T::HP * (KC / 4), IPT = (NQ + 255) / 256;
+    f32x4 ireg[IPT];
+    auto load_input = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int q = tid + i * 256;
             const int c4 = q & 3, hp = q >> 2;
             const int img = hp / T::HPI, rem = hp - img * T::HPI;
             const int gy = ty0 + rem / T::HTW - 1, gx = tx0 + rem % T::HTW - 1, ib = img0 + img;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)gy < (unsigned)HS && (unsigned)gx < (unsigned)HS && ib < a.B)
-                v = *reinterpret_cast<const float4*>(a.in + ((size_t)(ib * HS + gy) * HS + gx) * CIN + cc * KC + c4 * 4);
-            float* d = lds_in + (c4 * 4) * T::PS + hp;
-            d[0] = v.x; d[T::PS] = v.y; d[2 * T::PS] = v.z; d[3 * T::PS] = v.w;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((NQ % 256 == 0 || q < NQ) && (unsigned)gy < (unsigned)HS && (unsigned)gx < (unsigned)HS && ib < a.B)
+                v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(ib * HS + gy) * HS + gx) * CIN + cc * KC + c4 * 4);
+            ireg[i] = v;
+        }
+    };
+    auto store_input = [&]() {
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int q = tid + i * 256;
+            if (NQ % 256 == 0 || q < NQ) {
+                float* d = lds_in + ((q & 3) * 4) * T::PS + (q >> 2);
+                d[0] = ireg[i].x; d[T::PS] = ireg[i].y; d[2 * T::PS] = ireg[i].z; d[3 * T::PS] = ireg[i].w;
+            }
         }
     };
 
@@ -141,14 +155,17 @@ __global__ __launch_bounds__(256) void conv_up_fwd_kernel(UpArgs a) {
     constexpr int NST = (CIN / KC) / KSPLIT * 3;
     const int st0 = blockIdx.z * NST, st1 = st0 + NST;
     load_w(st0);
+    load_input(st0 / 3);
     for (int st = st0; st < st1; ++st) {
         const int ar = st % 3;
         __syncthreads();
-        if (ar == 0) stage_input(st / 3);
+        if (ar == 0) store_input();
         store_w();
+        if (ar == 0 && st + 3 < st1) load_input(st / 3 + 1);     // older than the weight load below: see conv_mfma.hip
         if (st + 1 < st1) load_w(st + 1);
         __syncthreads();
         const float* ap = lds_in + aBase + ar * T::HTW;
+        __builtin_amdgcn_iglp_opt(0);
 #pragma unroll
         for (int b = 0; b < 3; ++b)
 #pragma unroll
@@ -226,18 +243,33 @@ __global__ __launch_bounds__(256) void conv_up_dgrad_kernel(UpArgs a) {
             }
         }
     };
-    auto stage_input = [&](int cc, int p) {       // D_p[yy][xx] = dout[2yy+py][2xx+px], halo +-1, zero outside
-        const int py = p >> 1, px = p & 1;
-        for (int q = tid; q < T::HP * (KC / 4); q += 256) {
+    // D_p[yy][xx] = dout[2yy+py][2xx+px], halo +-1, zero outside: global -> registers one stage
+    // ahead -> LDS channel planes
+    constexpr int NQ = T::HP * (KC / 4), IPT = (NQ + 255) / 256;
+    f32x4 ireg[IPT];
+    auto load_input = [&](int st) {
+        const int cc = st / 4, py = (st % 4) >> 1, px = st & 1;
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int q = tid + i * 256;
             const int c4 = q & 3, hp = q >> 2;
             const int img = hp / T::HPI, rem = hp - img * T::HPI;
             const int yy = ty0 + rem / T::HTW - 1, xx = tx0 + rem % T::HTW - 1, ib = img0 + img;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)yy < (unsigned)HS && (unsigned)xx < (unsigned)HS && ib < a.B)
-                v = *reinterpret_cast<const float4*>(
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((NQ % 256 == 0 || q < NQ) && (unsigned)yy < (unsigned)HS && (unsigned)xx < (unsigned)HS && ib < a.B)
+                v = *reinterpret_cast<const f32x4*>(
                     a.in + ((size_t)(ib * H + 2 * yy + py) * H + 2 * xx + px) * COUT + cc * KC + c4 * 4);
-            float* d = lds_in + (c4 * 4) * T::PS + hp;
-            d[0] = v.x; d[T::PS] = v.y; d[2 * T::PS] = v.z; d[3 * T::PS] = v.w;
+            ireg[i] = v;
+        }
+    };
+    auto store_input = [&]() {
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int q = tid + i * 256;
+            if (NQ % 256 == 0 || q < NQ) {
+                float* d = lds_in + ((q & 3) * 4) * T::PS + (q >> 2);
+                d[0] = ireg[i].x; d[T::PS] = ireg[i].y; d[2 * T::PS] = ireg[i].z; d[3 * T::PS] = ireg[i].w;
+            }
         }
     };
 
@@ -245,12 +277,14 @@ __global__ __launch_bounds__(256) void conv_up_dgrad_kernel(UpArgs a) {
     constexpr int NST = (COUT / KC) / KSPLIT * 4;
     const int st0 = blockIdx.z * NST, st1 = st0 + NST;
     load_w(st0);
+    load_input(st0);
     for (int st = st0; st < st1; ++st) {
         __syncthreads();
-        stage_input(st / 4, st % 4);
+        store_input();
         store_w();
-        if (st + 1 < st1) load_w(st + 1);
+        if (st + 1 < st1) { load_input(st + 1); load_w(st + 1); }
         __syncthreads();
+        __builtin_amdgcn_iglp_opt(0);
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -340,29 +374,49 @@ __global__ __launch_bounds__(256, 2) void conv_up_wgrad_kernel(UpWgradArgs a) {
         for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
     const int t0 = split * a.tilesPerSplit;
     int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
-    for (int mt = t0; mt < t1; ++mt) {
+    // software pipeline: tile mt+1 travels global -> registers while the MFMAs of tile mt run
+    constexpr int IQ = (T::HP * 8 + 255) / 256;
+    f32x4 rin[IQ], rdo[8];
+    auto fetch = [&](int mt) {
         const int tileInImg = mt % T::TILES_PER_IMG, img0 = (mt / T::TILES_PER_IMG) * T::IMGS;
         const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;
-        __syncthreads();
-        for (int q = tid; q < T::HP * 8; q += 256) {
+#pragma unroll
+        for (int i = 0; i < IQ; ++i) {
+            const int q = tid + i * 256;
             const int c4 = q & 7, hp = q >> 3;
             const int img = hp / T::HPI, rem = hp % T::HPI;
             const int gy = ty0 + rem / T::HTW - 1, gx = tx0 + rem % T::HTW - 1, ib = img0 + img;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)gy < (unsigned)HS && (unsigned)gx < (unsigned)HS && ib < a.B)
-                v = *reinterpret_cast<const float4*>(a.in + ((size_t)(ib * HS + gy) * HS + gx) * CIN + ci0 + c4 * 4);
-            *reinterpret_cast<float4*>(lds_in + hp * CS + c4 * 4) = v;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (((T::HP * 8) % 256 == 0 || q < T::HP * 8) && (unsigned)gy < (unsigned)HS && (unsigned)gx < (unsigned)HS && ib < a.B)
+                v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(ib * HS + gy) * HS + gx) * CIN + ci0 + c4 * 4);
+            rin[i] = v;
         }
-        for (int q = tid; q < 4 * 64 * 8; q += 256) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = tid + i * 256;
             const int c4 = q & 7, mm = (q >> 3) & 63, p = q >> 9;
             const int im = mm / (T::TH * T::TW), rem = mm % (T::TH * T::TW);
             const int oy = 2 * (ty0 + rem / T::TW) + (p >> 1), ox = 2 * (tx0 + rem % T::TW) + (p & 1), ib = img0 + im;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ib < a.B)
-                v = *reinterpret_cast<const float4*>(a.dout + ((size_t)(ib * H + oy) * H + ox) * COUT + n0 + c4 * 4);
-            *reinterpret_cast<float4*>(lds_d + (p * 64 + mm) * 32 + c4 * 4) = v;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ib < a.B) v = *reinterpret_cast<const f32x4*>(a.dout + ((size_t)(ib * H + oy) * H + ox) * COUT + n0 + c4 * 4);
+            rdo[i] = v;
+        }
+    };
+    if (t0 < t1) fetch(t0);
+    for (int mt = t0; mt < t1; ++mt) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < IQ; ++i) {
+            const int q = tid + i * 256;
+            if ((T::HP * 8) % 256 == 0 || q < T::HP * 8) *reinterpret_cast<f32x4*>(lds_in + (q >> 3) * CS + (q & 7) * 4) = rin[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = tid + i * 256;
+            *reinterpret_cast<f32x4*>(lds_d + (q >> 9) * 64 * 32 + ((q >> 3) & 63) * 32 + (q & 7) * 4) = rdo[i];
         }
         __syncthreads();
+        if (mt + 1 < t1) fetch(mt + 1);
         const float* dph = lds_d + wave * 64 * 32 + li;
 #pragma unroll 4
         for (int kk = 0; kk < 32; ++kk) {

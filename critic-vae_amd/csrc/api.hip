@@ -105,7 +105,7 @@ static WsLayout carve(const cvae_handle_s* h, int B) {
     w.ms = take(msssim_ws_floats(W, B));
     int64_t sc = 0, scw = 0;
     auto mx = [&](int64_t v) { if (v > sc) sc = v; };
-    for (int l = 1; l <= 4; ++l) { if (wgrad_ws_floats(l, W, B) > scw) scw = wgrad_ws_floats(l, W, B); mx(conv_fwd_ws_floats(l, W, B)); }
+    for (int l = 1; l <= 4; ++l) { if (wgrad_ws_floats(l, W, B) > scw) scw = wgrad_ws_floats(l, W, B); mx(conv_fwd_ws_floats(l, W, B)); mx(conv_dgrad_ws_floats(l, W, B)); }
     for (int l = 5; l <= 7; ++l) { if (conv_up_wgrad_ws_floats(l, W, B) > scw) scw = conv_up_wgrad_ws_floats(l, W, B); mx(conv_up_ws_floats(l, W, B)); }
     if (e1_wgrad_ws_floats(W, B) > scw) scw = e1_wgrad_ws_floats(W, B);
     w.scratch_w = take(scw);
@@ -303,7 +303,7 @@ int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, c
         RC(fork(k++));
         if (i == 0) {
             { ProbeArm pa(h, 2, l); RC(launch_conv_wgrad(l, W, B, in, ws + w.d_o[0], G_(h->dec_w[0]), G_(h->dec_b[0]), scw, sd)); }
-            { ProbeArm pa(h, 1, l); RC(launch_conv_dgrad(l, W, B, ws + w.d_o[0], P_(h->dec_w[0]), nullptr, ws + w.d_h, st)); }
+            { ProbeArm pa(h, 1, l); RC(launch_conv_dgrad(l, W, B, ws + w.d_o[0], P_(h->dec_w[0]), nullptr, ws + w.d_h, ws + w.scratch, st)); }
         } else {
             { ProbeArm pa(h, 2, l); RC(launch_conv_up_wgrad(l, W, B, in, ws + w.d_o[i], G_(h->dec_w[i]), G_(h->dec_b[i]), scw, sd)); }
             { ProbeArm pa(h, 1, l); RC(launch_conv_up_dgrad(l, W, B, ws + w.d_o[i], ws + w.wc[i - 1], ws + w.o[i - 1], ws + w.d_o[i - 1], sc, st)); }
@@ -322,7 +322,7 @@ int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, c
             RC(launch_e1_wgrad(W, B, x, ws + w.d_y[0], G_(h->enc_w[0]), G_(h->enc_b[0]), scw, sd));
         } else {
             { ProbeArm pa(h, 2, l); RC(launch_conv_wgrad(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd)); }
-            { ProbeArm pa(h, 1, l); RC(launch_conv_dgrad(l, W, B, ws + w.d_y[l], P_(h->enc_w[l]), nullptr, ws + w.d_a[l - 1], st)); }
+            { ProbeArm pa(h, 1, l); RC(launch_conv_dgrad(l, W, B, ws + w.d_y[l], P_(h->enc_w[l]), nullptr, ws + w.d_a[l - 1], nullptr, st)); }
         }
     }
     if (overlap) {                                      // join: grads are complete on the caller's stream
@@ -413,7 +413,7 @@ int cvae_op_conv_dgrad(cvae_handle h, int32_t layer, int32_t B, const float* dou
         RC(launch_collapse_w(layer, wt, wc, (hipStream_t)stream));
         return launch_conv_up_dgrad(layer, h->cfg.width, B, dout, wc, mask_src, din, wc + conv_up_wc_floats(layer), (hipStream_t)stream);
     }
-    return launch_conv_dgrad(layer, h->cfg.width, B, dout, wt, mask_src, din, (hipStream_t)stream);
+    return launch_conv_dgrad(layer, h->cfg.width, B, dout, wt, mask_src, din, nullptr, (hipStream_t)stream);
 }
 
 int64_t cvae_op_scratch_floats(cvae_handle h, int32_t B) {

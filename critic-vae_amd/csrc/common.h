@@ -70,7 +70,8 @@ int launch_conv_fwd(int layer, int width, int B, const float* in, const float* w
                     float* out, float* bnpart, float* ws, hipStream_t st);
 int64_t conv_fwd_ws_floats(int layer, int width, int B);
 int launch_conv_dgrad(int layer, int width, int B, const float* dout, const float* w,
-                      const float* mask_src, float* din, hipStream_t st);
+                      const float* mask_src, float* din, float* ws, hipStream_t st);   // ws may be null (no split-K)
+int64_t conv_dgrad_ws_floats(int layer, int width, int B);
 // conv_wgrad.hip
 int64_t wgrad_ws_floats(int layer, int width, int B);
 int launch_conv_wgrad(int layer, int width, int B, const float* in, const float* dout, float* dw,

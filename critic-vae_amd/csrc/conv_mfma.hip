@@ -265,10 +265,25 @@ int launch_conv_fwd(int layer, int width, int B, const float* in, const float* w
     return -2;
 }
 
+// D0 dgrad at 4x4 images is 256 workgroups only: split-K x2 over the co chunks when the caller
+// provides scratch (the training step does; the single-op entry point runs the unsplit kernel)
+static constexpr int D0_DGRAD_KSPLIT = 2;
+int64_t conv_dgrad_ws_floats(int layer, int width, int B) {
+    if (layer != 4 || width != 64) return 0;
+    return (int64_t)D0_DGRAD_KSPLIT * B * 16 * kLayers[4].cin;
+}
+
 int launch_conv_dgrad(int layer, int width, int B, const float* dout, const float* w,
-                      const float* mask_src, float* din, hipStream_t st) {
+                      const float* mask_src, float* din, float* ws, hipStream_t st) {
     // KCH = layer Cout (channels of dout), NCH = layer Cin (channels of din)
     ConvArgs a{dout, w, nullptr, mask_src, din, nullptr, B, 0};
+    if (width == 64 && layer == 4 && ws != nullptr) {
+        const int64_t slice = (int64_t)B * 16 * 256;
+        a.out = ws; a.sliceFloats = slice;
+        int rc = run<128, 256, 4, false, true, 32, EPI_PLAIN, D0_DGRAD_KSPLIT>(a, st);
+        if (rc) return rc;
+        return launch_reduce_slabs(ws, din, slice, D0_DGRAD_KSPLIT, slice, st, nullptr);
+    }
     if (width == 64) {
         switch (layer) {
             case 1: return run<64, 32, 32, false, true, 32, EPI_PLAIN>(a, st);

@@ -32,6 +32,10 @@ LAYERS = [(3, 32, 64, 0), (32, 64, 32, 0), (64, 128, 16, 0), (128, 256, 8, 0),
           (256, 128, 4, 0), (128, 64, 8, 1), (64, 32, 16, 1), (32, 32, 32, 1), (32, 3, 64, 1)]
 KINDS = ("conv_fwd", "conv_dgrad", "conv_wgrad")
 PROBE_IDS = [k * 9 + l for k in range(3) for l in range(1, 8)]
+BN_PROBE_IDS = [27, 28, 29, 30]   # BatchNorm+pool backward apply kernel of encoder block 0..3 (HBM-bound)
+BN_CH_H = [(32, 64), (64, 32), (128, 16), (256, 8)]
+PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
 
 
 def conv_flops(layer, B):
@@ -41,7 +45,26 @@ def conv_flops(layer, B):
 
 
 def probe_name(pid):
+    if pid >= 27:
+        return f"bn_pool_bwd_apply_L{pid - 27}"
     return f"{KINDS[pid // 9]}_L{pid % 9}"
+
+
+def bn_apply_bytes(layer, B):
+    """Algorithmic HBM bytes of one BatchNorm+pool backward apply launch: read y and the pooled a, da;
+    write dy (fp32): (2 + 2/4) * B*H*H*C * 4."""
+    c, h = BN_CH_H[layer]
+    return 2.5 * B * h * h * c * 4.0
+
+
+def measured_traffic(name):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/: separate --pmc runs,
+    FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950), or None."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            return json.load(f)["bytes_per_launch"].get(name)
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def cpu_baseline(B, steps=5):
@@ -119,16 +142,17 @@ def main():
     for i in range(args.warmup):
         if probing and i == args.warmup - n_survey:
             torch.cuda.synchronize()
-            H.probe_config(PROBE_IDS)                 # last warm-up steps: time every conv kernel in-step
+            H.probe_config(PROBE_IDS + BN_PROBE_IDS)  # last warm-up steps: time every conv kernel in-step
         tr.step(*pool[i % len(pool)])
     torch.cuda.synchronize()
     if probing and n_survey:
-        for pid in PROBE_IDS:
+        for pid in PROBE_IDS + BN_PROBE_IDS:
             ms = H.probe_read(pid)
             if ms:
                 survey[pid] = sum(ms) / len(ms)
-        dominant = max(survey, key=survey.get)
-        H.probe_config([dominant])                    # timed region: only the dominant kernel
+        dominant = max((p for p in survey if p < 27), key=survey.get)
+        dominant_hbm = max((p for p in survey if p >= 27), key=survey.get)
+        H.probe_config([dominant, dominant_hbm])      # timed region: the dominant MFMA and HBM kernels only
         note(f"dominant kernel {probe_name(dominant)} ({survey[dominant] * 1e3:.1f} us)")
     barrier()
     torch.cuda.synchronize()
@@ -157,17 +181,28 @@ def main():
         res["config"]["whole_step_algorithmic_TFLOPs"] = round(B * args.steps / dt * FLOP_PER_IMG / 1e12, 2)
         if dominant is not None:
             ms = H.probe_read(dominant)
+            ms_hbm = H.probe_read(dominant_hbm)
             H.probe_config([])
             sec = sum(ms) / len(ms) * 1e-3
             fl = conv_flops(dominant % 9, B)
             res["roofline"] = {
                 "bound": "mfma", "kernel": probe_name(dominant), "achieved": round(fl / sec / 1e12, 2),
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                "traffic": measured_traffic(probe_name(dominant)) if B == 256 else None,
                 "avg_launch_us": round(sec * 1e6, 2), "launches_timed": len(ms),
                 "algorithmic_flops_per_launch": fl,
                 "in_step_TFLOPs_all_conv_kernels": {probe_name(k): round(conv_flops(k % 9, B) / (v * 1e-3) / 1e12, 1)
-                                                    for k, v in sorted(survey.items())}}
+                                                    for k, v in sorted(survey.items()) if k < 27}}
+            if ms_hbm:          # second roofline: the largest HBM-bound kernel of the step
+                sh = sum(ms_hbm) / len(ms_hbm) * 1e-3
+                by = bn_apply_bytes(dominant_hbm - 27, B)
+                res["roofline_hbm"] = {
+                    "bound": "hbm", "kernel": probe_name(dominant_hbm), "achieved": round(by / sh / 1e9, 1),
+                    "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(by / sh / 1e9 / PEAK_HBM_GBPS, 4),
+                    "traffic": measured_traffic(probe_name(dominant_hbm)) if B == 256 else None,
+                    "avg_launch_us": round(sh * 1e6, 2), "launches_timed": len(ms_hbm),
+                    "algorithmic_bytes_per_launch": by}
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(B)
     if rank == 0:

@@ -17,8 +17,9 @@ void cvae_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-// ---- in-step kernel probe: ids = kind*9 + layer, kind 0 fwd / 1 dgrad / 2 wgrad ----
-static constexpr int PROBE_IDS = 27, PROBE_CAP = 128;
+// ---- in-step kernel probe: ids = kind*9 + layer, kind 0 fwd / 1 dgrad / 2 wgrad (conv kernels);
+//      kind 3 (ids 27..30) = the BatchNorm+pool backward apply kernel of encoder block `layer` (HBM-bound) ----
+static constexpr int PROBE_IDS = 31, PROBE_CAP = 128;
 struct ProbeSlot { hipEvent_t e0[PROBE_CAP], e1[PROBE_CAP]; int n = 0; bool made = false; };
 struct ProbeState { uint32_t mask = 0; ProbeSlot slot[PROBE_IDS]; };
 static thread_local ProbeSlot* g_probe_cur = nullptr;
@@ -315,8 +316,9 @@ int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, c
                      G_(h->fc_b), ws + w.d_a[3], sc, st));
     // encoder
     for (int l = 3; l >= 0; --l) {
-        RC(launch_bn_pool_act_bwd(l, W, B, ws + w.y[l], ws + w.a[l], ws + w.d_a[l], ws + w.coef[l], P_(h->enc_g[l]),
-                                  ws + w.d_y[l], G_(h->enc_g[l]), G_(h->enc_be[l]), nullptr, sc, st));
+        { ProbeArm pa(h, 3, l);
+          RC(launch_bn_pool_act_bwd(l, W, B, ws + w.y[l], ws + w.a[l], ws + w.d_a[l], ws + w.coef[l], P_(h->enc_g[l]),
+                                    ws + w.d_y[l], G_(h->enc_g[l]), G_(h->enc_be[l]), nullptr, sc, st)); }
         RC(fork(k++));
         if (l == 0) {
             RC(launch_e1_wgrad(W, B, x, ws + w.d_y[0], G_(h->enc_w[0]), G_(h->enc_b[0]), scw, sd));

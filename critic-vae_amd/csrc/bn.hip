@@ -311,8 +311,10 @@ int launch_bn_pool_act_bwd(int layer, int width, int B, const float* y, const fl
     { int rc = launch_col_reduce_partial(part, nblk, 2 * g.C, 2 * g.C, crws, st, &rows, &R, &rstride); if (rc) return rc; }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(g.C, 64)), dim3(64), 0, st, rows, R, rstride, g.C, invN, dgamma, dbeta, bcoef);
     CVAE_CHECK_LAUNCH();
+    cvae_probe_begin(st);                       // the apply pass: reads y, a, da, writes dy — the step's largest HBM-bound kernel
     if (g.act) hipLaunchKernelGGL((bn_bwd_kernel<1, 1>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, bcoef, dy, part, g.C, g.H, totalPx, ppb);
     else hipLaunchKernelGGL((bn_bwd_kernel<0, 1>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, bcoef, dy, part, g.C, g.H, totalPx, ppb);
+    cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();
     if (dbias) return launch_col_reduce(part, nblk, g.C, g.C, dbias, crws, st);   // else: the wgrad kernel provides it
     return 0;

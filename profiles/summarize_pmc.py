@@ -16,8 +16,14 @@ def load(d):
     kt = glob.glob(d + "/*/*_kernel_trace.csv")[0]
     dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kt))}
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(cc)):
+    rows = list(csv.DictReader(open(cc)))
+    grids = collections.defaultdict(set)
+    for r in rows:
+        grids[r["Kernel_Name"]].add(r["Grid_Size"])
+    for r in rows:
         k = r["Kernel_Name"]
+        if len(grids[k]) > 1 and SPLIT_BY_GRID:      # same kernel at several sizes (one per layer): keep them apart
+            k = k[:70] + " [grid " + r["Grid_Size"] + "]"
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         agg[k]["_dur:" + r["Dispatch_Id"]] = [dur.get(r["Dispatch_Id"], 0)]
     out = {}
@@ -29,6 +35,7 @@ def load(d):
     return out
 
 
+SPLIT_BY_GRID = True
 m, f, w = (load(a) for a in sys.argv[1:4])
 wr = csv.writer(sys.stdout)
 wr.writerow(["kernel", "launches", "avg_us", "eff_clock_GHz", "mfma_pipe_util", "fetch_MB_raw", "fetch_MB_x2", "write_MB",
@@ -39,6 +46,6 @@ for k, v in sorted(m.items(), key=lambda kv: -kv[1]["dur_ns"] * kv[1]["launches"
     fe = f.get(k, {}).get("FETCH_SIZE", 0.0) * 1024 / 1e6
     wb = w.get(k, {}).get("WRITE_SIZE", 0.0) * 1024 / 1e6
     us = v["dur_ns"] / 1e3
-    wr.writerow([k[:110], v["launches"], round(us, 1), round(gui / 8 / v["dur_ns"], 2) if v["dur_ns"] else 0,
+    wr.writerow([k[:110] if "[grid" not in k else k, v["launches"], round(us, 1), round(gui / 8 / v["dur_ns"], 2) if v["dur_ns"] else 0,
                  round(mf / 1024 / (gui / 8), 3) if gui else 0, round(fe, 2), round(2 * fe, 2), round(wb, 2),
                  round((2 * fe + wb) / us * 1e3, 0) if us else 0])

@@ -28,6 +28,7 @@ import torch  # noqa: E402
 
 FLOP_PER_IMG = 1.43762e9          # fwd + dgrad + wgrad of 9 convs + 3 linears @64x64
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, matrix fp32
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md, dense bf16
 LAYERS = [(3, 32, 64, 0), (32, 64, 32, 0), (64, 128, 16, 0), (128, 256, 8, 0),
           (256, 128, 4, 0), (128, 64, 8, 1), (64, 32, 16, 1), (32, 32, 32, 1), (32, 3, 64, 1)]
 KINDS = ("conv_fwd", "conv_dgrad", "conv_wgrad")
@@ -102,6 +103,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE.json configs[1])")
+    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
+                    help="f32 = the 1e-4-parity path (default, BASELINE configs[1]); bf16 = bf16-MFMA forward/dgrad "
+                         "convs (configs[2]: use with --batch 2048)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     args = ap.parse_args()
@@ -124,7 +128,7 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    vae = VariationalAutoencoder(max_batch=B, seed=0).to(dev)
+    vae = VariationalAutoencoder(max_batch=B, seed=0, precision=args.precision).to(dev)
     tr = FusedTrainer(vae, world_size=world)
     H = vae.handle
     # synthetic inputs, resident in HBM before the timed region; each rank its own shard
@@ -171,8 +175,10 @@ def main():
         "value": round(world * B * args.steps / dt, 1), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[1]: fp32 train step (fwd+MS-SSIM/KLD loss+bwd+Adam), "
+        "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16 MFMA operands (E2-E4, D0 fwd+dgrad), f32 elsewhere",
+        "data": "synthetic",
+        "config": {"workload": ("BASELINE.json configs[1]: fp32" if args.precision == "f32" else "BASELINE.json configs[2]: bf16-MFMA")
+                               + " train step (fwd+MS-SSIM/KLD loss+bwd+Adam), "
                                f"batch {B}/GPU, 64x64x3 frames + critic scalars", "global_batch": world * B,
                    "frame": "64x64x3", "parallelism": f"dp{world}", "optimizer": "fused flat Adam",
                    "final_loss": loss, "loss_finite": bool(loss == loss and abs(loss) != float("inf"))},
@@ -185,11 +191,12 @@ def main():
             H.probe_config([])
             sec = sum(ms) / len(ms) * 1e-3
             fl = conv_flops(dominant % 9, B)
+            on_bf16 = args.precision == "bf16" and dominant // 9 < 2 and 1 <= dominant % 9 <= 4
+            peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
             res["roofline"] = {
                 "bound": "mfma", "kernel": probe_name(dominant), "achieved": round(fl / sec / 1e12, 2),
-                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": measured_traffic(probe_name(dominant)) if B == 256 else None,
+                "peak": peak, "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak, 4),
+                "traffic": measured_traffic(probe_name(dominant)) if B == 256 and args.precision == "f32" else None,
                 "avg_launch_us": round(sec * 1e6, 2), "launches_timed": len(ms),
                 "algorithmic_flops_per_launch": fl,
                 "in_step_TFLOPs_all_conv_kernels": {probe_name(k): round(conv_flops(k % 9, B) / (v * 1e-3) / 1e12, 1)

@@ -39,6 +39,7 @@ struct WsLayout {
     int64_t zcat, h, o[4];
     int64_t dout4, d_o[4], d_h, d_zcat, d_a[4], d_y[4];
     int64_t wc[3];             // phase-collapsed weights of D1..D3 (rebuilt every forward)
+    int64_t wpack;             // bf16 mode: packed E2..E4 / D0 weights, forward + dgrad orientation (rebuilt every forward)
     int64_t ms, scratch_w, scratch, total;     // scratch_w: wgrad slabs (side stream); scratch: everything else (last)
 };
 
@@ -103,6 +104,7 @@ static WsLayout carve(const cvae_handle_s* h, int B) {
     }
     w.dout4 = take((int64_t)B * 3 * W * W);
     for (int i = 0; i < 3; ++i) w.wc[i] = take(conv_up_wc_floats(5 + i));
+    w.wpack = take(h->cfg.reserved1 == 1 ? conv_bf16_pack_floats() : 0);
     w.ms = take(msssim_ws_floats(W, B));
     int64_t sc = 0, scw = 0;
     auto mx = [&](int64_t v) { if (v > sc) sc = v; };
@@ -204,6 +206,14 @@ int cvae_decode(cvae_handle h, int32_t B, const float* zcat, const float* params
 #define G_(idx) (grads + h->params[(idx)].offset)
 #define RC(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
+// cvae_config.reserved1 == 1: bf16-MFMA forward / input-gradient kernels for E2..E4 and D0 (conv_bf16.hip)
+static bool use_bf16(cvae_handle h, int layer) { return h->cfg.reserved1 == 1 && conv_bf16_supported(layer, h->cfg.width); }
+static int pack_bf16_weights(cvae_handle h, const float* params, float* ws, const WsLayout& w, hipStream_t st) {
+    if (!use_bf16(h, 1)) return 0;
+    const float* wl[4] = {P_(h->enc_w[1]), P_(h->enc_w[2]), P_(h->enc_w[3]), P_(h->dec_w[0])};
+    return launch_pack_w_bf16(wl, ws + w.wpack, st);
+}
+
 static int check(cvae_handle h, int32_t batch, const void* ws) {
     if (!h) { cvae_set_error("null handle"); return CVAE_EINVAL; }
     if (batch < 1 || batch > h->cfg.max_batch) { cvae_set_error("batch %d outside [1, %d]", batch, h->cfg.max_batch); return CVAE_EINVAL; }
@@ -219,8 +229,10 @@ int cvae_forward(cvae_handle h, int32_t B, const float* x, const float* pred, co
     float* ws = (float*)wsv;
     const WsLayout w = carve(h, B);
     const int W = h->cfg.width;
+    RC(pack_bf16_weights(h, params, ws, w, st));
     for (int l = 0; l < 4; ++l) {
         if (l == 0) RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], ws + w.bnpart[0], st));
+        else if (use_bf16(h, l)) { ProbeArm pa(h, 0, l); RC(launch_conv_fwd_bf16(l, B, ws + w.a[l - 1], ws + w.wpack, P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st)); }
         else { ProbeArm pa(h, 0, l); RC(launch_conv_fwd(l, W, B, ws + w.a[l - 1], P_(h->enc_w[l]), P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st)); }
         RC(launch_bn_fwd_finalize(l, W, B, ws + w.bnpart[l], P_(h->enc_g[l]), P_(h->enc_be[l]), bn_state + kBnOff[l],
                                   bn_state + 480 + kBnOff[l], ws + w.coef[l], ws + w.scratch, train, st));
@@ -242,12 +254,14 @@ int cvae_decode(cvae_handle h, int32_t B, const float* zcat, const float* params
     if (zcat) {
         hipError_t e = hipMemcpyAsync(ws + w.zcat, zcat, (size_t)B * 33 * sizeof(float), hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) { cvae_set_error("cvae_decode: copy failed: %s", hipGetErrorString(e)); return (int)e; }
+        RC(pack_bf16_weights(h, params, ws, w, st));          // stand-alone decode: cvae_forward did not run
     }
     RC(launch_decin_fwd(W, B, ws + w.zcat, P_(h->di_w), P_(h->di_b), ws + w.h, st));
     for (int i = 0; i < 4; ++i) {
         ProbeArm pa(h, 0, 4 + i);
         if (i == 0) {
-            RC(launch_conv_fwd(4, W, B, ws + w.h, P_(h->dec_w[0]), P_(h->dec_b[0]), ws + w.o[0], nullptr, ws + w.scratch, st));
+            if (use_bf16(h, 4)) RC(launch_conv_fwd_bf16(4, B, ws + w.h, ws + w.wpack, P_(h->dec_b[0]), ws + w.o[0], nullptr, ws + w.scratch, st));
+            else RC(launch_conv_fwd(4, W, B, ws + w.h, P_(h->dec_w[0]), P_(h->dec_b[0]), ws + w.o[0], nullptr, ws + w.scratch, st));
         } else {          // Upsample -> Conv at the low resolution with phase-collapsed weights
             RC(launch_collapse_w(4 + i, P_(h->dec_w[i]), ws + w.wc[i - 1], st));
             RC(launch_conv_up_fwd(4 + i, W, B, ws + w.o[i - 1], ws + w.wc[i - 1], P_(h->dec_b[i]), ws + w.o[i], ws + w.scratch, st));
@@ -304,7 +318,9 @@ int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, c
         RC(fork(k++));
         if (i == 0) {
             { ProbeArm pa(h, 2, l); RC(launch_conv_wgrad(l, W, B, in, ws + w.d_o[0], G_(h->dec_w[0]), G_(h->dec_b[0]), scw, sd)); }
-            { ProbeArm pa(h, 1, l); RC(launch_conv_dgrad(l, W, B, ws + w.d_o[0], P_(h->dec_w[0]), nullptr, ws + w.d_h, ws + w.scratch, st)); }
+            { ProbeArm pa(h, 1, l);
+              if (use_bf16(h, 4)) RC(launch_conv_dgrad_bf16(4, B, ws + w.d_o[0], ws + w.wpack, ws + w.d_h, ws + w.scratch, st));
+              else RC(launch_conv_dgrad(l, W, B, ws + w.d_o[0], P_(h->dec_w[0]), nullptr, ws + w.d_h, ws + w.scratch, st)); }
         } else {
             { ProbeArm pa(h, 2, l); RC(launch_conv_up_wgrad(l, W, B, in, ws + w.d_o[i], G_(h->dec_w[i]), G_(h->dec_b[i]), scw, sd)); }
             { ProbeArm pa(h, 1, l); RC(launch_conv_up_dgrad(l, W, B, ws + w.d_o[i], ws + w.wc[i - 1], ws + w.o[i - 1], ws + w.d_o[i - 1], sc, st)); }
@@ -324,7 +340,9 @@ int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, c
             RC(launch_e1_wgrad(W, B, x, ws + w.d_y[0], G_(h->enc_w[0]), G_(h->enc_b[0]), scw, sd));
         } else {
             { ProbeArm pa(h, 2, l); RC(launch_conv_wgrad(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd)); }
-            { ProbeArm pa(h, 1, l); RC(launch_conv_dgrad(l, W, B, ws + w.d_y[l], P_(h->enc_w[l]), nullptr, ws + w.d_a[l - 1], nullptr, st)); }
+            { ProbeArm pa(h, 1, l);
+              if (use_bf16(h, l)) RC(launch_conv_dgrad_bf16(l, B, ws + w.d_y[l], ws + w.wpack, ws + w.d_a[l - 1], ws + w.scratch, st));
+              else RC(launch_conv_dgrad(l, W, B, ws + w.d_y[l], P_(h->enc_w[l]), nullptr, ws + w.d_a[l - 1], nullptr, st)); }
         }
     }
     if (overlap) {                                      // join: grads are complete on the caller's stream

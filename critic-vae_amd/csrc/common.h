@@ -72,6 +72,14 @@ int64_t conv_fwd_ws_floats(int layer, int width, int B);
 int launch_conv_dgrad(int layer, int width, int B, const float* dout, const float* w,
                       const float* mask_src, float* din, float* ws, hipStream_t st);   // ws may be null (no split-K)
 int64_t conv_dgrad_ws_floats(int layer, int width, int B);
+// conv_bf16.hip — precision mode 1: bf16-MFMA forward / dgrad of layers 1..4 at width 64
+bool conv_bf16_supported(int layer, int width);
+int64_t conv_bf16_pack_floats();
+int launch_pack_w_bf16(const float* const w[4], float* packed, hipStream_t st);
+int launch_conv_fwd_bf16(int layer, int B, const float* in, const float* packed, const float* bias, float* out,
+                         float* bnpart, float* ws, hipStream_t st);
+int launch_conv_dgrad_bf16(int layer, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st);
+int launch_splitk_bias_relu(const float* slab, const float* bias, float* out, int64_t slice, int KS, int C, hipStream_t st);
 // conv_wgrad.hip
 int64_t wgrad_ws_floats(int layer, int width, int B);
 int launch_conv_wgrad(int layer, int width, int B, const float* in, const float* dout, float* dw,

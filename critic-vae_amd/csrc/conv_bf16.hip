@@ -1,0 +1,247 @@
+// conv_bf16.hip — bf16-MFMA variant of the 5x5 conv forward / input-gradient kernels
+// (precision mode 1 of cvae_config; BASELINE.json configs 3-5 ask for a bf16 implicit GEMM).
+//
+// Same call sites as conv_mfma.hip (nn.Conv2d E2..E4 and D0, vae_nets.py:74,79,84,117, and their
+// input gradients in loss.backward(), vae.py:57), same tiling (Tile<H>: 128 output pixels x NT
+// channels per workgroup, wave = 32 pixels), same fp32 epilogues (conv_epilogue.h).  What changes:
+//   * operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) when they are staged into LDS;
+//     activations, gradients, BatchNorm statistics and the master weights stay fp32 in HBM;
+//   * the contraction runs on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): one instruction covers
+//     a 16-channel block of one tap — 8x fewer instructions at half the cycles each;
+//   * a K stage = one kernel row x up to 64 channels; LDS holds 16-byte units of 8 channels,
+//     [channel octet][pixel] for the input halo (tap shifts stay 16-byte aligned, lanes read
+//     consecutive units) and [tap][octet][n] for the weight slab;
+//   * weights are re-packed once per step by pack_w_bf16_kernel into that unit order, for the
+//     forward orientation (k = ci) and the dgrad orientation (k = co, taps flipped), so ONE kernel
+//     body serves both passes.
+// Results differ from the fp32 path at the bf16 rounding level (~3e-3 relative per product);
+// tests/test_gpu_bf16.py states the tolerances.
+#include "common.h"
+#include "conv_epilogue.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct ConvBf16Args {
+    const float* in;        // fp32 NHWC, KCH channels
+    const bf16x8* wp;       // packed weights [25][KCH/16][2][NCH] units of 8 bf16
+    const float* bias;
+    float* out;
+    float* bnpart;
+    int B;
+    int64_t sliceFloats;    // KSPLIT > 1: out = slab [KSPLIT][sliceFloats]
+};
+
+__device__ __forceinline__ bf16x8 to_bf16x8(f32x4 lo, f32x4 hi) {
+    bf16x8 r;
+    r[0] = (__bf16)lo.x; r[1] = (__bf16)lo.y; r[2] = (__bf16)lo.z; r[3] = (__bf16)lo.w;
+    r[4] = (__bf16)hi.x; r[5] = (__bf16)hi.y; r[6] = (__bf16)hi.z; r[7] = (__bf16)hi.w;
+    return r;
+}
+
+template <int H> struct Bf16Geom {
+    // halo plane stride in 16-byte units: >= HP and == 2 (mod 16) so that the 16 lanes of one
+    // b128 write phase (8 octets x 2 pixels) land in 16 different 16-byte bank groups
+    static constexpr int PSP = ((Tile<H>::HP + 13) / 16) * 16 + 2;
+};
+
+template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT>
+__global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
+    using T = Tile<H>;
+    constexpr int KCB = KCH < 64 ? KCH : 64;          // channels per K chunk
+    constexpr int KB = KCB / 16, OCT = KCB / 8, NB = NT / 32;
+    constexpr int PSP = Bf16Geom<H>::PSP;
+    constexpr int A_UNITS = OCT * PSP, W_UNITS = 5 * KB * 2 * NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);
+    bf16x8* lds_w = lds_a + A_UNITS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int mt = blockIdx.x, n0 = blockIdx.y * NT;
+    const int tileInImg = mt % T::TILES_PER_IMG, img0 = (mt / T::TILES_PER_IMG) * T::IMGS;
+    const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;
+    const int m = wave * 32 + li;
+    const int pimg = m / (T::TH * T::TW), prem = m % (T::TH * T::TW);
+    const int aPix = pimg * T::HPI + (prem / T::TW) * T::HTW + (prem % T::TW);
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[nb][v] = 0.f;
+
+    // weight slab of stage (cc, r): units [s][kb][half][n] <- wp[(r*5+s)][cc*KB + kb][half][n0 + n]
+    constexpr int WPT = (W_UNITS + 255) / 256;
+    bf16x8 wreg[WPT];
+    auto load_w = [&](int st) {
+        const int cc = st / 5, r = st % 5;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int q = tid + i * 256;
+            if (W_UNITS % 256 == 0 || q < W_UNITS) {
+                const int n = q % NT, row = q / NT, half = row & 1, kb = (row >> 1) % KB, s = row / (2 * KB);
+                wreg[i] = a.wp[((size_t)((r * 5 + s) * (KCH / 16) + cc * KB + kb) * 2 + half) * NCH + n0 + n];
+            }
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int q = tid + i * 256;
+            if (W_UNITS % 256 == 0 || q < W_UNITS) lds_w[q] = wreg[i];
+        }
+    };
+    // input halo chunk: fp32 NHWC -> bf16 units [octet][halo pixel]
+    auto stage_input = [&](int cc) {
+        constexpr int NQ = T::HP * OCT;
+        for (int q = tid; q < NQ; q += 256) {
+            const int oct = q % OCT, hp = q / OCT;
+            const int img = hp / T::HPI, rem = hp - img * T::HPI;
+            const int gy = ty0 + rem / T::HTW - 2, gx = tx0 + rem % T::HTW - 2, ib = img0 + img;
+            f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B) {
+                const float* src = a.in + ((size_t)(ib * H + gy) * H + gx) * KCH + cc * KCB + oct * 8;
+                lo = *reinterpret_cast<const f32x4*>(src);
+                hi = *reinterpret_cast<const f32x4*>(src + 4);
+            }
+            lds_a[oct * PSP + hp] = to_bf16x8(lo, hi);
+        }
+    };
+
+    static_assert(KCH % KCB == 0 && (KCH / KCB) % KSPLIT == 0, "channel chunking");
+    constexpr int NST = (KCH / KCB) / KSPLIT * 5;
+    const int st0 = blockIdx.z * NST, st1 = st0 + NST;
+    load_w(st0);
+    for (int st = st0; st < st1; ++st) {
+        const int r = st % 5;
+        __syncthreads();                       // everyone finished reading the previous stage
+        if (r == 0) stage_input(st / 5);
+        store_w();
+        if (st + 1 < st1) load_w(st + 1);      // in flight while this stage computes
+        __syncthreads();
+        const bf16x8* ap = lds_a + lh * PSP + aPix + r * T::HTW;
+        const bf16x8* bp = lds_w + lh * NT + li;
+#pragma unroll
+        for (int s = 0; s < 5; ++s)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const bf16x8 av = ap[(kb * 2) * PSP + s];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bp[((s * KB + kb) * 2) * NT + nb * 32], acc[nb], 0, 0, 0);
+            }
+    }
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    if (KSPLIT > 1)
+        epilogue_store<H, NT, NCH, EPI_PLAIN>(acc, nullptr, a.out + (size_t)blockIdx.z * a.sliceFloats, nullptr, smem, a.B,
+                                              mt, n0, img0, ty0, tx0);
+    else
+        epilogue_store<H, NT, NCH, EPI>(acc, a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0);
+}
+
+// ---- weight packing: fp32 W[tap][CIN][COUT] -> bf16 units, forward (k = ci, n = co) and dgrad
+//      (k = co, n = ci, tap flipped) orientations: unit ((tap*(K/16) + kb)*2 + half)*N + n holds
+//      k = kb*16 + half*8 .. +7 ----
+struct PackJob { const float* w; bf16x8* dst; int cin, cout, dgrad; };
+struct PackJobs { PackJob j[8]; };
+
+__global__ __launch_bounds__(256) void pack_w_bf16_kernel(PackJobs jobs) {
+    const PackJob jb = jobs.j[blockIdx.y];
+    const int K = jb.dgrad ? jb.cout : jb.cin, N = jb.dgrad ? jb.cin : jb.cout;
+    const int units = 25 * (K / 8) * N;
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {
+        const int n = u % N, row = u / N, half = row & 1, kb = (row >> 1) % (K / 16), tap = row / (2 * (K / 16));
+        const int k0 = kb * 16 + half * 8;
+        bf16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = jb.dgrad ? jb.w[((size_t)(24 - tap) * jb.cin + n) * jb.cout + k0 + e]
+                                     : jb.w[((size_t)tap * jb.cin + k0 + e) * jb.cout + n];
+            r[e] = (__bf16)v;
+        }
+        jb.dst[u] = r;
+    }
+}
+
+// packed copies of layers 1..4 live in one workspace block: [fwd L1 | dgrad L1 | fwd L2 | ...]
+static int64_t pack_units(int layer) { return (int64_t)25 * kLayers[layer].cin * kLayers[layer].cout / 8; }
+int64_t conv_bf16_pack_floats() {
+    int64_t u = 0;
+    for (int l = 1; l <= 4; ++l) u += 2 * pack_units(l);
+    return u * 4;                               // 16-byte units -> floats
+}
+static bf16x8* pack_ptr(float* packed, int layer, int dgrad) {
+    int64_t u = 0;
+    for (int l = 1; l < layer; ++l) u += 2 * pack_units(l);
+    if (dgrad) u += pack_units(layer);
+    return reinterpret_cast<bf16x8*>(packed) + u;
+}
+
+int launch_pack_w_bf16(const float* const w[4], float* packed, hipStream_t st) {
+    PackJobs jobs;
+    for (int l = 1; l <= 4; ++l)
+        for (int d = 0; d < 2; ++d)
+            jobs.j[(l - 1) * 2 + d] = PackJob{w[l - 1], pack_ptr(packed, l, d), kLayers[l].cin, kLayers[l].cout, d};
+    hipLaunchKernelGGL(pack_w_bf16_kernel, dim3(128, 8), dim3(256), 0, st, jobs);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT = 1>
+static int run_bf16(const ConvBf16Args& a, hipStream_t st) {
+    using T = Tile<H>;
+    constexpr int KCB = KCH < 64 ? KCH : 64;
+    constexpr int STAGE = ((KCB / 8) * Bf16Geom<H>::PSP + 5 * (KCB / 16) * 2 * NT) * 16;
+    constexpr int EPI_BYTES = (8 * NT > 4 * 32 * 36 ? 8 * NT : 4 * 32 * 36) * 4;
+    constexpr int SMEM = STAGE > EPI_BYTES ? STAGE : EPI_BYTES;
+    auto kern = conv5x5_bf16_kernel<KCH, NCH, H, NT, EPI, KSPLIT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        attr_set = true;
+    }
+    dim3 grid(cdiv(a.B, T::IMGS) * T::TILES_PER_IMG, NCH / NT, KSPLIT);
+    cvae_probe_begin(st);
+    hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, st, a);
+    cvae_probe_end(st);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+bool conv_bf16_supported(int layer, int width) { return width == 64 && layer >= 1 && layer <= 4; }
+
+int launch_conv_fwd_bf16(int layer, int B, const float* in, const float* packed, const float* bias, float* out,
+                         float* bnpart, float* ws, hipStream_t st) {
+    ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0), bias, out, bnpart, B, 0};
+    switch (layer) {
+        case 1: return run_bf16<32, 64, 32, 64, EPI_BIAS_BNSTAT>(a, st);
+        case 2: return run_bf16<64, 128, 16, 64, EPI_BIAS_BNSTAT>(a, st);
+        case 3: return run_bf16<128, 256, 8, 64, EPI_BIAS_BNSTAT>(a, st);
+        case 4: {
+            const int64_t slice = (int64_t)B * 16 * 128;
+            a.out = ws; a.sliceFloats = slice;
+            int rc = run_bf16<256, 128, 4, 64, EPI_PLAIN, 4>(a, st);
+            if (rc) return rc;
+            return launch_splitk_bias_relu(ws, bias, out, slice, 4, 128, st);
+        }
+    }
+    cvae_set_error("conv_fwd_bf16: unsupported layer %d", layer);
+    return -2;
+}
+
+int launch_conv_dgrad_bf16(int layer, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st) {
+    ConvBf16Args a{dout, pack_ptr(const_cast<float*>(packed), layer, 1), nullptr, din, nullptr, B, 0};
+    switch (layer) {
+        case 1: return run_bf16<64, 32, 32, 32, EPI_PLAIN>(a, st);
+        case 2: return run_bf16<128, 64, 16, 64, EPI_PLAIN>(a, st);
+        case 3: return run_bf16<256, 128, 8, 32, EPI_PLAIN>(a, st);
+        case 4: {
+            const int64_t slice = (int64_t)B * 16 * 256;
+            a.out = ws; a.sliceFloats = slice;
+            int rc = run_bf16<128, 256, 4, 64, EPI_PLAIN, 2>(a, st);
+            if (rc) return rc;
+            return launch_reduce_slabs(ws, din, slice, 2, slice, st, nullptr);
+        }
+    }
+    cvae_set_error("conv_dgrad_bf16: unsupported layer %d", layer);
+    return -2;
+}

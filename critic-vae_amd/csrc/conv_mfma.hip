@@ -226,6 +226,13 @@ __global__ __launch_bounds__(256) void splitk_bias_relu_kernel(const float* __re
     *reinterpret_cast<float4*>(out + i * 4) = acc;
 }
 
+int launch_splitk_bias_relu(const float* slab, const float* bias, float* out, int64_t slice, int KS, int C, hipStream_t st) {
+    hipLaunchKernelGGL(splitk_bias_relu_kernel, dim3((unsigned)((slice / 4 + 255) / 256)), dim3(256), 0, st, slab, bias, out,
+                       slice / 4, slice, KS, C);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}
+
 static constexpr int D0_KSPLIT = 4;
 int64_t conv_fwd_ws_floats(int layer, int width, int B) {
     if (layer != 4 || width != 64) return 0;

@@ -106,9 +106,17 @@ def _stream():
 class Handle:
     """Opaque library handle + the flat-parameter layout it reports."""
 
-    def __init__(self, width=64, max_batch=256, overlap_wgrad=False):
+    PRECISIONS = {"f32": 0, "bf16": 1}
+
+    def __init__(self, width=64, max_batch=256, overlap_wgrad=False, precision="f32"):
+        """precision "f32": every contraction on the exact-fp32 MFMA (the 1e-4 parity path).
+        "bf16": forward and input-gradient convs of E2..E4 / D0 on the bf16 MFMA (fp32 accumulate,
+        fp32 tensors in HBM; BASELINE.json configs 3-5); weight gradients stay fp32."""
         self.lib = load()
-        cfg = _Config(width, max_batch, int(bool(overlap_wgrad)), 0)
+        if precision not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
+        self.precision = precision
+        cfg = _Config(width, max_batch, int(bool(overlap_wgrad)), self.PRECISIONS[precision])
         h = _p()
         rc = self.lib.cvae_create(C.byref(cfg), C.byref(h))
         self._check(rc)

@@ -108,7 +108,9 @@ static WsLayout carve(const cvae_handle_s* h, int B) {
     w.ms = take(msssim_ws_floats(W, B));
     int64_t sc = 0, scw = 0;
     auto mx = [&](int64_t v) { if (v > sc) sc = v; };
-    for (int l = 1; l <= 4; ++l) { if (wgrad_ws_floats(l, W, B) > scw) scw = wgrad_ws_floats(l, W, B); mx(conv_fwd_ws_floats(l, W, B)); mx(conv_dgrad_ws_floats(l, W, B)); }
+    for (int l = 1; l <= 4; ++l) { if (wgrad_ws_floats(l, W, B) > scw) scw = wgrad_ws_floats(l, W, B);
+        if (h->cfg.reserved1 == 1 && conv_bf16_supported(l, W) && wgrad_bf16_ws_floats(l, B) > scw) scw = wgrad_bf16_ws_floats(l, B);
+        mx(conv_fwd_ws_floats(l, W, B)); mx(conv_dgrad_ws_floats(l, W, B)); }
     for (int l = 5; l <= 7; ++l) { if (conv_up_wgrad_ws_floats(l, W, B) > scw) scw = conv_up_wgrad_ws_floats(l, W, B); mx(conv_up_ws_floats(l, W, B)); }
     if (e1_wgrad_ws_floats(W, B) > scw) scw = e1_wgrad_ws_floats(W, B);
     w.scratch_w = take(scw);
@@ -317,7 +319,9 @@ int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, c
         const float* in = i == 0 ? ws + w.h : ws + w.o[i - 1];
         RC(fork(k++));
         if (i == 0) {
-            { ProbeArm pa(h, 2, l); RC(launch_conv_wgrad(l, W, B, in, ws + w.d_o[0], G_(h->dec_w[0]), G_(h->dec_b[0]), scw, sd)); }
+            { ProbeArm pa(h, 2, l);
+              if (use_bf16(h, 4)) RC(launch_conv_wgrad_bf16(4, B, in, ws + w.d_o[0], G_(h->dec_w[0]), G_(h->dec_b[0]), scw, sd));
+              else RC(launch_conv_wgrad(l, W, B, in, ws + w.d_o[0], G_(h->dec_w[0]), G_(h->dec_b[0]), scw, sd)); }
             { ProbeArm pa(h, 1, l);
               if (use_bf16(h, 4)) RC(launch_conv_dgrad_bf16(4, B, ws + w.d_o[0], ws + w.wpack, ws + w.d_h, ws + w.scratch, st));
               else RC(launch_conv_dgrad(l, W, B, ws + w.d_o[0], P_(h->dec_w[0]), nullptr, ws + w.d_h, ws + w.scratch, st)); }
@@ -339,7 +343,9 @@ int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, c
         if (l == 0) {
             RC(launch_e1_wgrad(W, B, x, ws + w.d_y[0], G_(h->enc_w[0]), G_(h->enc_b[0]), scw, sd));
         } else {
-            { ProbeArm pa(h, 2, l); RC(launch_conv_wgrad(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd)); }
+            { ProbeArm pa(h, 2, l);
+              if (use_bf16(h, l)) RC(launch_conv_wgrad_bf16(l, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd));
+              else RC(launch_conv_wgrad(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd)); }
             { ProbeArm pa(h, 1, l);
               if (use_bf16(h, l)) RC(launch_conv_dgrad_bf16(l, B, ws + w.d_y[l], ws + w.wpack, ws + w.d_a[l - 1], ws + w.scratch, st));
               else RC(launch_conv_dgrad(l, W, B, ws + w.d_y[l], P_(h->enc_w[l]), nullptr, ws + w.d_a[l - 1], nullptr, st)); }

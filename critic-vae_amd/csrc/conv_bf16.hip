@@ -245,3 +245,209 @@ int launch_conv_dgrad_bf16(int layer, int B, const float* dout, const float* pac
     cvae_set_error("conv_dgrad_bf16: unsupported layer %d", layer);
     return -2;
 }
+
+// ---------------------------------------------------------------------------------------------
+// weight gradients on the bf16 MFMA: dW[tap][ci][co] = sum_{img,y,x} in[img][y+r-2][x+s-2][ci] * dy[img][y][x][co]
+// (the wgrad half of loss.backward() for nn.Conv2d E2..E4 / D0).  GEMM M = ci (32), N = co (32),
+// K = pixels.  The MFMA wants 8 consecutive k per lane; a tap shift must not break 16-byte
+// alignment, so k runs over IMAGES: one 16-byte LDS unit = the values of 8 images at one (pixel,
+// channel), lanes 0-31 take pixel p and lanes 32-63 pixel p+1 — one instruction contracts 2 pixels
+// x 8 images.  Workgroup = 8 images x (4 x TW) pixels x 32 ci x 32 co, all 25 taps; wave w owns
+// taps w, w+4, .., w+20 and row w of tap 24 (as conv_wgrad.hip).  Staging transposes on the fly:
+// a thread loads the same 4 channels of the 8 images (8 coalesced 16-byte loads), rounds to bf16
+// and writes 4 units.  The bias gradient is summed from the fp32 values while they pass through
+// the registers.  Split-K slabs + fixed-order reduce_slabs as in the fp32 kernel.
+// ---------------------------------------------------------------------------------------------
+template <int H> struct WgTile {
+    static constexpr int TW = H < 8 ? H : 8, TH = 4;
+    static constexpr int HTW = TW + 4, HTH = TH + 4, HP = HTW * HTH, NPX = TH * TW;
+    static constexpr int TILES_X = H / TW, TILES_Y = H / TH, TILES_PER_GRP = TILES_X * TILES_Y;
+};
+
+struct WgradBf16Args {
+    const float* in;     // (B,H,H,CIN) fp32
+    const float* dout;   // (B,H,H,COUT) fp32
+    float* slab;         // [S][25*CIN*COUT + COUT]
+    int B, numTiles, tilesPerSplit;
+};
+
+template <int H, int W>
+__device__ __forceinline__ void wgrad_bf16_body(f32x16 (&acc)[7], const bf16x8* lds_in, const bf16x8* lds_d, int li, int lh) {
+    using T = WgTile<H>;
+#pragma unroll
+    for (int pp = 0; pp < T::NPX / 2; ++pp) {
+        const int py = pp / (T::TW / 2), px = (pp % (T::TW / 2)) * 2;
+        const bf16x8 bv = lds_d[(py * T::TW + px + lh) * 32 + li];
+        const bf16x8* ip = lds_in + (py * T::HTW + px + lh) * 32 + li;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int tap = 4 * j + W, r = tap / 5, s = tap % 5;
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ip[(r * T::HTW + s) * 32], bv, acc[j], 0, 0, 0);
+        }
+        if (py == W) acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ip[(4 * T::HTW + 4) * 32], bv, acc[6], 0, 0, 0);
+    }
+}
+
+template <int CIN, int COUT, int H>
+__global__ __launch_bounds__(256, 2) void conv5x5_wgrad_bf16_kernel(WgradBf16Args a) {
+    using T = WgTile<H>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16x8* lds_in = reinterpret_cast<bf16x8*>(smem_raw);       // [halo pixel][32 ci] units of 8 images
+    bf16x8* lds_d = lds_in + T::HP * 32;                        // [pixel][32 co]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int split = blockIdx.x, ci0 = blockIdx.y * 32, n0 = blockIdx.z * 32;
+    const int quad = tid & 7;                                   // the 4 channels this thread stages (fixed)
+
+    f32x16 acc[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+    const int t0 = split * a.tilesPerSplit;
+    int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
+    for (int mt = t0; mt < t1; ++mt) {
+        const int grp = mt / T::TILES_PER_GRP, t = mt % T::TILES_PER_GRP;
+        const int img0 = grp * 8, ty0 = (t / T::TILES_X) * T::TH, tx0 = (t % T::TILES_X) * T::TW;
+        __syncthreads();
+        for (int q = tid; q < T::HP * 8; q += 256) {
+            const int hp = q >> 3;
+            const int gy = ty0 + hp / T::HTW - 2, gx = tx0 + hp % T::HTW - 2;
+            const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H;
+            f32x4 v[8];
+#pragma unroll
+            for (int im = 0; im < 8; ++im) {
+                v[im] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (inb && img0 + im < a.B)
+                    v[im] = *reinterpret_cast<const f32x4*>(a.in + ((size_t)((img0 + im) * H + gy) * H + gx) * CIN + ci0 + quad * 4);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bf16x8 u;
+#pragma unroll
+                for (int im = 0; im < 8; ++im) u[im] = (__bf16)v[im][c];
+                lds_in[hp * 32 + quad * 4 + c] = u;
+            }
+        }
+        for (int q = tid; q < T::NPX * 8; q += 256) {
+            const int px = q >> 3;
+            const int gy = ty0 + px / T::TW, gx = tx0 + px % T::TW;
+            f32x4 v[8];
+#pragma unroll
+            for (int im = 0; im < 8; ++im) {
+                v[im] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (img0 + im < a.B)
+                    v[im] = *reinterpret_cast<const f32x4*>(a.dout + ((size_t)((img0 + im) * H + gy) * H + gx) * COUT + n0 + quad * 4);
+                bsum += v[im];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bf16x8 u;
+#pragma unroll
+                for (int im = 0; im < 8; ++im) u[im] = (__bf16)v[im][c];
+                lds_d[px * 32 + quad * 4 + c] = u;
+            }
+        }
+        __syncthreads();
+        switch (wave) {
+            case 0: wgrad_bf16_body<H, 0>(acc, lds_in, lds_d, li, lh); break;
+            case 1: wgrad_bf16_body<H, 1>(acc, lds_in, lds_d, li, lh); break;
+            case 2: wgrad_bf16_body<H, 2>(acc, lds_in, lds_d, li, lh); break;
+            default: wgrad_bf16_body<H, 3>(acc, lds_in, lds_d, li, lh); break;
+        }
+    }
+
+    float* out = a.slab + (size_t)split * (25 * CIN * COUT + COUT);     // slab row: [25][CIN][COUT] | bias[COUT]
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int ci = ci0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            out[((size_t)(4 * j + wave) * CIN + ci) * COUT + n0 + li] = acc[j][v];
+        }
+    // tap 24: each wave holds the partial of its pixel rows; bias: 32 threads per channel quad
+    float* red = reinterpret_cast<float*>(smem_raw);
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) red[((wave - 1) * 16 + v) * 64 + lane] = acc[6][v];
+    }
+    f32x4* bred = reinterpret_cast<f32x4*>(red + 3 * 16 * 64);
+    bred[tid] = bsum;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float x = ((acc[6][v] + red[v * 64 + lane]) + red[(16 + v) * 64 + lane]) + red[(32 + v) * 64 + lane];
+            const int ci = ci0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            out[((size_t)24 * CIN + ci) * COUT + n0 + li] = x;
+        }
+    }
+    if (blockIdx.y == 0 && tid < 8) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 32; ++k) s += bred[k * 8 + tid];
+        *reinterpret_cast<f32x4*>(out + (size_t)25 * CIN * COUT + n0 + tid * 4) = s;
+    }
+}
+
+template <int H>
+static int wgrad_bf16_splits(int B, int blocksPerSplit, int* tilesPerSplit, int* numTilesOut) {
+    using T = WgTile<H>;
+    const int numTiles = cdiv(B, 8) * T::TILES_PER_GRP;
+    int S = cdiv(512, blocksPerSplit);
+    if (S > numTiles) S = numTiles;
+    if (S < 1) S = 1;
+    const int tps = cdiv(numTiles, S);
+    S = cdiv(numTiles, tps);
+    *tilesPerSplit = tps; *numTilesOut = numTiles;
+    return S;
+}
+
+template <int CIN, int COUT, int H>
+static int run_wgrad_bf16(int B, const float* in, const float* dout, float* dw, float* dbias, float* ws, hipStream_t st,
+                          int64_t* need) {
+    using T = WgTile<H>;
+    int tps, numTiles;
+    const int S = wgrad_bf16_splits<H>(B, (CIN / 32) * (COUT / 32), &tps, &numTiles);
+    const int64_t n = (int64_t)25 * CIN * COUT, row = n + COUT;
+    if (need) { *need = (int64_t)(S + 16) * row; return 0; }
+    WgradBf16Args a{in, dout, ws, B, numTiles, tps};
+    constexpr int STAGE = (T::HP + T::NPX) * 32 * 16, RED = (3 * 16 * 64) * 4 + 256 * 16;
+    constexpr int SMEM = STAGE > RED ? STAGE : RED;
+    auto kern = conv5x5_wgrad_bf16_kernel<CIN, COUT, H>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        attr_set = true;
+    }
+    cvae_probe_begin(st);
+    hipLaunchKernelGGL(kern, dim3(S, CIN / 32, COUT / 32), dim3(256), SMEM, st, a);
+    cvae_probe_end(st);
+    CVAE_CHECK_LAUNCH();
+    float* mid = ws + (size_t)S * row;
+    if (dbias == dw + n) return launch_reduce_slabs(ws, dw, row, S, row, st, mid);
+    int rc = launch_reduce_slabs(ws, dw, n, S, row, st, mid);
+    if (rc || !dbias) return rc;
+    return launch_reduce_slabs(ws + n, dbias, COUT, S, row, st, nullptr);
+}
+
+static int dispatch_wgrad_bf16(int layer, int B, const float* in, const float* dout, float* dw, float* dbias, float* ws,
+                               hipStream_t st, int64_t* need) {
+    switch (layer) {
+        case 1: return run_wgrad_bf16<32, 64, 32>(B, in, dout, dw, dbias, ws, st, need);
+        case 2: return run_wgrad_bf16<64, 128, 16>(B, in, dout, dw, dbias, ws, st, need);
+        case 3: return run_wgrad_bf16<128, 256, 8>(B, in, dout, dw, dbias, ws, st, need);
+        case 4: return run_wgrad_bf16<256, 128, 4>(B, in, dout, dw, dbias, ws, st, need);
+    }
+    cvae_set_error("conv_wgrad_bf16: unsupported layer %d", layer);
+    return -2;
+}
+int64_t wgrad_bf16_ws_floats(int layer, int B) {
+    int64_t need = 0;
+    if (dispatch_wgrad_bf16(layer, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &need) != 0) return 0;
+    return need;
+}
+int launch_conv_wgrad_bf16(int layer, int B, const float* in, const float* dout, float* dw, float* dbias, float* ws, hipStream_t st) {
+    return dispatch_wgrad_bf16(layer, B, in, dout, dw, dbias, ws, st, nullptr);
+}

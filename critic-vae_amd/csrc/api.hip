@@ -259,13 +259,20 @@ int cvae_decode(cvae_handle h, int32_t B, const float* zcat, const float* params
         RC(pack_bf16_weights(h, params, ws, w, st));          // stand-alone decode: cvae_forward did not run
     }
     RC(launch_decin_fwd(W, B, ws + w.zcat, P_(h->di_w), P_(h->di_b), ws + w.h, st));
+    // Upsample -> Conv of D1..D3 runs at the low resolution with phase-collapsed weights (conv_up.hip)
+    for (int i = 1; i < 4; ++i) RC(launch_collapse_w(4 + i, P_(h->dec_w[i]), ws + w.wc[i - 1], st));
+    if (use_bf16(h, 5)) {
+        const float* wcs[3] = {ws + w.wc[0], ws + w.wc[1], ws + w.wc[2]};
+        RC(launch_pack_up_bf16(wcs, ws + w.wpack, st));
+    }
     for (int i = 0; i < 4; ++i) {
         ProbeArm pa(h, 0, 4 + i);
         if (i == 0) {
             if (use_bf16(h, 4)) RC(launch_conv_fwd_bf16(4, B, ws + w.h, ws + w.wpack, P_(h->dec_b[0]), ws + w.o[0], nullptr, ws + w.scratch, st));
             else RC(launch_conv_fwd(4, W, B, ws + w.h, P_(h->dec_w[0]), P_(h->dec_b[0]), ws + w.o[0], nullptr, ws + w.scratch, st));
-        } else {          // Upsample -> Conv at the low resolution with phase-collapsed weights
-            RC(launch_collapse_w(4 + i, P_(h->dec_w[i]), ws + w.wc[i - 1], st));
+        } else if (use_bf16(h, 4 + i)) {
+            RC(launch_conv_up_fwd_bf16(4 + i, B, ws + w.o[i - 1], ws + w.wpack, P_(h->dec_b[i]), ws + w.o[i], st));
+        } else {
             RC(launch_conv_up_fwd(4 + i, W, B, ws + w.o[i - 1], ws + w.wc[i - 1], P_(h->dec_b[i]), ws + w.o[i], ws + w.scratch, st));
         }
     }
@@ -327,7 +334,9 @@ int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, c
               else RC(launch_conv_dgrad(l, W, B, ws + w.d_o[0], P_(h->dec_w[0]), nullptr, ws + w.d_h, ws + w.scratch, st)); }
         } else {
             { ProbeArm pa(h, 2, l); RC(launch_conv_up_wgrad(l, W, B, in, ws + w.d_o[i], G_(h->dec_w[i]), G_(h->dec_b[i]), scw, sd)); }
-            { ProbeArm pa(h, 1, l); RC(launch_conv_up_dgrad(l, W, B, ws + w.d_o[i], ws + w.wc[i - 1], ws + w.o[i - 1], ws + w.d_o[i - 1], sc, st)); }
+            { ProbeArm pa(h, 1, l);
+              if (use_bf16(h, l)) RC(launch_conv_up_dgrad_bf16(l, B, ws + w.d_o[i], ws + w.wpack, ws + w.o[i - 1], ws + w.d_o[i - 1], st));
+              else RC(launch_conv_up_dgrad(l, W, B, ws + w.d_o[i], ws + w.wc[i - 1], ws + w.o[i - 1], ws + w.d_o[i - 1], sc, st)); }
         }
     }
     // latent

@@ -79,6 +79,9 @@ int launch_pack_w_bf16(const float* const w[4], float* packed, hipStream_t st);
 int launch_conv_fwd_bf16(int layer, int B, const float* in, const float* packed, const float* bias, float* out,
                          float* bnpart, float* ws, hipStream_t st);
 int launch_conv_dgrad_bf16(int layer, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st);
+int launch_pack_up_bf16(const float* const wc[3], float* packed, hipStream_t st);
+int launch_conv_up_fwd_bf16(int layer, int B, const float* in, const float* packed, const float* bias, float* out, hipStream_t st);
+int launch_conv_up_dgrad_bf16(int layer, int B, const float* dout, const float* packed, const float* aux, float* din, hipStream_t st);
 int64_t wgrad_bf16_ws_floats(int layer, int B);
 int launch_conv_wgrad_bf16(int layer, int B, const float* in, const float* dout, float* dw, float* dbias, float* ws, hipStream_t st);
 int launch_splitk_bias_relu(const float* slab, const float* bias, float* out, int64_t slice, int KS, int C, hipStream_t st);

@@ -29,7 +29,17 @@ struct ConvBf16Args {
     float* bnpart;
     int B;
     int64_t sliceFloats;    // KSPLIT > 1: out = slab [KSPLIT][sliceFloats]
+    const float* aux;       // MODE_UP_DGRAD: forward output of the producing layer (ReLU mask), layout of `out`
 };
+
+// MODE_STD: 5x5 (or 3x3) conv of an NHWC tensor, epilogues of conv_epilogue.h.
+// MODE_UP_FWD: Upsample(2)->Conv5x5 (vae_nets.py:119-131) as the phase-collapsed 3x3 conv of
+//   conv_up.hip over the stored low-resolution tensor with N = 4 phases x COUT columns; the epilogue
+//   adds the bias, applies ReLU and scatters column (p, co) of low-res pixel (y, x) to output pixel
+//   (2y+py, 2x+px).
+// MODE_UP_DGRAD: its input gradient: K = 4 phases x COUT channels gathered from dout by phase
+//   (space-to-depth view), taps flipped in the packed weights, ReLU mask of the producer in the epilogue.
+enum { MODE_STD = 0, MODE_UP_FWD = 1, MODE_UP_DGRAD = 2 };
 
 __device__ __forceinline__ bf16x8 to_bf16x8(f32x4 lo, f32x4 hi) {
     bf16x8 r;
@@ -44,13 +54,15 @@ template <int H> struct Bf16Geom {
     static constexpr int PSP = ((Tile<H>::HP + 13) / 16) * 16 + 2;
 };
 
-template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT>
+template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT, int KS = 5, int MODE = MODE_STD>
 __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     using T = Tile<H>;
+    constexpr int OFF = 2 - KS / 2;                   // a 3x3 window sits one pixel inside the 5x5 halo
+    constexpr int COUT_UP = (MODE == MODE_UP_FWD) ? NCH / 4 : KCH / 4;   // conv channels of the upsampled layer
     constexpr int KCB = KCH < 64 ? KCH : 64;          // channels per K chunk
     constexpr int KB = KCB / 16, OCT = KCB / 8, NB = NT / 32;
     constexpr int PSP = Bf16Geom<H>::PSP;
-    constexpr int A_UNITS = OCT * PSP, W_UNITS = 5 * KB * 2 * NT;
+    constexpr int A_UNITS = OCT * PSP, W_UNITS = KS * KB * 2 * NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);
     bf16x8* lds_w = lds_a + A_UNITS;
@@ -73,13 +85,13 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     constexpr int WPT = (W_UNITS + 255) / 256;
     bf16x8 wreg[WPT];
     auto load_w = [&](int st) {
-        const int cc = st / 5, r = st % 5;
+        const int cc = st / KS, r = st % KS;
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int q = tid + i * 256;
             if (W_UNITS % 256 == 0 || q < W_UNITS) {
                 const int n = q % NT, row = q / NT, half = row & 1, kb = (row >> 1) % KB, s = row / (2 * KB);
-                wreg[i] = a.wp[((size_t)((r * 5 + s) * (KCH / 16) + cc * KB + kb) * 2 + half) * NCH + n0 + n];
+                wreg[i] = a.wp[((size_t)((r * KS + s) * (KCH / 16) + cc * KB + kb) * 2 + half) * NCH + n0 + n];
             }
         }
     };
@@ -99,7 +111,13 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
             const int gy = ty0 + rem / T::HTW - 2, gx = tx0 + rem % T::HTW - 2, ib = img0 + img;
             f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
             if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B) {
-                const float* src = a.in + ((size_t)(ib * H + gy) * H + gx) * KCH + cc * KCB + oct * 8;
+                const float* src;
+                if (MODE == MODE_UP_DGRAD) {        // channel k = p*COUT + co of the low-res view = dout[2y+py][2x+px][co]
+                    const int k0 = cc * KCB + oct * 8, p = k0 / COUT_UP, co = k0 % COUT_UP;
+                    src = a.in + ((size_t)(ib * 2 * H + 2 * gy + (p >> 1)) * (2 * H) + 2 * gx + (p & 1)) * COUT_UP + co;
+                } else {
+                    src = a.in + ((size_t)(ib * H + gy) * H + gx) * KCH + cc * KCB + oct * 8;
+                }
                 lo = *reinterpret_cast<const f32x4*>(src);
                 hi = *reinterpret_cast<const f32x4*>(src + 4);
             }
@@ -108,20 +126,20 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     };
 
     static_assert(KCH % KCB == 0 && (KCH / KCB) % KSPLIT == 0, "channel chunking");
-    constexpr int NST = (KCH / KCB) / KSPLIT * 5;
+    constexpr int NST = (KCH / KCB) / KSPLIT * KS;
     const int st0 = blockIdx.z * NST, st1 = st0 + NST;
     load_w(st0);
     for (int st = st0; st < st1; ++st) {
-        const int r = st % 5;
+        const int r = st % KS;
         __syncthreads();                       // everyone finished reading the previous stage
-        if (r == 0) stage_input(st / 5);
+        if (r == 0) stage_input(st / KS);
         store_w();
         if (st + 1 < st1) load_w(st + 1);      // in flight while this stage computes
         __syncthreads();
-        const bf16x8* ap = lds_a + lh * PSP + aPix + r * T::HTW;
+        const bf16x8* ap = lds_a + lh * PSP + aPix + (r + OFF) * T::HTW + OFF;
         const bf16x8* bp = lds_w + lh * NT + li;
 #pragma unroll
-        for (int s = 0; s < 5; ++s)
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 const bf16x8 av = ap[(kb * 2) * PSP + s];
@@ -131,42 +149,89 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
             }
     }
     float* smem = reinterpret_cast<float*>(smem_raw);
-    if (KSPLIT > 1)
+    if (MODE != MODE_STD) {
+        // per-wave transpose through LDS, then 16-byte stores (as epilogue_store)
+        __syncthreads();
+        float* patch = smem + wave * (32 * 36);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int n = n0 + nb * 32;                               // 32 columns of one phase (COUT >= 32)
+            const int p = MODE == MODE_UP_FWD ? n / COUT_UP : 0, c0 = MODE == MODE_UP_FWD ? n % COUT_UP : n;
+            const float bv = MODE == MODE_UP_FWD ? a.bias[c0 + li] : 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float x = acc[nb][v] + bv;
+                if (MODE == MODE_UP_FWD) x = fmaxf(x, 0.f);
+                patch[((v & 3) + 8 * (v >> 2) + 4 * lh) * 36 + li] = x;
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = it * 64 + lane, px = idx >> 3, c4 = idx & 7;
+                f32x4 val = *reinterpret_cast<const f32x4*>(patch + px * 36 + c4 * 4);
+                const int mm = wave * 32 + px;
+                const int im = mm / (T::TH * T::TW), rem = mm % (T::TH * T::TW);
+                const int gy = ty0 + rem / T::TW, gx = tx0 + rem % T::TW, ib = img0 + im;
+                if (ib >= a.B) continue;
+                if (MODE == MODE_UP_FWD) {
+                    const size_t o = ((size_t)(ib * 2 * H + 2 * gy + (p >> 1)) * (2 * H) + 2 * gx + (p & 1)) * COUT_UP + c0 + c4 * 4;
+                    *reinterpret_cast<f32x4*>(a.out + o) = val;
+                } else {
+                    const size_t o = ((size_t)(ib * H + gy) * H + gx) * NCH + c0 + c4 * 4;
+                    const f32x4 mk = *reinterpret_cast<const f32x4*>(a.aux + o);
+                    val.x = mk.x > 0.f ? val.x : 0.f; val.y = mk.y > 0.f ? val.y : 0.f;
+                    val.z = mk.z > 0.f ? val.z : 0.f; val.w = mk.w > 0.f ? val.w : 0.f;
+                    *reinterpret_cast<f32x4*>(a.out + o) = val;
+                }
+            }
+        }
+    } else if (KSPLIT > 1) {
         epilogue_store<H, NT, NCH, EPI_PLAIN>(acc, nullptr, a.out + (size_t)blockIdx.z * a.sliceFloats, nullptr, smem, a.B,
                                               mt, n0, img0, ty0, tx0);
-    else
+    } else {
         epilogue_store<H, NT, NCH, EPI>(acc, a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0);
+    }
 }
 
-// ---- weight packing: fp32 W[tap][CIN][COUT] -> bf16 units, forward (k = ci, n = co) and dgrad
-//      (k = co, n = ci, tap flipped) orientations: unit ((tap*(K/16) + kb)*2 + half)*N + n holds
-//      k = kb*16 + half*8 .. +7 ----
-struct PackJob { const float* w; bf16x8* dst; int cin, cout, dgrad; };
+// ---- weight packing into bf16 units: unit ((tap*(K/16) + kb)*2 + half)*N + n holds k = kb*16 + half*8 .. +7.
+//   PACK_FWD    : fp32 W[25][CIN][COUT]            -> k = ci, n = co
+//   PACK_DGRAD  : same source, taps flipped        -> k = co, n = ci
+//   PACK_UPFWD  : collapsed wc[4][9][CIN][COUT]    -> k = ci, n = p*COUT + co          (9 taps)
+//   PACK_UPDGRAD: same source, taps flipped        -> k = p*COUT + co, n = ci          (9 taps)
+enum { PACK_FWD = 0, PACK_DGRAD = 1, PACK_UPFWD = 2, PACK_UPDGRAD = 3 };
+struct PackJob { const float* w; bf16x8* dst; int cin, cout, mode; };
 struct PackJobs { PackJob j[8]; };
 
 __global__ __launch_bounds__(256) void pack_w_bf16_kernel(PackJobs jobs) {
     const PackJob jb = jobs.j[blockIdx.y];
-    const int K = jb.dgrad ? jb.cout : jb.cin, N = jb.dgrad ? jb.cin : jb.cout;
-    const int units = 25 * (K / 8) * N;
+    if (jb.w == nullptr) return;
+    const int cin = jb.cin, cout = jb.cout, mode = jb.mode;
+    const int taps = mode >= PACK_UPFWD ? 9 : 25;
+    const int K = mode == PACK_FWD || mode == PACK_UPFWD ? cin : (mode == PACK_DGRAD ? cout : 4 * cout);
+    const int N = mode == PACK_FWD ? cout : (mode == PACK_UPFWD ? 4 * cout : cin);
+    const int units = taps * (K / 8) * N;
     for (int u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {
         const int n = u % N, row = u / N, half = row & 1, kb = (row >> 1) % (K / 16), tap = row / (2 * (K / 16));
         const int k0 = kb * 16 + half * 8;
         bf16x8 r;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float v = jb.dgrad ? jb.w[((size_t)(24 - tap) * jb.cin + n) * jb.cout + k0 + e]
-                                     : jb.w[((size_t)tap * jb.cin + k0 + e) * jb.cout + n];
+            const int k = k0 + e;
+            float v;
+            if (mode == PACK_FWD) v = jb.w[((size_t)tap * cin + k) * cout + n];
+            else if (mode == PACK_DGRAD) v = jb.w[((size_t)(24 - tap) * cin + n) * cout + k];
+            else if (mode == PACK_UPFWD) v = jb.w[((size_t)((n / cout) * 9 + tap) * cin + k) * cout + n % cout];
+            else v = jb.w[((size_t)((k / cout) * 9 + 8 - tap) * cin + n) * cout + k % cout];
             r[e] = (__bf16)v;
         }
         jb.dst[u] = r;
     }
 }
 
-// packed copies of layers 1..4 live in one workspace block: [fwd L1 | dgrad L1 | fwd L2 | ...]
-static int64_t pack_units(int layer) { return (int64_t)25 * kLayers[layer].cin * kLayers[layer].cout / 8; }
+// packed copies live in one workspace block: [fwd L1 | dgrad L1 | ... | dgrad L4 | upfwd L5 | updgrad L5 | ... L7]
+static int64_t pack_units(int layer) { return (int64_t)(layer >= 5 ? 36 : 25) * kLayers[layer].cin * kLayers[layer].cout / 8; }
 int64_t conv_bf16_pack_floats() {
     int64_t u = 0;
-    for (int l = 1; l <= 4; ++l) u += 2 * pack_units(l);
+    for (int l = 1; l <= 7; ++l) u += 2 * pack_units(l);
     return u * 4;                               // 16-byte units -> floats
 }
 static bf16x8* pack_ptr(float* packed, int layer, int dgrad) {
@@ -180,20 +245,31 @@ int launch_pack_w_bf16(const float* const w[4], float* packed, hipStream_t st) {
     PackJobs jobs;
     for (int l = 1; l <= 4; ++l)
         for (int d = 0; d < 2; ++d)
-            jobs.j[(l - 1) * 2 + d] = PackJob{w[l - 1], pack_ptr(packed, l, d), kLayers[l].cin, kLayers[l].cout, d};
+            jobs.j[(l - 1) * 2 + d] = PackJob{w[l - 1], pack_ptr(packed, l, d), kLayers[l].cin, kLayers[l].cout, d ? PACK_DGRAD : PACK_FWD};
     hipLaunchKernelGGL(pack_w_bf16_kernel, dim3(128, 8), dim3(256), 0, st, jobs);
     CVAE_CHECK_LAUNCH();
     return 0;
 }
+// collapsed weights wc[i] of D1..D3 (conv_up.hip: collapse_w_kernel must have run on `st` before)
+int launch_pack_up_bf16(const float* const wc[3], float* packed, hipStream_t st) {
+    PackJobs jobs;
+    for (int i = 0; i < 8; ++i) jobs.j[i] = PackJob{nullptr, nullptr, 0, 0, 0};
+    for (int l = 5; l <= 7; ++l)
+        for (int d = 0; d < 2; ++d)
+            jobs.j[(l - 5) * 2 + d] = PackJob{wc[l - 5], pack_ptr(packed, l, d), kLayers[l].cin, kLayers[l].cout, d ? PACK_UPDGRAD : PACK_UPFWD};
+    hipLaunchKernelGGL(pack_w_bf16_kernel, dim3(32, 6), dim3(256), 0, st, jobs);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}
 
-template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT = 1>
+template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT = 1, int KS = 5, int MODE = MODE_STD>
 static int run_bf16(const ConvBf16Args& a, hipStream_t st) {
     using T = Tile<H>;
     constexpr int KCB = KCH < 64 ? KCH : 64;
-    constexpr int STAGE = ((KCB / 8) * Bf16Geom<H>::PSP + 5 * (KCB / 16) * 2 * NT) * 16;
+    constexpr int STAGE = ((KCB / 8) * Bf16Geom<H>::PSP + KS * (KCB / 16) * 2 * NT) * 16;
     constexpr int EPI_BYTES = (8 * NT > 4 * 32 * 36 ? 8 * NT : 4 * 32 * 36) * 4;
     constexpr int SMEM = STAGE > EPI_BYTES ? STAGE : EPI_BYTES;
-    auto kern = conv5x5_bf16_kernel<KCH, NCH, H, NT, EPI, KSPLIT>;
+    auto kern = conv5x5_bf16_kernel<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -207,11 +283,11 @@ static int run_bf16(const ConvBf16Args& a, hipStream_t st) {
     return 0;
 }
 
-bool conv_bf16_supported(int layer, int width) { return width == 64 && layer >= 1 && layer <= 4; }
+bool conv_bf16_supported(int layer, int width) { return width == 64 && layer >= 1 && layer <= 7; }
 
 int launch_conv_fwd_bf16(int layer, int B, const float* in, const float* packed, const float* bias, float* out,
                          float* bnpart, float* ws, hipStream_t st) {
-    ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0), bias, out, bnpart, B, 0};
+    ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0), bias, out, bnpart, B, 0, nullptr};
     switch (layer) {
         case 1: return run_bf16<32, 64, 32, 64, EPI_BIAS_BNSTAT>(a, st);
         case 2: return run_bf16<64, 128, 16, 64, EPI_BIAS_BNSTAT>(a, st);
@@ -229,7 +305,7 @@ int launch_conv_fwd_bf16(int layer, int B, const float* in, const float* packed,
 }
 
 int launch_conv_dgrad_bf16(int layer, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st) {
-    ConvBf16Args a{dout, pack_ptr(const_cast<float*>(packed), layer, 1), nullptr, din, nullptr, B, 0};
+    ConvBf16Args a{dout, pack_ptr(const_cast<float*>(packed), layer, 1), nullptr, din, nullptr, B, 0, nullptr};
     switch (layer) {
         case 1: return run_bf16<64, 32, 32, 32, EPI_PLAIN>(a, st);
         case 2: return run_bf16<128, 64, 16, 64, EPI_PLAIN>(a, st);
@@ -243,6 +319,30 @@ int launch_conv_dgrad_bf16(int layer, int B, const float* dout, const float* pac
         }
     }
     cvae_set_error("conv_dgrad_bf16: unsupported layer %d", layer);
+    return -2;
+}
+
+// Upsample(2)->Conv5x5 of D1..D3 (layers 5..7) on the bf16 MFMA: phase-collapsed 3x3 conv at the stored
+// low resolution (see conv_up.hip for the algebra); `in` = stored low-res activation (B,HS,HS,CIN).
+int launch_conv_up_fwd_bf16(int layer, int B, const float* in, const float* packed, const float* bias, float* out, hipStream_t st) {
+    ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0), bias, out, nullptr, B, 0, nullptr};
+    switch (layer) {
+        case 5: return run_bf16<128, 256, 4, 64, EPI_PLAIN, 1, 3, MODE_UP_FWD>(a, st);
+        case 6: return run_bf16<64, 128, 8, 64, EPI_PLAIN, 1, 3, MODE_UP_FWD>(a, st);
+        case 7: return run_bf16<32, 128, 16, 64, EPI_PLAIN, 1, 3, MODE_UP_FWD>(a, st);
+    }
+    cvae_set_error("conv_up_fwd_bf16: unsupported layer %d", layer);
+    return -2;
+}
+// d_in (B,HS,HS,CIN) = relu'(aux) * sum over phases/taps of dout (B,2HS,2HS,COUT)
+int launch_conv_up_dgrad_bf16(int layer, int B, const float* dout, const float* packed, const float* aux, float* din, hipStream_t st) {
+    ConvBf16Args a{dout, pack_ptr(const_cast<float*>(packed), layer, 1), nullptr, din, nullptr, B, 0, aux};
+    switch (layer) {
+        case 5: return run_bf16<256, 128, 4, 32, EPI_PLAIN, 1, 3, MODE_UP_DGRAD>(a, st);
+        case 6: return run_bf16<128, 64, 8, 32, EPI_PLAIN, 1, 3, MODE_UP_DGRAD>(a, st);
+        case 7: return run_bf16<128, 32, 16, 32, EPI_PLAIN, 1, 3, MODE_UP_DGRAD>(a, st);
+    }
+    cvae_set_error("conv_up_dgrad_bf16: unsupported layer %d", layer);
     return -2;
 }
 

@@ -333,7 +333,7 @@ int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, c
               if (use_bf16(h, 4)) RC(launch_conv_dgrad_bf16(4, B, ws + w.d_o[0], ws + w.wpack, ws + w.d_h, ws + w.scratch, st));
               else RC(launch_conv_dgrad(l, W, B, ws + w.d_o[0], P_(h->dec_w[0]), nullptr, ws + w.d_h, ws + w.scratch, st)); }
         } else {
-            { ProbeArm pa(h, 2, l); RC(launch_conv_up_wgrad(l, W, B, in, ws + w.d_o[i], G_(h->dec_w[i]), G_(h->dec_b[i]), scw, sd)); }
+            { ProbeArm pa(h, 2, l); RC(launch_conv_up_wgrad(l, W, B, in, ws + w.d_o[i], G_(h->dec_w[i]), G_(h->dec_b[i]), scw, sd, use_bf16(h, l))); }
             { ProbeArm pa(h, 1, l);
               if (use_bf16(h, l)) RC(launch_conv_up_dgrad_bf16(l, B, ws + w.d_o[i], ws + w.wpack, ws + w.o[i - 1], ws + w.d_o[i - 1], st));
               else RC(launch_conv_up_dgrad(l, W, B, ws + w.d_o[i], ws + w.wc[i - 1], ws + w.o[i - 1], ws + w.d_o[i - 1], sc, st)); }

@@ -120,7 +120,8 @@ int launch_conv_up_dgrad(int layer, int width, int B, const float* dout, const f
                          float* din, float* ws, hipStream_t st);
 int64_t conv_up_wgrad_ws_floats(int layer, int width, int B);
 int launch_conv_up_wgrad(int layer, int width, int B, const float* in, const float* dout, float* dw,
-                         float* dbias, float* ws, hipStream_t st);
+                         float* dbias, float* ws, hipStream_t st, bool bf16 = false);
+int launch_up_wgrad_bf16_main(int layer, int B, const float* in, const float* dout, float* slab, int Smax, int* S_out, hipStream_t st);
 // bn.hip
 int bn_num_tiles(int layer, int width, int B);
 int launch_bn_fwd_finalize(int layer, int width, int B, const float* bnpart, const float* gamma,

@@ -551,3 +551,138 @@ int64_t wgrad_bf16_ws_floats(int layer, int B) {
 int launch_conv_wgrad_bf16(int layer, int B, const float* in, const float* dout, float* dw, float* dbias, float* ws, hipStream_t st) {
     return dispatch_wgrad_bf16(layer, B, in, dout, dw, dbias, ws, st, nullptr);
 }
+
+// ---------------------------------------------------------------------------------------------
+// weight gradients of the phase-collapsed up-convs (D1..D3) on the bf16 MFMA:
+//   dwc[p][t][ci][co] = sum_{img,y,x} in[img][y+a-1][x+b-1][ci] * dout[img][2y+py][2x+px][co],  t = a*3+b
+// Same operand scheme as conv5x5_wgrad_bf16_kernel (k over 8 images, lane halves = adjacent pixels);
+// workgroup = 8 images x 16 low-res pixels x 32 ci x 32 co, wave w = output phase w with its 9 taps
+// (as conv_up_wgrad_kernel).  The slab row [36][CIN][COUT] | bias[COUT] is what conv_up.hip's
+// reduce + expand_dw_kernel consume.
+// ---------------------------------------------------------------------------------------------
+template <int HS> struct UpWgTile {
+    static constexpr int TW = HS < 8 ? HS : 8, TH = 16 / TW;              // 16 low-res pixels
+    static constexpr int HTW = TW + 2, HTH = TH + 2, HP = HTW * HTH, NPX = 16;
+    static constexpr int TILES_X = HS / TW, TILES_Y = HS / TH, TILES_PER_GRP = TILES_X * TILES_Y;
+};
+
+template <int CIN, int COUT, int HS>
+__global__ __launch_bounds__(256, 2) void conv_up_wgrad_bf16_kernel(WgradBf16Args a) {
+    using T = UpWgTile<HS>;
+    constexpr int H = 2 * HS;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[(T::HP + 4 * T::NPX) * 32 * 16];
+    bf16x8* lds_in = reinterpret_cast<bf16x8*>(smem_raw);       // [halo pixel][32 ci]
+    bf16x8* lds_d = lds_in + T::HP * 32;                        // [phase][pixel][32 co]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int split = blockIdx.x, ci0 = blockIdx.y * 32, n0 = blockIdx.z * 32;
+    const int quad = tid & 7;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const int t0 = split * a.tilesPerSplit;
+    int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
+    for (int mt = t0; mt < t1; ++mt) {
+        const int grp = mt / T::TILES_PER_GRP, t = mt % T::TILES_PER_GRP;
+        const int img0 = grp * 8, ty0 = (t / T::TILES_X) * T::TH, tx0 = (t % T::TILES_X) * T::TW;
+        __syncthreads();
+        for (int q = tid; q < T::HP * 8; q += 256) {
+            const int hp = q >> 3;
+            const int gy = ty0 + hp / T::HTW - 1, gx = tx0 + hp % T::HTW - 1;
+            const bool inb = (unsigned)gy < (unsigned)HS && (unsigned)gx < (unsigned)HS;
+            f32x4 v[8];
+#pragma unroll
+            for (int im = 0; im < 8; ++im) {
+                v[im] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (inb && img0 + im < a.B)
+                    v[im] = *reinterpret_cast<const f32x4*>(a.in + ((size_t)((img0 + im) * HS + gy) * HS + gx) * CIN + ci0 + quad * 4);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bf16x8 u;
+#pragma unroll
+                for (int im = 0; im < 8; ++im) u[im] = (__bf16)v[im][c];
+                lds_in[hp * 32 + quad * 4 + c] = u;
+            }
+        }
+        for (int q = tid; q < 4 * T::NPX * 8; q += 256) {
+            const int px = (q >> 3) % T::NPX, p = q / (8 * T::NPX);
+            const int oy = 2 * (ty0 + px / T::TW) + (p >> 1), ox = 2 * (tx0 + px % T::TW) + (p & 1);
+            f32x4 v[8];
+#pragma unroll
+            for (int im = 0; im < 8; ++im) {
+                v[im] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (img0 + im < a.B)
+                    v[im] = *reinterpret_cast<const f32x4*>(a.dout + ((size_t)((img0 + im) * H + oy) * H + ox) * COUT + n0 + quad * 4);
+                bsum += v[im];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bf16x8 u;
+#pragma unroll
+                for (int im = 0; im < 8; ++im) u[im] = (__bf16)v[im][c];
+                lds_d[(p * T::NPX + px) * 32 + quad * 4 + c] = u;
+            }
+        }
+        __syncthreads();
+        const bf16x8* dph = lds_d + wave * T::NPX * 32 + li;
+#pragma unroll
+        for (int pp = 0; pp < T::NPX / 2; ++pp) {
+            const int py = pp / (T::TW / 2), px = (pp % (T::TW / 2)) * 2;
+            const bf16x8 bv = dph[(py * T::TW + px + lh) * 32];
+            const bf16x8* ip = lds_in + (py * T::HTW + px + lh) * 32 + li;
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9)
+                acc[t9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ip[((t9 / 3) * T::HTW + t9 % 3) * 32], bv, acc[t9], 0, 0, 0);
+        }
+    }
+    float* out = a.slab + (size_t)split * (36 * CIN * COUT + COUT);
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int ci = ci0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            out[((size_t)(wave * 9 + t9) * CIN + ci) * COUT + n0 + li] = acc[t9][v];
+        }
+    __syncthreads();
+    f32x4* bred = reinterpret_cast<f32x4*>(smem_raw);
+    bred[tid] = bsum;
+    __syncthreads();
+    if (blockIdx.y == 0 && tid < 8) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 32; ++k) s += bred[k * 8 + tid];
+        *reinterpret_cast<f32x4*>(out + (size_t)36 * CIN * COUT + n0 + tid * 4) = s;
+    }
+}
+
+template <int CIN, int COUT, int HS>
+static int run_up_wgrad_bf16_main(int B, const float* in, const float* dout, float* slab, int Smax, int* S_out, hipStream_t st) {
+    using T = UpWgTile<HS>;
+    const int numTiles = cdiv(B, 8) * T::TILES_PER_GRP;
+    int S = cdiv(384, (CIN / 32) * (COUT / 32));
+    if (S > Smax) S = Smax;
+    if (S > numTiles) S = numTiles;
+    if (S < 1) S = 1;
+    const int tps = cdiv(numTiles, S);
+    S = cdiv(numTiles, tps);
+    WgradBf16Args a{in, dout, slab, B, numTiles, tps};
+    cvae_probe_begin(st);
+    hipLaunchKernelGGL((conv_up_wgrad_bf16_kernel<CIN, COUT, HS>), dim3(S, CIN / 32, COUT / 32), dim3(256), 0, st, a);
+    cvae_probe_end(st);
+    CVAE_CHECK_LAUNCH();
+    *S_out = S;
+    return 0;
+}
+
+// main kernel only: writes S (<= Smax) slab rows [36][CIN][COUT] | bias[COUT]; conv_up.hip reduces and expands them
+int launch_up_wgrad_bf16_main(int layer, int B, const float* in, const float* dout, float* slab, int Smax, int* S_out, hipStream_t st) {
+    switch (layer) {
+        case 5: return run_up_wgrad_bf16_main<128, 64, 4>(B, in, dout, slab, Smax, S_out, st);
+        case 6: return run_up_wgrad_bf16_main<64, 32, 8>(B, in, dout, slab, Smax, S_out, st);
+        case 7: return run_up_wgrad_bf16_main<32, 32, 16>(B, in, dout, slab, Smax, S_out, st);
+    }
+    cvae_set_error("conv_up_wgrad_bf16: unsupported layer %d", layer);
+    return -2;
+}

@@ -550,7 +550,7 @@ int launch_conv_up_dgrad(int layer, int width, int B, const float* dout, const f
 
 template <int CIN, int COUT, int HS>
 static int run_up_wgrad(int B, const float* in, const float* dout, float* dw, float* dbias, float* ws, hipStream_t st,
-                        int64_t* need) {
+                        int64_t* need, int bf16_layer = 0) {
     using T = UpTile64<HS>;
     const int numTiles = cdiv(B, T::IMGS) * T::TILES_PER_IMG;
     const int bps = (CIN / 32) * (COUT / 32);
@@ -561,11 +561,16 @@ static int run_up_wgrad(int B, const float* in, const float* dout, float* dw, fl
     const int64_t nc = (int64_t)36 * CIN * COUT, row = nc + COUT;
     // ws = [S slabs | 16 mid rows | reduced row]
     if (need) { *need = (int64_t)(S + 17) * row; return 0; }
-    UpWgradArgs a{in, dout, ws, B, numTiles, tps};
-    cvae_probe_begin(st);
-    hipLaunchKernelGGL((conv_up_wgrad_kernel<CIN, COUT, HS>), dim3(S, CIN / 32, COUT / 32), dim3(256), 0, st, a);
-    cvae_probe_end(st);
-    CVAE_CHECK_LAUNCH();
+    if (bf16_layer) {          // precision mode 1: same slab rows from the bf16-MFMA kernel (conv_bf16.hip), S' <= S of them
+        int rc = launch_up_wgrad_bf16_main(bf16_layer, B, in, dout, ws, S, &S, st);
+        if (rc) return rc;
+    } else {
+        UpWgradArgs a{in, dout, ws, B, numTiles, tps};
+        cvae_probe_begin(st);
+        hipLaunchKernelGGL((conv_up_wgrad_kernel<CIN, COUT, HS>), dim3(S, CIN / 32, COUT / 32), dim3(256), 0, st, a);
+        cvae_probe_end(st);
+        CVAE_CHECK_LAUNCH();
+    }
     float* mid = ws + (size_t)S * row;
     float* red = mid + (size_t)16 * row;
     { int rc = launch_reduce_slabs(ws, red, row, S, row, st, mid); if (rc) return rc; }
@@ -578,12 +583,12 @@ static int run_up_wgrad(int B, const float* in, const float* dout, float* dw, fl
 }
 
 static int dispatch_up_wgrad(int layer, int width, int B, const float* in, const float* dout, float* dw, float* dbias,
-                             float* ws, hipStream_t st, int64_t* need) {
+                             float* ws, hipStream_t st, int64_t* need, bool bf16 = false) {
     if (width == 64) {
         switch (layer) {
-            case 5: return run_up_wgrad<128, 64, 4>(B, in, dout, dw, dbias, ws, st, need);
-            case 6: return run_up_wgrad<64, 32, 8>(B, in, dout, dw, dbias, ws, st, need);
-            case 7: return run_up_wgrad<32, 32, 16>(B, in, dout, dw, dbias, ws, st, need);
+            case 5: return run_up_wgrad<128, 64, 4>(B, in, dout, dw, dbias, ws, st, need, bf16 ? 5 : 0);
+            case 6: return run_up_wgrad<64, 32, 8>(B, in, dout, dw, dbias, ws, st, need, bf16 ? 6 : 0);
+            case 7: return run_up_wgrad<32, 32, 16>(B, in, dout, dw, dbias, ws, st, need, bf16 ? 7 : 0);
         }
     }
     if (width == 128) {
@@ -602,6 +607,6 @@ int64_t conv_up_wgrad_ws_floats(int layer, int width, int B) {
     return need;
 }
 int launch_conv_up_wgrad(int layer, int width, int B, const float* in, const float* dout, float* dw, float* dbias,
-                         float* ws, hipStream_t st) {
-    return dispatch_up_wgrad(layer, width, B, in, dout, dw, dbias, ws, st, nullptr);
+                         float* ws, hipStream_t st, bool bf16) {
+    return dispatch_up_wgrad(layer, width, B, in, dout, dw, dbias, ws, st, nullptr, bf16 && width == 64);
 }

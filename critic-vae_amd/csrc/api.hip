@@ -138,6 +138,8 @@ const char* cvae_last_error(void) { return g_err; }
 int cvae_create(const cvae_config* cfg, cvae_handle* out) {
     if (!cfg || !out) { cvae_set_error("cvae_create: null argument"); return CVAE_EINVAL; }
     if (cfg->width != 64 && cfg->width != 128) { cvae_set_error("cvae_create: width %d not supported (64 or 128)", cfg->width); return CVAE_EUNSUPPORTED; }
+    if (cfg->reserved1 != 0 && cfg->reserved1 != 1) { cvae_set_error("cvae_create: precision %d not supported (0 = fp32, 1 = bf16 MFMA)", cfg->reserved1); return CVAE_EUNSUPPORTED; }
+    if (cfg->reserved1 == 1 && cfg->width != 64) { cvae_set_error("cvae_create: the bf16 MFMA kernels are instantiated for width 64 only"); return CVAE_EUNSUPPORTED; }
     cvae_handle_s* h = new cvae_handle_s();
     h->cfg = *cfg;
     h->param_total = 0;

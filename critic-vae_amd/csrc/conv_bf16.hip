@@ -14,6 +14,8 @@
 //   * weights are re-packed once per step by pack_w_bf16_kernel into that unit order, for the
 //     forward orientation (k = ci) and the dgrad orientation (k = co, taps flipped), so ONE kernel
 //     body serves both passes.
+// The file also holds the bf16 weight-gradient kernels (k runs over images so that tap shifts keep
+// 16-byte alignment) and the bf16 variants of the phase-collapsed up-convs of conv_up.hip.
 // Results differ from the fp32 path at the bf16 rounding level (~3e-3 relative per product);
 // tests/test_gpu_bf16.py states the tolerances.
 #include "common.h"
@@ -495,7 +497,7 @@ template <int H>
 static int wgrad_bf16_splits(int B, int blocksPerSplit, int* tilesPerSplit, int* numTilesOut) {
     using T = WgTile<H>;
     const int numTiles = cdiv(B, 8) * T::TILES_PER_GRP;
-    int S = cdiv(512, blocksPerSplit);
+    int S = cdiv(512, blocksPerSplit);                // ~2 workgroups per CU (256 and 1024 measured slower)
     if (S > numTiles) S = numTiles;
     if (S < 1) S = 1;
     const int tps = cdiv(numTiles, S);

@@ -80,3 +80,28 @@ def test_bf16_training_trajectory_tracks_fp32():
     assert np.isfinite(curves["bf16"]).all()
     assert np.abs(curves["bf16"] - curves["f32"]).max() < 2e-2
     assert curves["bf16"][-1] < 0.6 * curves["bf16"][0]
+
+
+def test_bf16_mode_is_width_64_only_and_rejects_unknown_precisions():
+    from critic_vae_amd.lib import Handle, CvaeError
+    with pytest.raises(CvaeError):
+        Handle(128, 4, precision="bf16")
+    with pytest.raises(ValueError):
+        Handle(64, 4, precision="fp8")
+
+
+def test_bf16_inference_path_matches_fp32_mode():
+    """evaluate / decode (cvae_forward(recon=NULL) + stand-alone cvae_decode, which re-packs the bf16
+    weights itself) in bf16 mode vs the fp32 mode of the same library."""
+    from critic_vae_amd.nets import VariationalAutoencoder
+    dev = torch.device("cuda:0")
+    B = 6
+    x, pred, _ = (torch.from_numpy(v).to(dev) for v in synth.make_batch(7, 0, B))
+    outs = {}
+    for prec in ("f32", "bf16"):
+        vae = VariationalAutoencoder(max_batch=B, seed=3, precision=prec).to(dev).eval()
+        with torch.no_grad():
+            mu, logvar = vae.encoder(x)
+            outs[prec] = (mu.cpu(), vae.decoder(mu, pred).cpu())
+    assert (outs["bf16"][0] - outs["f32"][0]).abs().max() < 3e-2
+    assert (outs["bf16"][1] - outs["f32"][1]).abs().max() < 3e-2

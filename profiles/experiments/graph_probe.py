@@ -1,6 +1,6 @@
 """Experiment: does replaying the whole step as one HIP graph beat stream launches?"""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from critic_vae_amd.nets import VariationalAutoencoder
 from critic_vae_amd.train import FusedTrainer

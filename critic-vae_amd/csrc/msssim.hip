@@ -82,7 +82,39 @@ __global__ __launch_bounds__(256) void msssim_fwd_kernel(MsFwdArgs a) {
     float w[11];
 #pragma unroll
     for (int t = 0; t < 11; ++t) w[t] = c_win[t];
-    // horizontal pass
+    // horizontal pass.  Large levels (one plane per workgroup): 4 adjacent outputs per work item from
+    // a 14-wide register window (3.5 LDS reads per output instead of 22); same fma order per output.
+    if constexpr (S >= 32) {
+        constexpr int CG = S / 4;
+        for (int it = threadIdx.x; it < G::HR * CG; it += 256) {
+            const int r = it / CG, c = (it % CG) * 4;
+            const float* px = lin + r * G::HC + c;
+            const float* py = px + PER_IN;
+            float xs[14], ys[14];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const float2 u = *reinterpret_cast<const float2*>(px + 2 * i);
+                const float2 v = *reinterpret_cast<const float2*>(py + 2 * i);
+                xs[2 * i] = u.x; xs[2 * i + 1] = u.y; ys[2 * i] = v.x; ys[2 * i + 1] = v.y;
+            }
+            f32x4 o0, o1, o2, o3, o4;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float hx = 0.f, hy = 0.f, hxx = 0.f, hyy = 0.f, hxy = 0.f;
+#pragma unroll
+                for (int t = 0; t < 11; ++t) {
+                    const float xv = xs[o + t], yv = ys[o + t];
+                    hx = fmaf(w[t], xv, hx); hy = fmaf(w[t], yv, hy);
+                    hxx = fmaf(w[t], xv * xv, hxx); hyy = fmaf(w[t], yv * yv, hyy); hxy = fmaf(w[t], xv * yv, hxy);
+                }
+                o0[o] = hx; o1[o] = hy; o2[o] = hxx; o3[o] = hyy; o4[o] = hxy;
+            }
+            float* d = tmp + r * S + c;
+            *reinterpret_cast<f32x4*>(d) = o0; *reinterpret_cast<f32x4*>(d + PER_T) = o1;
+            *reinterpret_cast<f32x4*>(d + 2 * PER_T) = o2; *reinterpret_cast<f32x4*>(d + 3 * PER_T) = o3;
+            *reinterpret_cast<f32x4*>(d + 4 * PER_T) = o4;
+        }
+    } else {
     for (int q = threadIdx.x; q < PER_T; q += 256) {
         const int pl = q / (G::HR * S), rem = q % (G::HR * S), r = rem / S, c = rem % S;
         const float* px = lin + (pl * G::HR + r) * G::HC + c;
@@ -96,21 +128,12 @@ __global__ __launch_bounds__(256) void msssim_fwd_kernel(MsFwdArgs a) {
         }
         tmp[q] = hx; tmp[PER_T + q] = hy; tmp[2 * PER_T + q] = hxx; tmp[3 * PER_T + q] = hyy; tmp[4 * PER_T + q] = hxy;
     }
+    }
     __syncthreads();
     // vertical pass + maps
     const float C1 = 0.0001f, C2 = 0.0009f;
     float s_ssim = 0.f, s_cs = 0.f;
-    for (int q = threadIdx.x; q < G::PPB * G::RS * S; q += 256) {
-        const int pl = q / (G::RS * S), rem = q % (G::RS * S), r = rem / S, c = rem % S;
-        if (plane0 + pl >= a.P) continue;
-        const float* t0 = tmp + (pl * G::HR + r) * S + c;
-        float mu1 = 0.f, mu2 = 0.f, a11 = 0.f, a22 = 0.f, a12 = 0.f;
-#pragma unroll
-        for (int t = 0; t < 11; ++t) {
-            mu1 = fmaf(w[t], t0[t * S], mu1); mu2 = fmaf(w[t], t0[PER_T + t * S], mu2);
-            a11 = fmaf(w[t], t0[2 * PER_T + t * S], a11); a22 = fmaf(w[t], t0[3 * PER_T + t * S], a22);
-            a12 = fmaf(w[t], t0[4 * PER_T + t * S], a12);
-        }
+    auto pixel = [&](int pl, int r, int c, float mu1, float mu2, float a11, float a22, float a12) {
         const float mu1sq = mu1 * mu1, mu2sq = mu2 * mu2, mu12 = mu1 * mu2;
         const float v1 = 2.0f * (a12 - mu12) + C2;
         const float v2 = (a11 - mu1sq) + (a22 - mu2sq) + C2;
@@ -132,6 +155,44 @@ __global__ __launch_bounds__(256) void msssim_fwd_kernel(MsFwdArgs a) {
             const size_t o = ((size_t)(plane0 + pl) * S + r0 + r) * S + c;
             a.um[o] = dm; a.u11[o] = d11; a.u12[o] = d12;
         }
+    };
+    if constexpr (S >= 32) {       // 4 vertically adjacent outputs per work item from a 14-deep register window
+        if (plane0 < a.P) {
+            for (int it = threadIdx.x; it < (G::RS / 4) * S; it += 256) {
+                const int c = it % S, rb = (it / S) * 4;
+                float res[5][4];
+#pragma unroll
+                for (int mI = 0; mI < 5; ++mI) {
+                    const float* t0 = tmp + mI * PER_T + rb * S + c;
+                    float v[14];
+#pragma unroll
+                    for (int i = 0; i < 14; ++i) v[i] = t0[i * S];
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 11; ++t) acc = fmaf(w[t], v[o + t], acc);
+                        res[mI][o] = acc;
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) pixel(0, rb + o, c, res[0][o], res[1][o], res[2][o], res[3][o], res[4][o]);
+            }
+        }
+    } else {
+    for (int q = threadIdx.x; q < G::PPB * G::RS * S; q += 256) {
+        const int pl = q / (G::RS * S), rem = q % (G::RS * S), r = rem / S, c = rem % S;
+        if (plane0 + pl >= a.P) continue;
+        const float* t0 = tmp + (pl * G::HR + r) * S + c;
+        float mu1 = 0.f, mu2 = 0.f, a11 = 0.f, a22 = 0.f, a12 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 11; ++t) {
+            mu1 = fmaf(w[t], t0[t * S], mu1); mu2 = fmaf(w[t], t0[PER_T + t * S], mu2);
+            a11 = fmaf(w[t], t0[2 * PER_T + t * S], a11); a22 = fmaf(w[t], t0[3 * PER_T + t * S], a22);
+            a12 = fmaf(w[t], t0[4 * PER_T + t * S], a12);
+        }
+        pixel(pl, r, c, mu1, mu2, a11, a22, a12);
+    }
     }
     s_ssim = wave_sum(s_ssim); s_cs = wave_sum(s_cs);
     if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = s_ssim; red[(threadIdx.x >> 6) * 2 + 1] = s_cs; }
@@ -238,6 +299,31 @@ __global__ __launch_bounds__(256) void msssim_bwd_kernel(MsBwdArgs a) {
     float w[11];
 #pragma unroll
     for (int t = 0; t < 11; ++t) w[t] = c_win[t];
+    if constexpr (S >= 32) {
+        constexpr int CG = S / 4;
+        for (int it = threadIdx.x; it < G::HR * CG; it += 256) {
+            const int r = it / CG, c = (it % CG) * 4;
+#pragma unroll
+            for (int mI = 0; mI < 3; ++mI) {
+                const float* p0 = lin + mI * PER_IN + r * G::HC + c;
+                float xs[14];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    const float2 u = *reinterpret_cast<const float2*>(p0 + 2 * i);
+                    xs[2 * i] = u.x; xs[2 * i + 1] = u.y;
+                }
+                f32x4 o4v;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float h = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 11; ++t) h = fmaf(w[t], xs[o + t], h);
+                    o4v[o] = h;
+                }
+                *reinterpret_cast<f32x4*>(tmp + mI * PER_T + r * S + c) = o4v;
+            }
+        }
+    } else {
     for (int q = threadIdx.x; q < PER_T; q += 256) {
         const int pl = q / (G::HR * S), rem = q % (G::HR * S), r = rem / S, c = rem % S;
         const float* p0 = lin + (pl * G::HR + r) * G::HC + c;
@@ -248,8 +334,39 @@ __global__ __launch_bounds__(256) void msssim_bwd_kernel(MsBwdArgs a) {
         }
         tmp[q] = h0; tmp[PER_T + q] = h1; tmp[2 * PER_T + q] = h2;
     }
+    }
     __syncthreads();
     const float coef = a.coef[0];
+    auto emit = [&](int pl, int r, int c, float f0, float f1, float f2) {
+        const size_t o = ((size_t)(plane0 + pl) * S + r0 + r) * S + c;
+        float g = coef * (f0 + 2.0f * a.x[o] * f1 + a.y[o] * f2);
+        if (a.gup) g += 0.25f * a.gup[((size_t)(plane0 + pl) * (S / 2) + (r0 + r) / 2) * (S / 2) + c / 2];
+        a.dx[o] = g;
+    };
+    if constexpr (S >= 32) {
+        if (plane0 < a.P) {
+            for (int it = threadIdx.x; it < (G::RS / 4) * S; it += 256) {
+                const int c = it % S, rb = (it / S) * 4;
+                float res[3][4];
+#pragma unroll
+                for (int mI = 0; mI < 3; ++mI) {
+                    const float* t0 = tmp + mI * PER_T + rb * S + c;
+                    float v[14];
+#pragma unroll
+                    for (int i = 0; i < 14; ++i) v[i] = t0[i * S];
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 11; ++t) acc = fmaf(w[t], v[o + t], acc);
+                        res[mI][o] = acc;
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) emit(0, rb + o, c, res[0][o], res[1][o], res[2][o]);
+            }
+        }
+    } else {
     for (int q = threadIdx.x; q < G::PPB * G::RS * S; q += 256) {
         const int pl = q / (G::RS * S), rem = q % (G::RS * S), r = rem / S, c = rem % S;
         if (plane0 + pl >= a.P) continue;
@@ -259,10 +376,8 @@ __global__ __launch_bounds__(256) void msssim_bwd_kernel(MsBwdArgs a) {
         for (int t = 0; t < 11; ++t) {
             f0 = fmaf(w[t], t0[t * S], f0); f1 = fmaf(w[t], t0[PER_T + t * S], f1); f2 = fmaf(w[t], t0[2 * PER_T + t * S], f2);
         }
-        const size_t o = ((size_t)(plane0 + pl) * S + r0 + r) * S + c;
-        float g = coef * (f0 + 2.0f * a.x[o] * f1 + a.y[o] * f2);
-        if (a.gup) g += 0.25f * a.gup[((size_t)(plane0 + pl) * (S / 2) + (r0 + r) / 2) * (S / 2) + c / 2];
-        a.dx[o] = g;
+        emit(pl, r, c, f0, f1, f2);
+    }
     }
 }
 

@@ -205,6 +205,9 @@ int64_t cvae_ws_offset(cvae_handle h, int32_t batch, const char* name) {
 
 static const int kBnOff[4] = {0, 32, 96, 224};
 int cvae_decode(cvae_handle h, int32_t B, const float* zcat, const float* params, float* recon, void* wsv, void* stream);
+int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* pred, const float* eps, const float* params,
+                         const float* logvar, const float* recon, const float* d_recon, const float* d_mu,
+                         const float* d_logvar, void* wsv, float* grads, int32_t phase_mask, void* stream);
 
 #define P_(idx) (params + h->params[(idx)].offset)
 #define G_(idx) (grads + h->params[(idx)].offset)
@@ -297,8 +300,27 @@ int cvae_loss(cvae_handle h, int32_t B, const float* x, const float* mu, const f
 int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, const float* eps, const float* params,
                   const float* logvar, const float* recon, const float* d_recon, const float* d_mu,
                   const float* d_logvar, void* wsv, float* grads, void* stream) {
+    return cvae_backward_phases(h, B, x, pred, eps, params, logvar, recon, d_recon, d_mu, d_logvar, wsv, grads, 7, stream);
+}
+
+// Gradient buckets in the order backward completes them (for bucketed all-reduce overlapped with the
+// rest of backward): phase 0 = decoder + decoder_input, 1 = fc_mu|fc_var + encoder block 3,
+// 2 = encoder blocks 2..0.  Each bucket is one contiguous range of the flat gradient buffer.
+int cvae_grad_bucket(cvae_handle h, int32_t phase, int64_t* offset, int64_t* numel) {
+    if (!h || !offset || !numel || phase < 0 || phase > 2) { cvae_set_error("cvae_grad_bucket: bad argument"); return CVAE_EINVAL; }
+    const int64_t enc3 = h->params[h->enc_w[3]].offset, dec0 = h->params[h->dec_w[0]].offset;
+    if (phase == 0) { *offset = dec0; *numel = h->param_total - dec0; }
+    else if (phase == 1) { *offset = enc3; *numel = dec0 - enc3; }
+    else { *offset = 0; *numel = enc3; }
+    return 0;
+}
+
+int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* pred, const float* eps, const float* params,
+                         const float* logvar, const float* recon, const float* d_recon, const float* d_mu,
+                         const float* d_logvar, void* wsv, float* grads, int32_t phase_mask, void* stream) {
     (void)pred;
     RC(check(h, B, wsv));
+    if ((phase_mask & ~7) != 0 || phase_mask == 0) { cvae_set_error("cvae_backward_phases: phase_mask %d (bits 0..2)", phase_mask); return CVAE_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)wsv;
     const WsLayout w = carve(h, B);
@@ -313,20 +335,26 @@ int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, c
 #define HIPRC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cvae_set_error("%s: %s", #call, hipGetErrorString(e_)); return (int)e_; } } while (0)
     // `ready k` = the gradient a weight-gradient kernel needs exists on the main stream; the side
     // stream picks it up from there, so dW/db never delay the dgrad chain.
-    int k = 0;
     auto fork = [&](int idx) -> int {
         if (!overlap) return 0;
         HIPRC(hipEventRecord(h->ev_ready[idx], st));
         HIPRC(hipStreamWaitEvent(sd, h->ev_ready[idx], 0));
         return 0;
     };
+    auto join = [&]() -> int {                          // side-stream work of this phase is complete on the caller's stream
+        if (!overlap) return 0;
+        HIPRC(hipEventRecord(h->ev_side, sd));
+        HIPRC(hipStreamWaitEvent(st, h->ev_side, 0));
+        return 0;
+    };
+    if (phase_mask & 1) {
     // decoder, last layer first
     RC(launch_d4_bwd(W, B, ws + w.o[3], d_recon, recon, P_(h->dec_w[4]), ws + w.dout4, ws + w.d_o[3],
                      G_(h->dec_w[4]), G_(h->dec_b[4]), sc, st));
     for (int i = 3; i >= 0; --i) {
         const int l = 4 + i;
         const float* in = i == 0 ? ws + w.h : ws + w.o[i - 1];
-        RC(fork(k++));
+        RC(fork(3 - i));
         if (i == 0) {
             { ProbeArm pa(h, 2, l);
               if (use_bf16(h, 4)) RC(launch_conv_wgrad_bf16(4, B, in, ws + w.d_o[0], G_(h->dec_w[0]), G_(h->dec_b[0]), scw, sd));
@@ -343,14 +371,18 @@ int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, c
     }
     // latent
     RC(launch_decin_bwd(W, B, ws + w.zcat, ws + w.d_h, P_(h->di_w), G_(h->di_w), G_(h->di_b), ws + w.d_zcat, sc, st));
-    RC(launch_fc_bwd(W, B, ws + w.a[3], P_(h->fc_w), ws + w.d_zcat, eps, logvar, d_mu, d_logvar, G_(h->fc_w),
-                     G_(h->fc_b), ws + w.d_a[3], sc, st));
+    RC(join());
+    }
+    if (phase_mask & 2)
+        RC(launch_fc_bwd(W, B, ws + w.a[3], P_(h->fc_w), ws + w.d_zcat, eps, logvar, d_mu, d_logvar, G_(h->fc_w),
+                         G_(h->fc_b), ws + w.d_a[3], sc, st));
     // encoder
     for (int l = 3; l >= 0; --l) {
+        if (!(phase_mask & (l == 3 ? 2 : 4))) continue;
         { ProbeArm pa(h, 3, l);
           RC(launch_bn_pool_act_bwd(l, W, B, ws + w.y[l], ws + w.a[l], ws + w.d_a[l], ws + w.coef[l], P_(h->enc_g[l]),
                                     ws + w.d_y[l], G_(h->enc_g[l]), G_(h->enc_be[l]), nullptr, sc, st)); }
-        RC(fork(k++));
+        RC(fork(7 - l));
         if (l == 0) {
             RC(launch_e1_wgrad(W, B, x, ws + w.d_y[0], G_(h->enc_w[0]), G_(h->enc_b[0]), scw, sd));
         } else {
@@ -361,10 +393,7 @@ int cvae_backward(cvae_handle h, int32_t B, const float* x, const float* pred, c
               if (use_bf16(h, l)) RC(launch_conv_dgrad_bf16(l, B, ws + w.d_y[l], ws + w.wpack, ws + w.d_a[l - 1], ws + w.scratch, st));
               else RC(launch_conv_dgrad(l, W, B, ws + w.d_y[l], P_(h->enc_w[l]), nullptr, ws + w.d_a[l - 1], nullptr, st)); }
         }
-    }
-    if (overlap) {                                      // join: grads are complete on the caller's stream
-        HIPRC(hipEventRecord(h->ev_side, sd));
-        HIPRC(hipStreamWaitEvent(st, h->ev_side, 0));
+        if (l == 3 || l == 0) RC(join());               // end of phase 1 / phase 2
     }
 #undef HIPRC
     return 0;

@@ -130,11 +130,15 @@ __device__ __forceinline__ void thin_slab_out(f32x16 (&acc)[3], float* red, floa
 #pragma unroll
                 for (int w2 = 0; w2 < 3; ++w2) x += red[((w2 * 3 + mb) * 16 + v) * 64 + lane];
                 const int k = mb * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-                if (!(with_bias && k == 75)) slab_blk[k * 32 + li] = x;
+                // E1: row 75 is the K pad (its accumulator saw real pixels through offset 0 -> write the
+                // zero it stands for), row 76 is reserved for the bias-gradient partial below
+                if (!with_bias) slab_blk[k * 32 + li] = x;
+                else if (k < 75) slab_blk[k * 32 + li] = x;
+                else if (k == 75) slab_blk[k * 32 + li] = 0.f;
             }
-        if (with_bias) {                       // row 75 of the slab carries the bias-gradient partial
+        if (with_bias) {                       // row 76 of the slab carries the bias-gradient partial
             bsum += __shfl_xor(bsum, 32, 64);
-            if (lh == 0) slab_blk[75 * 32 + li] = bsum;
+            if (lh == 0) slab_blk[76 * 32 + li] = bsum;
         }
     }
 }
@@ -265,11 +269,13 @@ int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw
     if (width == 64) hipLaunchKernelGGL(e1_wgrad_kernel<64>, dim3(S), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(e1_wgrad_kernel<128>, dim3(S), dim3(256), 0, st, a);
     CVAE_CHECK_LAUNCH();
-    if (dbias == dw + 2432)                   // flat buffer: enc0.b sits right after the 64-float-padded enc0.w
-        return launch_col_reduce(ws, S, 2432, 3072, dw, ws + (size_t)S * 3072, st);
+    // slab row = [75 x 32 weights | 32 zeros (K pad) | 32 bias partials]: in the flat buffer enc0.b sits at
+    // enc0.w + 2432 (2400 weights padded to 64 floats), so ONE column reduction fills both
+    if (dbias == dw + 2432)
+        return launch_col_reduce(ws, S, 2464, 3072, dw, ws + (size_t)S * 3072, st);
     int rc = launch_col_reduce(ws, S, 2400, 3072, dw, ws + (size_t)S * 3072, st);
     if (rc || !dbias) return rc;
-    return launch_col_reduce(ws + 2400, S, 32, 3072, dbias, ws + (size_t)S * 3072, st);
+    return launch_col_reduce(ws + 2432, S, 32, 3072, dbias, ws + (size_t)S * 3072, st);
 }
 
 // ------------------------------------------ D4 ------------------------------------------------

@@ -52,6 +52,8 @@ _SIGS = {
     "cvae_decode": (C.c_int, [_p, _i32] + [_p] * 5),
     "cvae_loss": (C.c_int, [_p, _i32] + [_p] * 10),
     "cvae_backward": (C.c_int, [_p, _i32] + [_p] * 12),
+    "cvae_backward_phases": (C.c_int, [_p, _i32] + [_p] * 11 + [_i32, _p]),
+    "cvae_grad_bucket": (C.c_int, [_p, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "cvae_adam_step": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _f, _f, _f, _f, _f, _p]),
     "cvae_critic_param_count": (_i32, []),
     "cvae_critic_forward": (C.c_int, [_p, _i32, _p, _p, _p, _p]),
@@ -166,6 +168,18 @@ class Handle:
         self._check(self.lib.cvae_backward(self.h, B, _ptr(x), _ptr(pred), _ptr(eps), _ptr(params), _ptr(logvar),
                                            _ptr(recon), _ptr(d_recon), _ptr(d_mu), _ptr(d_logvar), _ptr(ws),
                                            _ptr(grads), _stream()))
+
+    def backward_phase(self, phase, B, x, pred, eps, params, logvar, recon, d_recon, d_mu, d_logvar, ws, grads):
+        """Phase 0..2 of the backward (decoder | fc + encoder block 3 | encoder blocks 2..0), in order."""
+        self._check(self.lib.cvae_backward_phases(self.h, B, _ptr(x), _ptr(pred), _ptr(eps), _ptr(params), _ptr(logvar),
+                                                  _ptr(recon), _ptr(d_recon), _ptr(d_mu), _ptr(d_logvar), _ptr(ws),
+                                                  _ptr(grads), 1 << phase, _stream()))
+
+    def grad_bucket(self, phase):
+        """(offset, numel) of the flat-gradient range that backward phase `phase` completes."""
+        off, n = C.c_int64(), C.c_int64()
+        self._check(self.lib.cvae_grad_bucket(self.h, phase, C.byref(off), C.byref(n)))
+        return off.value, n.value
 
     def adam_step(self, params, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0):
         self._check(self.lib.cvae_adam_step(self.h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(),

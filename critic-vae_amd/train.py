@@ -11,6 +11,7 @@ Two drivers over the same C-ABI kernels:
     python -m critic_vae_amd.train -train --synthetic 1024 --batch 32 --epochs 1
 """
 import argparse
+import os
 import time
 
 import numpy as np
@@ -52,9 +53,16 @@ def train(autoencoder, dset, critic_fn, device, epochs=P.epochs, batch_size=P.ba
 class FusedTrainer:
     """One training step = forward + loss + backward + all-reduce + Adam on flat buffers."""
 
-    def __init__(self, vae, lr=P.lr, betas=P.adam_betas, eps=P.adam_eps, process_group=None, world_size=1):
+    def __init__(self, vae, lr=P.lr, betas=P.adam_betas, eps=P.adam_eps, process_group=None, world_size=1,
+                 overlap=None):
+        """overlap: all-reduce the gradient in three buckets while backward still runs (default for
+        world_size > 1; CVAE_DP_OVERLAP=0 or overlap=False = one all-reduce after backward)."""
         self.vae = vae
         self.h = vae.handle
+        if overlap is None:
+            overlap = os.environ.get("CVAE_DP_OVERLAP", "1") != "0"
+        self.overlap = bool(overlap) and world_size > 1
+        self.buckets = [self.h.grad_bucket(ph) for ph in range(3)]
         self.lr, self.betas, self.eps = lr, betas, eps
         self.world_size, self.pg = world_size, process_group
         dev = vae.theta.device
@@ -79,10 +87,22 @@ class FusedTrainer:
         theta = v.theta.data
         h.forward(B, x, pred, eps, theta, v.bn_state, self.mu, self.logvar, self.recon, self.ws, train=True)
         h.loss(B, x, self.mu, self.logvar, self.recon, self.ws, self.scalars, self.d_recon, self.d_mu, self.d_logvar)
-        h.backward(B, x, pred, eps, theta, self.logvar, self.recon, self.d_recon, self.d_mu, self.d_logvar,
-                   self.ws, self.grads)
-        if self.world_size > 1:
-            torch.distributed.all_reduce(self.grads, group=self.pg)          # one flat RCCL all-reduce (sum)
+        if self.world_size > 1 and self.overlap:
+            # bucketed all-reduce overlapped with backward (torch DDP's scheme on the flat buffer): the
+            # three buckets are contiguous ranges, each reduced (sum, RCCL) while the next phase computes
+            works = []
+            for ph in range(3):
+                h.backward_phase(ph, B, x, pred, eps, theta, self.logvar, self.recon, self.d_recon, self.d_mu,
+                                 self.d_logvar, self.ws, self.grads)
+                off, n = self.buckets[ph]
+                works.append(torch.distributed.all_reduce(self.grads[off:off + n], group=self.pg, async_op=True))
+            for wk in works:
+                wk.wait()                     # nccl: the compute stream waits for the collective's stream
+        else:
+            h.backward(B, x, pred, eps, theta, self.logvar, self.recon, self.d_recon, self.d_mu, self.d_logvar,
+                       self.ws, self.grads)
+            if self.world_size > 1:
+                torch.distributed.all_reduce(self.grads, group=self.pg)      # one flat RCCL all-reduce (sum)
         self.step_count += 1
         v.num_batches_tracked += 1
         h.adam_step(theta, self.grads, self.m, self.v, self.step_count, self.lr, self.betas[0], self.betas[1],

@@ -102,6 +102,20 @@ int cvae_backward(cvae_handle h, int32_t batch, const float* x, const float* pre
                   const float* d_mu, const float* d_logvar, void* ws, float* grads, void* stream);
 
 /*
+ * The same backward in three phases, in the order the gradients complete, so that a data-parallel
+ * host can all-reduce one bucket of the flat gradient buffer while the next phase computes
+ * (torch DDP's bucketed overlap; vae.py:57 under the north star's RCCL all-reduce):
+ *   bit 0: decoder + decoder_input      bit 1: fc_mu|fc_var + encoder block 3      bit 2: encoder blocks 2..0
+ * Phases must be issued in that order on one stream; phase_mask 7 == cvae_backward.  cvae_grad_bucket
+ * returns the contiguous [offset, offset+numel) range of `grads` that phase `phase` (0..2) completes.
+ */
+int cvae_backward_phases(cvae_handle h, int32_t batch, const float* x, const float* pred, const float* eps,
+                         const float* params, const float* logvar, const float* recon, const float* d_recon,
+                         const float* d_mu, const float* d_logvar, void* ws, float* grads, int32_t phase_mask,
+                         void* stream);
+int cvae_grad_bucket(cvae_handle h, int32_t phase, int64_t* offset, int64_t* numel);
+
+/*
  * Optimizer: torch.optim.Adam.step() with defaults (vae.py:36,58) on the flat buffers.
  * grad_scale multiplies the gradient first (1/world_size after a summing all-reduce).
  */

@@ -1,0 +1,58 @@
+"""2-rank worker for tests/test_gpu_dp.py: the data-parallel FusedTrainer step on the GPU (both ranks
+on device 0, gloo carrying the collectives — RCCL refuses two ranks on one device), with the bucketed
+all-reduce overlapped with backward and with the single all-reduce, against the contract of SURVEY.md
+§8e: reduced gradient == mean of the per-shard single-rank gradients, then one identical Adam step."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from critic_vae_amd import dp, synth                      # noqa: E402
+from critic_vae_amd.nets import VariationalAutoencoder    # noqa: E402
+from critic_vae_amd.train import FusedTrainer             # noqa: E402
+
+world, rank, local = dp.init()
+assert world == 2
+dev = torch.device("cuda", dp.device_index(local))
+torch.cuda.set_device(dev)
+GLOBAL_B = 16
+first, per = dp.shard_rows(GLOBAL_B, world, rank)
+
+
+def batch(r):
+    f, n = dp.shard_rows(GLOBAL_B, world, r)
+    return tuple(torch.from_numpy(a).to(dev) for a in synth.make_batch(1234, 0, n, first_index=f))
+
+
+def single_rank_grad(r):
+    vae = VariationalAutoencoder(max_batch=per, seed=0).to(dev)
+    tr = FusedTrainer(vae)                                   # world 1: grads of this shard only
+    tr.step(*batch(r))
+    return tr.grads.clone()
+
+
+want_grad = (single_rank_grad(0) + single_rank_grad(1))      # FusedTrainer keeps the SUM; 1/N is folded into Adam
+results = {}
+for overlap in (True, False):
+    vae = VariationalAutoencoder(max_batch=per, seed=0).to(dev)
+    tr = FusedTrainer(vae, world_size=world, overlap=overlap)
+    assert tr.overlap == overlap
+    tr.step(*batch(rank))
+    torch.cuda.synchronize()
+    err = (tr.grads - want_grad).abs().max().item()
+    assert err <= 2e-6 * max(want_grad.abs().max().item(), 1.0), (overlap, err)
+    results[overlap] = vae.theta.data.clone()
+    # every rank holds the same parameters after the step
+    other = results[overlap].clone()
+    dist.broadcast(other, src=0)
+    assert torch.equal(other, results[overlap]), "ranks diverged"
+assert torch.equal(results[True], results[False]), "bucketed and single all-reduce differ"
+# buckets tile the flat buffer exactly
+b = sorted(tr.buckets)
+assert b[0][0] == 0 and all(b[i][0] + b[i][1] == b[i + 1][0] for i in range(2)) and b[2][0] + b[2][1] == tr.grads.numel()
+print(f"DP_GPU_OK rank {rank} err {err:.2e}", flush=True)
+dist.destroy_process_group()

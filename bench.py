@@ -181,6 +181,7 @@ def main():
                                + " train step (fwd+MS-SSIM/KLD loss+bwd+Adam), "
                                f"batch {B}/GPU, 64x64x3 frames + critic scalars", "global_batch": world * B,
                    "frame": "64x64x3", "parallelism": f"dp{world}", "optimizer": "fused flat Adam",
+                   "grad_allreduce": ("3 buckets overlapped with backward" if tr.overlap else "single, after backward") if world > 1 else "none",
                    "final_loss": loss, "loss_finite": bool(loss == loss and abs(loss) != float("inf"))},
     }
     if rank == 0 and world == 1:

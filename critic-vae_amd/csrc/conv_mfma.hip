@@ -30,13 +30,15 @@ struct ConvArgs {
     int64_t sliceFloats;   // KSPLIT > 1: out is a slab [KSPLIT][sliceFloats] of raw partial sums
 };
 
-static constexpr int KC = 16;        // channels per K chunk
-static constexpr int KCP = KC + 1;   // padded row for the transposed (dgrad) weight slab
+// channels per K chunk: the NT=32 kernels run half as many MFMAs per stage, so they take 32-channel
+// chunks to keep ~80 MFMAs per wave between barrier pairs; KCP = padded row of the transposed (dgrad) slab
+template <int NT> struct KChunk { static constexpr int KC = NT == 32 ? 32 : 16, KCP = KC + 1; };
 
 template <int KCH, int NCH, int H, bool UP, bool DGRAD, int NT, int EPI, int KSPLIT>
 __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
     using T = Tile<H>;
     constexpr int NB = NT / 32;
+    constexpr int KC = KChunk<NT>::KC, KCP = KChunk<NT>::KCP, QPP = KC / 4;     // QPP: float4 per pixel per chunk
     constexpr int IN_FLOATS = KC * T::PS;
     constexpr int W_FLOATS = DGRAD ? 5 * NT * KCP : 5 * KC * NT;
     constexpr int EPI_FLOATS = (EPI == EPI_POOLSUM_MASK) ? 128 * (NT + 1) : 4 * 32 * 36;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
                     const int s = row / KC, kc = row % KC;
                     src = a.w + (size_t)((r * 5 + s) * KCH + cc * KC + kc) * NCH + n0 + c4 * 4;
                 } else {
-                    const int c4 = q & 3, rown = q >> 2;
+                    const int c4 = q % QPP, rown = q / QPP;
                     const int n = rown % NT, s = rown / NT;
                     src = a.w + (size_t)((24 - (r * 5 + s)) * NCH + n0 + n) * KCH + cc * KC + c4 * 4;
                 }
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
                 if (!DGRAD) {
                     *reinterpret_cast<f32x4*>(lds_w + q * 4) = wreg[i];
                 } else {
-                    const int c4 = q & 3, rown = q >> 2;
+                    const int c4 = q % QPP, rown = q / QPP;
                     float* d = lds_w + rown * KCP + c4 * 4;   // rown = s*NT + n
                     d[0] = wreg[i].x; d[1] = wreg[i].y; d[2] = wreg[i].z; d[3] = wreg[i].w;
                 }
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < IPT; ++i) {
             const int q = tid + i * 256;
-            const int c4 = q & 3, hp = q >> 2;
+            const int c4 = q % QPP, hp = q / QPP;
             const int img = hp / T::HPI, rem = hp - img * T::HPI;
             const int hy = rem / T::HTW, hx = rem - hy * T::HTW;
             const int gy = ty0 + hy - 2, gx = tx0 + hx - 2, ib = img0 + img;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
         for (int i = 0; i < IPT; ++i) {
             const int q = tid + i * 256;
             if (NQ % 256 == 0 || q < NQ) {
-                float* d = lds_in + ((q & 3) * 4) * T::PS + (q >> 2);
+                float* d = lds_in + ((q % QPP) * 4) * T::PS + (q / QPP);
                 d[0] = ireg[i].x; d[T::PS] = ireg[i].y; d[2 * T::PS] = ireg[i].z; d[3 * T::PS] = ireg[i].w;
             }
         }
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
 template <int KCH, int NCH, int H, bool UP, bool DGRAD, int NT, int EPI, int KSPLIT = 1>
 static int run(const ConvArgs& a, hipStream_t st) {
     using T = Tile<H>;
-    static_assert(KCH % KC == 0 && NCH % NT == 0, "channel tiling");
+    static_assert(KCH % KChunk<NT>::KC == 0 && NCH % NT == 0, "channel tiling");
     dim3 grid(cdiv(a.B, T::IMGS) * T::TILES_PER_IMG, NCH / NT, KSPLIT);
     cvae_probe_begin(st);
     hipLaunchKernelGGL((conv5x5_mfma_kernel<KCH, NCH, H, UP, DGRAD, NT, EPI, KSPLIT>), grid, dim3(256), 0, st, a);

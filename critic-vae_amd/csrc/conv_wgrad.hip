@@ -37,7 +37,8 @@ __device__ __forceinline__ void wgrad_body(f32x16 (&acc)[7], float& bsum, const 
         const float* inrow = lds_in + ((img * T::HTH + ty) * T::HTW + lh) * CS + li;
         const float* drow = lds_d + (rho * T::TW + lh) * 32 + li;
         const bool extra = (rho & 3) == W && gy + 2 < H;
-#pragma unroll
+        constexpr int KKU = T::TW / 2 < 8 ? T::TW / 2 : 8;      // full unroll of 16 k-steps (H >= 32) spills registers
+#pragma unroll KKU
         for (int kk = 0; kk < T::TW / 2; ++kk) {
             const float bv = drow[(2 * kk) * 32];
             const int gx = tx0 + 2 * kk;                     // this k-step covers pixels gx, gx+1

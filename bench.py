@@ -26,7 +26,7 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-FLOP_PER_IMG = 1.43762e9          # fwd + dgrad + wgrad of 9 convs + 3 linears @64x64
+FLOP_PER_IMG = {64: 1.43762e9, 128: 5.75049e9}   # fwd + dgrad + wgrad of 9 convs + 3 linears
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, matrix fp32
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md, dense bf16
 LAYERS = [(3, 32, 64, 0), (32, 64, 32, 0), (64, 128, 16, 0), (128, 256, 8, 0),
@@ -39,9 +39,10 @@ PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (abou
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
 
 
-def conv_flops(layer, B):
+def conv_flops(layer, B, width=64):
     """Algorithmic FLOPs of one pass (forward, dgrad or wgrad) of conv `layer` on B images."""
     cin, cout, h, _ = LAYERS[layer]
+    h = h * width // 64
     return 2.0 * 25 * cin * cout * h * h * B
 
 
@@ -51,10 +52,11 @@ def probe_name(pid):
     return f"{KINDS[pid // 9]}_L{pid % 9}"
 
 
-def bn_apply_bytes(layer, B):
+def bn_apply_bytes(layer, B, width=64):
     """Algorithmic HBM bytes of one BatchNorm+pool backward apply launch: read y and the pooled a, da;
     write dy (fp32): (2 + 2/4) * B*H*H*C * 4."""
     c, h = BN_CH_H[layer]
+    h = h * width // 64
     return 2.5 * B * h * h * c * 4.0
 
 
@@ -68,17 +70,17 @@ def measured_traffic(name):
         return None
 
 
-def cpu_baseline(B, steps=5):
+def cpu_baseline(B, steps=5, width=64):
     """The oracle's training step (same ATen CPU kernels as the reference, equality pinned by
     tests/golden) timed on this host: bounded sample of the same workload."""
     from critic_vae_amd import synth
     from oracle import cvae_oracle as orc
     threads = min(len(os.sched_getaffinity(0)), 16)     # the 1-GPU box's CPU share is 16 cores
     torch.set_num_threads(threads)
-    p = orc.to_torch(synth.make_params(0), requires_grad=True)
+    p = orc.to_torch(synth.make_params(0, width), requires_grad=True)
     bn = orc.new_bn_state(p)
     st = {}
-    xs = torch.rand(B, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+    xs = torch.rand(B, 3, width, width, generator=torch.Generator().manual_seed(1))
     pr = torch.rand(B, 1, generator=torch.Generator().manual_seed(2))
     ep = torch.randn(B, 32, generator=torch.Generator().manual_seed(3))
 
@@ -103,6 +105,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE.json configs[1])")
+    ap.add_argument("--width", type=int, choices=[64, 128], default=64, help="frame size (128: BASELINE configs[4] shape)")
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
                     help="f32 = the 1e-4-parity path (default, BASELINE configs[1]); bf16 = bf16-MFMA forward/dgrad "
                          "convs (configs[2]: use with --batch 2048)")
@@ -128,12 +131,13 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    vae = VariationalAutoencoder(max_batch=B, seed=0, precision=args.precision).to(dev)
+    Wd = args.width
+    vae = VariationalAutoencoder(width=Wd, max_batch=B, seed=0, precision=args.precision).to(dev)
     tr = FusedTrainer(vae, world_size=world)
     H = vae.handle
     # synthetic inputs, resident in HBM before the timed region; each rank its own shard
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    pool = [(torch.rand(B, 3, 64, 64, device=dev, generator=gen), torch.rand(B, 1, device=dev, generator=gen),
+    pool = [(torch.rand(B, 3, Wd, Wd, device=dev, generator=gen), torch.rand(B, 1, device=dev, generator=gen),
              torch.randn(B, 32, device=dev, generator=gen)) for _ in range(4)]
 
     def barrier():
@@ -171,48 +175,49 @@ def main():
     note(f"timed {args.steps} steps in {dt:.3f}s, loss {loss}")
 
     res = {
-        "metric": "VAE train-step images/sec on 64x64x3 frames",
+        "metric": f"VAE train-step images/sec on {Wd}x{Wd}x3 frames",
         "value": round(world * B * args.steps / dt, 1), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16 MFMA operands (E2-E4, D0 fwd+dgrad), f32 elsewhere",
+        "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16 MFMA operands (fwd+dgrad+wgrad of E2-E4, D0-D3), f32 elsewhere",
         "data": "synthetic",
-        "config": {"workload": ("BASELINE.json configs[1]: fp32" if args.precision == "f32" else "BASELINE.json configs[2]: bf16-MFMA")
+        "config": {"workload": (("BASELINE.json configs[1]: fp32" if args.precision == "f32" else "BASELINE.json configs[2]: bf16-MFMA")
+                                if Wd == 64 else f"BASELINE.json configs[4] frame size (128x128), {args.precision}")
                                + " train step (fwd+MS-SSIM/KLD loss+bwd+Adam), "
-                               f"batch {B}/GPU, 64x64x3 frames + critic scalars", "global_batch": world * B,
-                   "frame": "64x64x3", "parallelism": f"dp{world}", "optimizer": "fused flat Adam",
+                               f"batch {B}/GPU, {Wd}x{Wd}x3 frames + critic scalars", "global_batch": world * B,
+                   "frame": f"{Wd}x{Wd}x3", "parallelism": f"dp{world}", "optimizer": "fused flat Adam",
                    "grad_allreduce": ("3 buckets overlapped with backward" if tr.overlap else "single, after backward") if world > 1 else "none",
                    "final_loss": loss, "loss_finite": bool(loss == loss and abs(loss) != float("inf"))},
     }
     if rank == 0 and world == 1:
-        res["config"]["whole_step_algorithmic_TFLOPs"] = round(B * args.steps / dt * FLOP_PER_IMG / 1e12, 2)
+        res["config"]["whole_step_algorithmic_TFLOPs"] = round(B * args.steps / dt * FLOP_PER_IMG[Wd] / 1e12, 2)
         if dominant is not None:
             ms = H.probe_read(dominant)
             ms_hbm = H.probe_read(dominant_hbm)
             H.probe_config([])
             sec = sum(ms) / len(ms) * 1e-3
-            fl = conv_flops(dominant % 9, B)
-            on_bf16 = args.precision == "bf16" and dominant // 9 < 2 and 1 <= dominant % 9 <= 4
+            fl = conv_flops(dominant % 9, B, Wd)
+            on_bf16 = args.precision == "bf16" and 1 <= dominant % 9 <= 7
             peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
             res["roofline"] = {
                 "bound": "mfma", "kernel": probe_name(dominant), "achieved": round(fl / sec / 1e12, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak, 4),
-                "traffic": measured_traffic(probe_name(dominant)) if B == 256 and args.precision == "f32" else None,
+                "traffic": measured_traffic(probe_name(dominant)) if B == 256 and Wd == 64 and args.precision == "f32" else None,
                 "avg_launch_us": round(sec * 1e6, 2), "launches_timed": len(ms),
                 "algorithmic_flops_per_launch": fl,
-                "in_step_TFLOPs_all_conv_kernels": {probe_name(k): round(conv_flops(k % 9, B) / (v * 1e-3) / 1e12, 1)
+                "in_step_TFLOPs_all_conv_kernels": {probe_name(k): round(conv_flops(k % 9, B, Wd) / (v * 1e-3) / 1e12, 1)
                                                     for k, v in sorted(survey.items()) if k < 27}}
             if ms_hbm:          # second roofline: the largest HBM-bound kernel of the step
                 sh = sum(ms_hbm) / len(ms_hbm) * 1e-3
-                by = bn_apply_bytes(dominant_hbm - 27, B)
+                by = bn_apply_bytes(dominant_hbm - 27, B, Wd)
                 res["roofline_hbm"] = {
                     "bound": "hbm", "kernel": probe_name(dominant_hbm), "achieved": round(by / sh / 1e9, 1),
                     "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(by / sh / 1e9 / PEAK_HBM_GBPS, 4),
-                    "traffic": measured_traffic(probe_name(dominant_hbm)) if B == 256 else None,
+                    "traffic": measured_traffic(probe_name(dominant_hbm)) if B == 256 and Wd == 64 else None,
                     "avg_launch_us": round(sh * 1e6, 2), "launches_timed": len(ms_hbm),
                     "algorithmic_bytes_per_launch": by}
         if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(B)
+            res["cpu_baseline"] = cpu_baseline(B, width=Wd)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -109,7 +109,7 @@ static WsLayout carve(const cvae_handle_s* h, int B) {
     int64_t sc = 0, scw = 0;
     auto mx = [&](int64_t v) { if (v > sc) sc = v; };
     for (int l = 1; l <= 4; ++l) { if (wgrad_ws_floats(l, W, B) > scw) scw = wgrad_ws_floats(l, W, B);
-        if (h->cfg.reserved1 == 1 && conv_bf16_supported(l, W) && wgrad_bf16_ws_floats(l, B) > scw) scw = wgrad_bf16_ws_floats(l, B);
+        if (h->cfg.reserved1 == 1 && conv_bf16_supported(l, W) && wgrad_bf16_ws_floats(l, W, B) > scw) scw = wgrad_bf16_ws_floats(l, W, B);
         mx(conv_fwd_ws_floats(l, W, B)); mx(conv_dgrad_ws_floats(l, W, B)); }
     for (int l = 5; l <= 7; ++l) { if (conv_up_wgrad_ws_floats(l, W, B) > scw) scw = conv_up_wgrad_ws_floats(l, W, B); mx(conv_up_ws_floats(l, W, B)); }
     if (e1_wgrad_ws_floats(W, B) > scw) scw = e1_wgrad_ws_floats(W, B);
@@ -139,7 +139,6 @@ int cvae_create(const cvae_config* cfg, cvae_handle* out) {
     if (!cfg || !out) { cvae_set_error("cvae_create: null argument"); return CVAE_EINVAL; }
     if (cfg->width != 64 && cfg->width != 128) { cvae_set_error("cvae_create: width %d not supported (64 or 128)", cfg->width); return CVAE_EUNSUPPORTED; }
     if (cfg->reserved1 != 0 && cfg->reserved1 != 1) { cvae_set_error("cvae_create: precision %d not supported (0 = fp32, 1 = bf16 MFMA)", cfg->reserved1); return CVAE_EUNSUPPORTED; }
-    if (cfg->reserved1 == 1 && cfg->width != 64) { cvae_set_error("cvae_create: the bf16 MFMA kernels are instantiated for width 64 only"); return CVAE_EUNSUPPORTED; }
     cvae_handle_s* h = new cvae_handle_s();
     h->cfg = *cfg;
     h->param_total = 0;
@@ -239,7 +238,7 @@ int cvae_forward(cvae_handle h, int32_t B, const float* x, const float* pred, co
     RC(pack_bf16_weights(h, params, ws, w, st));
     for (int l = 0; l < 4; ++l) {
         if (l == 0) RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], ws + w.bnpart[0], st));
-        else if (use_bf16(h, l)) { ProbeArm pa(h, 0, l); RC(launch_conv_fwd_bf16(l, B, ws + w.a[l - 1], ws + w.wpack, P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st)); }
+        else if (use_bf16(h, l)) { ProbeArm pa(h, 0, l); RC(launch_conv_fwd_bf16(l, W, B, ws + w.a[l - 1], ws + w.wpack, P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st)); }
         else { ProbeArm pa(h, 0, l); RC(launch_conv_fwd(l, W, B, ws + w.a[l - 1], P_(h->enc_w[l]), P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st)); }
         RC(launch_bn_fwd_finalize(l, W, B, ws + w.bnpart[l], P_(h->enc_g[l]), P_(h->enc_be[l]), bn_state + kBnOff[l],
                                   bn_state + 480 + kBnOff[l], ws + w.coef[l], ws + w.scratch, train, st));
@@ -273,10 +272,10 @@ int cvae_decode(cvae_handle h, int32_t B, const float* zcat, const float* params
     for (int i = 0; i < 4; ++i) {
         ProbeArm pa(h, 0, 4 + i);
         if (i == 0) {
-            if (use_bf16(h, 4)) RC(launch_conv_fwd_bf16(4, B, ws + w.h, ws + w.wpack, P_(h->dec_b[0]), ws + w.o[0], nullptr, ws + w.scratch, st));
+            if (use_bf16(h, 4)) RC(launch_conv_fwd_bf16(4, W, B, ws + w.h, ws + w.wpack, P_(h->dec_b[0]), ws + w.o[0], nullptr, ws + w.scratch, st));
             else RC(launch_conv_fwd(4, W, B, ws + w.h, P_(h->dec_w[0]), P_(h->dec_b[0]), ws + w.o[0], nullptr, ws + w.scratch, st));
         } else if (use_bf16(h, 4 + i)) {
-            RC(launch_conv_up_fwd_bf16(4 + i, B, ws + w.o[i - 1], ws + w.wpack, P_(h->dec_b[i]), ws + w.o[i], st));
+            RC(launch_conv_up_fwd_bf16(4 + i, W, B, ws + w.o[i - 1], ws + w.wpack, P_(h->dec_b[i]), ws + w.o[i], st));
         } else {
             RC(launch_conv_up_fwd(4 + i, W, B, ws + w.o[i - 1], ws + w.wc[i - 1], P_(h->dec_b[i]), ws + w.o[i], ws + w.scratch, st));
         }
@@ -357,15 +356,15 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
         RC(fork(3 - i));
         if (i == 0) {
             { ProbeArm pa(h, 2, l);
-              if (use_bf16(h, 4)) RC(launch_conv_wgrad_bf16(4, B, in, ws + w.d_o[0], G_(h->dec_w[0]), G_(h->dec_b[0]), scw, sd));
+              if (use_bf16(h, 4)) RC(launch_conv_wgrad_bf16(4, W, B, in, ws + w.d_o[0], G_(h->dec_w[0]), G_(h->dec_b[0]), scw, sd));
               else RC(launch_conv_wgrad(l, W, B, in, ws + w.d_o[0], G_(h->dec_w[0]), G_(h->dec_b[0]), scw, sd)); }
             { ProbeArm pa(h, 1, l);
-              if (use_bf16(h, 4)) RC(launch_conv_dgrad_bf16(4, B, ws + w.d_o[0], ws + w.wpack, ws + w.d_h, ws + w.scratch, st));
+              if (use_bf16(h, 4)) RC(launch_conv_dgrad_bf16(4, W, B, ws + w.d_o[0], ws + w.wpack, ws + w.d_h, ws + w.scratch, st));
               else RC(launch_conv_dgrad(l, W, B, ws + w.d_o[0], P_(h->dec_w[0]), nullptr, ws + w.d_h, ws + w.scratch, st)); }
         } else {
             { ProbeArm pa(h, 2, l); RC(launch_conv_up_wgrad(l, W, B, in, ws + w.d_o[i], G_(h->dec_w[i]), G_(h->dec_b[i]), scw, sd, use_bf16(h, l))); }
             { ProbeArm pa(h, 1, l);
-              if (use_bf16(h, l)) RC(launch_conv_up_dgrad_bf16(l, B, ws + w.d_o[i], ws + w.wpack, ws + w.o[i - 1], ws + w.d_o[i - 1], st));
+              if (use_bf16(h, l)) RC(launch_conv_up_dgrad_bf16(l, W, B, ws + w.d_o[i], ws + w.wpack, ws + w.o[i - 1], ws + w.d_o[i - 1], st));
               else RC(launch_conv_up_dgrad(l, W, B, ws + w.d_o[i], ws + w.wc[i - 1], ws + w.o[i - 1], ws + w.d_o[i - 1], sc, st)); }
         }
     }
@@ -387,10 +386,10 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
             RC(launch_e1_wgrad(W, B, x, ws + w.d_y[0], G_(h->enc_w[0]), G_(h->enc_b[0]), scw, sd));
         } else {
             { ProbeArm pa(h, 2, l);
-              if (use_bf16(h, l)) RC(launch_conv_wgrad_bf16(l, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd));
+              if (use_bf16(h, l)) RC(launch_conv_wgrad_bf16(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd));
               else RC(launch_conv_wgrad(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd)); }
             { ProbeArm pa(h, 1, l);
-              if (use_bf16(h, l)) RC(launch_conv_dgrad_bf16(l, B, ws + w.d_y[l], ws + w.wpack, ws + w.d_a[l - 1], ws + w.scratch, st));
+              if (use_bf16(h, l)) RC(launch_conv_dgrad_bf16(l, W, B, ws + w.d_y[l], ws + w.wpack, ws + w.d_a[l - 1], ws + w.scratch, st));
               else RC(launch_conv_dgrad(l, W, B, ws + w.d_y[l], P_(h->enc_w[l]), nullptr, ws + w.d_a[l - 1], nullptr, st)); }
         }
         if (l == 3 || l == 0) RC(join());               // end of phase 1 / phase 2

@@ -72,18 +72,18 @@ int64_t conv_fwd_ws_floats(int layer, int width, int B);
 int launch_conv_dgrad(int layer, int width, int B, const float* dout, const float* w,
                       const float* mask_src, float* din, float* ws, hipStream_t st);   // ws may be null (no split-K)
 int64_t conv_dgrad_ws_floats(int layer, int width, int B);
-// conv_bf16.hip — precision mode 1: bf16-MFMA forward / dgrad of layers 1..4 at width 64
+// conv_bf16.hip — precision mode 1: bf16-MFMA forward / dgrad / wgrad of layers 1..7
 bool conv_bf16_supported(int layer, int width);
 int64_t conv_bf16_pack_floats();
 int launch_pack_w_bf16(const float* const w[4], float* packed, hipStream_t st);
-int launch_conv_fwd_bf16(int layer, int B, const float* in, const float* packed, const float* bias, float* out,
+int launch_conv_fwd_bf16(int layer, int width, int B, const float* in, const float* packed, const float* bias, float* out,
                          float* bnpart, float* ws, hipStream_t st);
-int launch_conv_dgrad_bf16(int layer, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st);
+int launch_conv_dgrad_bf16(int layer, int width, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st);
 int launch_pack_up_bf16(const float* const wc[3], float* packed, hipStream_t st);
-int launch_conv_up_fwd_bf16(int layer, int B, const float* in, const float* packed, const float* bias, float* out, hipStream_t st);
-int launch_conv_up_dgrad_bf16(int layer, int B, const float* dout, const float* packed, const float* aux, float* din, hipStream_t st);
-int64_t wgrad_bf16_ws_floats(int layer, int B);
-int launch_conv_wgrad_bf16(int layer, int B, const float* in, const float* dout, float* dw, float* dbias, float* ws, hipStream_t st);
+int launch_conv_up_fwd_bf16(int layer, int width, int B, const float* in, const float* packed, const float* bias, float* out, hipStream_t st);
+int launch_conv_up_dgrad_bf16(int layer, int width, int B, const float* dout, const float* packed, const float* aux, float* din, hipStream_t st);
+int64_t wgrad_bf16_ws_floats(int layer, int width, int B);
+int launch_conv_wgrad_bf16(int layer, int width, int B, const float* in, const float* dout, float* dw, float* dbias, float* ws, hipStream_t st);
 int launch_splitk_bias_relu(const float* slab, const float* bias, float* out, int64_t slice, int KS, int C, hipStream_t st);
 // conv_wgrad.hip
 int64_t wgrad_ws_floats(int layer, int width, int B);
@@ -121,7 +121,7 @@ int launch_conv_up_dgrad(int layer, int width, int B, const float* dout, const f
 int64_t conv_up_wgrad_ws_floats(int layer, int width, int B);
 int launch_conv_up_wgrad(int layer, int width, int B, const float* in, const float* dout, float* dw,
                          float* dbias, float* ws, hipStream_t st, bool bf16 = false);
-int launch_up_wgrad_bf16_main(int layer, int B, const float* in, const float* dout, float* slab, int Smax, int* S_out, hipStream_t st);
+int launch_up_wgrad_bf16_main(int layer, int width, int B, const float* in, const float* dout, float* slab, int Smax, int* S_out, hipStream_t st);
 // bn.hip
 int bn_num_tiles(int layer, int width, int B);
 int launch_bn_fwd_finalize(int layer, int width, int B, const float* bnpart, const float* gamma,

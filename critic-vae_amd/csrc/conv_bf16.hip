@@ -285,66 +285,100 @@ static int run_bf16(const ConvBf16Args& a, hipStream_t st) {
     return 0;
 }
 
-bool conv_bf16_supported(int layer, int width) { return width == 64 && layer >= 1 && layer <= 7; }
+bool conv_bf16_supported(int layer, int width) { return (width == 64 || width == 128) && layer >= 1 && layer <= 7; }
 
-int launch_conv_fwd_bf16(int layer, int B, const float* in, const float* packed, const float* bias, float* out,
+int launch_conv_fwd_bf16(int layer, int width, int B, const float* in, const float* packed, const float* bias, float* out,
                          float* bnpart, float* ws, hipStream_t st) {
     ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0), bias, out, bnpart, B, 0, nullptr};
-    switch (layer) {
-        case 1: return run_bf16<32, 64, 32, 64, EPI_BIAS_BNSTAT>(a, st);
-        case 2: return run_bf16<64, 128, 16, 64, EPI_BIAS_BNSTAT>(a, st);
-        case 3: return run_bf16<128, 256, 8, 64, EPI_BIAS_BNSTAT>(a, st);
-        case 4: {
-            const int64_t slice = (int64_t)B * 16 * 128;
-            a.out = ws; a.sliceFloats = slice;
-            int rc = run_bf16<256, 128, 4, 64, EPI_PLAIN, 4>(a, st);
-            if (rc) return rc;
-            return launch_splitk_bias_relu(ws, bias, out, slice, 4, 128, st);
+    if (width == 64) {
+        switch (layer) {
+            case 1: return run_bf16<32, 64, 32, 64, EPI_BIAS_BNSTAT>(a, st);
+            case 2: return run_bf16<64, 128, 16, 64, EPI_BIAS_BNSTAT>(a, st);
+            case 3: return run_bf16<128, 256, 8, 64, EPI_BIAS_BNSTAT>(a, st);
+            case 4: {     // 4x4 images: split-K x4 over the channel chunks so that 256 workgroups exist at B=256
+                const int64_t slice = (int64_t)B * 16 * 128;
+                a.out = ws; a.sliceFloats = slice;
+                int rc = run_bf16<256, 128, 4, 64, EPI_PLAIN, 4>(a, st);
+                if (rc) return rc;
+                return launch_splitk_bias_relu(ws, bias, out, slice, 4, 128, st);
+            }
+        }
+    } else if (width == 128) {
+        switch (layer) {
+            case 1: return run_bf16<32, 64, 64, 64, EPI_BIAS_BNSTAT>(a, st);
+            case 2: return run_bf16<64, 128, 32, 64, EPI_BIAS_BNSTAT>(a, st);
+            case 3: return run_bf16<128, 256, 16, 64, EPI_BIAS_BNSTAT>(a, st);
+            case 4: return run_bf16<256, 128, 8, 64, EPI_BIAS_RELU>(a, st);
         }
     }
-    cvae_set_error("conv_fwd_bf16: unsupported layer %d", layer);
+    cvae_set_error("conv_fwd_bf16: unsupported layer %d at width %d", layer, width);
     return -2;
 }
 
-int launch_conv_dgrad_bf16(int layer, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st) {
+int launch_conv_dgrad_bf16(int layer, int width, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st) {
     ConvBf16Args a{dout, pack_ptr(const_cast<float*>(packed), layer, 1), nullptr, din, nullptr, B, 0, nullptr};
-    switch (layer) {
-        case 1: return run_bf16<64, 32, 32, 32, EPI_PLAIN>(a, st);
-        case 2: return run_bf16<128, 64, 16, 64, EPI_PLAIN>(a, st);
-        case 3: return run_bf16<256, 128, 8, 32, EPI_PLAIN>(a, st);
-        case 4: {
-            const int64_t slice = (int64_t)B * 16 * 256;
-            a.out = ws; a.sliceFloats = slice;
-            int rc = run_bf16<128, 256, 4, 64, EPI_PLAIN, 2>(a, st);
-            if (rc) return rc;
-            return launch_reduce_slabs(ws, din, slice, 2, slice, st, nullptr);
+    if (width == 64) {
+        switch (layer) {
+            case 1: return run_bf16<64, 32, 32, 32, EPI_PLAIN>(a, st);
+            case 2: return run_bf16<128, 64, 16, 64, EPI_PLAIN>(a, st);
+            case 3: return run_bf16<256, 128, 8, 32, EPI_PLAIN>(a, st);
+            case 4: {
+                const int64_t slice = (int64_t)B * 16 * 256;
+                a.out = ws; a.sliceFloats = slice;
+                int rc = run_bf16<128, 256, 4, 64, EPI_PLAIN, 2>(a, st);
+                if (rc) return rc;
+                return launch_reduce_slabs(ws, din, slice, 2, slice, st, nullptr);
+            }
+        }
+    } else if (width == 128) {
+        switch (layer) {
+            case 1: return run_bf16<64, 32, 64, 32, EPI_PLAIN>(a, st);
+            case 2: return run_bf16<128, 64, 32, 64, EPI_PLAIN>(a, st);
+            case 3: return run_bf16<256, 128, 16, 64, EPI_PLAIN>(a, st);
+            case 4: return run_bf16<128, 256, 8, 64, EPI_PLAIN>(a, st);
         }
     }
-    cvae_set_error("conv_dgrad_bf16: unsupported layer %d", layer);
+    cvae_set_error("conv_dgrad_bf16: unsupported layer %d at width %d", layer, width);
     return -2;
 }
 
 // Upsample(2)->Conv5x5 of D1..D3 (layers 5..7) on the bf16 MFMA: phase-collapsed 3x3 conv at the stored
 // low resolution (see conv_up.hip for the algebra); `in` = stored low-res activation (B,HS,HS,CIN).
-int launch_conv_up_fwd_bf16(int layer, int B, const float* in, const float* packed, const float* bias, float* out, hipStream_t st) {
+int launch_conv_up_fwd_bf16(int layer, int width, int B, const float* in, const float* packed, const float* bias, float* out, hipStream_t st) {
     ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0), bias, out, nullptr, B, 0, nullptr};
-    switch (layer) {
-        case 5: return run_bf16<128, 256, 4, 64, EPI_PLAIN, 1, 3, MODE_UP_FWD>(a, st);
-        case 6: return run_bf16<64, 128, 8, 64, EPI_PLAIN, 1, 3, MODE_UP_FWD>(a, st);
-        case 7: return run_bf16<32, 128, 16, 64, EPI_PLAIN, 1, 3, MODE_UP_FWD>(a, st);
+    if (width == 64) {
+        switch (layer) {
+            case 5: return run_bf16<128, 256, 4, 64, EPI_PLAIN, 1, 3, MODE_UP_FWD>(a, st);
+            case 6: return run_bf16<64, 128, 8, 64, EPI_PLAIN, 1, 3, MODE_UP_FWD>(a, st);
+            case 7: return run_bf16<32, 128, 16, 64, EPI_PLAIN, 1, 3, MODE_UP_FWD>(a, st);
+        }
+    } else if (width == 128) {
+        switch (layer) {
+            case 5: return run_bf16<128, 256, 8, 64, EPI_PLAIN, 1, 3, MODE_UP_FWD>(a, st);
+            case 6: return run_bf16<64, 128, 16, 64, EPI_PLAIN, 1, 3, MODE_UP_FWD>(a, st);
+            case 7: return run_bf16<32, 128, 32, 64, EPI_PLAIN, 1, 3, MODE_UP_FWD>(a, st);
+        }
     }
-    cvae_set_error("conv_up_fwd_bf16: unsupported layer %d", layer);
+    cvae_set_error("conv_up_fwd_bf16: unsupported layer %d at width %d", layer, width);
     return -2;
 }
 // d_in (B,HS,HS,CIN) = relu'(aux) * sum over phases/taps of dout (B,2HS,2HS,COUT)
-int launch_conv_up_dgrad_bf16(int layer, int B, const float* dout, const float* packed, const float* aux, float* din, hipStream_t st) {
+int launch_conv_up_dgrad_bf16(int layer, int width, int B, const float* dout, const float* packed, const float* aux, float* din, hipStream_t st) {
     ConvBf16Args a{dout, pack_ptr(const_cast<float*>(packed), layer, 1), nullptr, din, nullptr, B, 0, aux};
-    switch (layer) {
-        case 5: return run_bf16<256, 128, 4, 32, EPI_PLAIN, 1, 3, MODE_UP_DGRAD>(a, st);
-        case 6: return run_bf16<128, 64, 8, 32, EPI_PLAIN, 1, 3, MODE_UP_DGRAD>(a, st);
-        case 7: return run_bf16<128, 32, 16, 32, EPI_PLAIN, 1, 3, MODE_UP_DGRAD>(a, st);
+    if (width == 64) {
+        switch (layer) {
+            case 5: return run_bf16<256, 128, 4, 32, EPI_PLAIN, 1, 3, MODE_UP_DGRAD>(a, st);
+            case 6: return run_bf16<128, 64, 8, 32, EPI_PLAIN, 1, 3, MODE_UP_DGRAD>(a, st);
+            case 7: return run_bf16<128, 32, 16, 32, EPI_PLAIN, 1, 3, MODE_UP_DGRAD>(a, st);
+        }
+    } else if (width == 128) {
+        switch (layer) {
+            case 5: return run_bf16<256, 128, 8, 32, EPI_PLAIN, 1, 3, MODE_UP_DGRAD>(a, st);
+            case 6: return run_bf16<128, 64, 16, 32, EPI_PLAIN, 1, 3, MODE_UP_DGRAD>(a, st);
+            case 7: return run_bf16<128, 32, 32, 32, EPI_PLAIN, 1, 3, MODE_UP_DGRAD>(a, st);
+        }
     }
-    cvae_set_error("conv_up_dgrad_bf16: unsupported layer %d", layer);
+    cvae_set_error("conv_up_dgrad_bf16: unsupported layer %d at width %d", layer, width);
     return -2;
 }
 
@@ -534,24 +568,33 @@ static int run_wgrad_bf16(int B, const float* in, const float* dout, float* dw, 
     return launch_reduce_slabs(ws + n, dbias, COUT, S, row, st, nullptr);
 }
 
-static int dispatch_wgrad_bf16(int layer, int B, const float* in, const float* dout, float* dw, float* dbias, float* ws,
+static int dispatch_wgrad_bf16(int layer, int width, int B, const float* in, const float* dout, float* dw, float* dbias, float* ws,
                                hipStream_t st, int64_t* need) {
-    switch (layer) {
-        case 1: return run_wgrad_bf16<32, 64, 32>(B, in, dout, dw, dbias, ws, st, need);
-        case 2: return run_wgrad_bf16<64, 128, 16>(B, in, dout, dw, dbias, ws, st, need);
-        case 3: return run_wgrad_bf16<128, 256, 8>(B, in, dout, dw, dbias, ws, st, need);
-        case 4: return run_wgrad_bf16<256, 128, 4>(B, in, dout, dw, dbias, ws, st, need);
+    if (width == 64) {
+        switch (layer) {
+            case 1: return run_wgrad_bf16<32, 64, 32>(B, in, dout, dw, dbias, ws, st, need);
+            case 2: return run_wgrad_bf16<64, 128, 16>(B, in, dout, dw, dbias, ws, st, need);
+            case 3: return run_wgrad_bf16<128, 256, 8>(B, in, dout, dw, dbias, ws, st, need);
+            case 4: return run_wgrad_bf16<256, 128, 4>(B, in, dout, dw, dbias, ws, st, need);
+        }
+    } else if (width == 128) {
+        switch (layer) {
+            case 1: return run_wgrad_bf16<32, 64, 64>(B, in, dout, dw, dbias, ws, st, need);
+            case 2: return run_wgrad_bf16<64, 128, 32>(B, in, dout, dw, dbias, ws, st, need);
+            case 3: return run_wgrad_bf16<128, 256, 16>(B, in, dout, dw, dbias, ws, st, need);
+            case 4: return run_wgrad_bf16<256, 128, 8>(B, in, dout, dw, dbias, ws, st, need);
+        }
     }
-    cvae_set_error("conv_wgrad_bf16: unsupported layer %d", layer);
+    cvae_set_error("conv_wgrad_bf16: unsupported layer %d at width %d", layer, width);
     return -2;
 }
-int64_t wgrad_bf16_ws_floats(int layer, int B) {
+int64_t wgrad_bf16_ws_floats(int layer, int width, int B) {
     int64_t need = 0;
-    if (dispatch_wgrad_bf16(layer, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &need) != 0) return 0;
+    if (dispatch_wgrad_bf16(layer, width, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &need) != 0) return 0;
     return need;
 }
-int launch_conv_wgrad_bf16(int layer, int B, const float* in, const float* dout, float* dw, float* dbias, float* ws, hipStream_t st) {
-    return dispatch_wgrad_bf16(layer, B, in, dout, dw, dbias, ws, st, nullptr);
+int launch_conv_wgrad_bf16(int layer, int width, int B, const float* in, const float* dout, float* dw, float* dbias, float* ws, hipStream_t st) {
+    return dispatch_wgrad_bf16(layer, width, B, in, dout, dw, dbias, ws, st, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -679,12 +722,20 @@ static int run_up_wgrad_bf16_main(int B, const float* in, const float* dout, flo
 }
 
 // main kernel only: writes S (<= Smax) slab rows [36][CIN][COUT] | bias[COUT]; conv_up.hip reduces and expands them
-int launch_up_wgrad_bf16_main(int layer, int B, const float* in, const float* dout, float* slab, int Smax, int* S_out, hipStream_t st) {
-    switch (layer) {
-        case 5: return run_up_wgrad_bf16_main<128, 64, 4>(B, in, dout, slab, Smax, S_out, st);
-        case 6: return run_up_wgrad_bf16_main<64, 32, 8>(B, in, dout, slab, Smax, S_out, st);
-        case 7: return run_up_wgrad_bf16_main<32, 32, 16>(B, in, dout, slab, Smax, S_out, st);
+int launch_up_wgrad_bf16_main(int layer, int width, int B, const float* in, const float* dout, float* slab, int Smax, int* S_out, hipStream_t st) {
+    if (width == 64) {
+        switch (layer) {
+            case 5: return run_up_wgrad_bf16_main<128, 64, 4>(B, in, dout, slab, Smax, S_out, st);
+            case 6: return run_up_wgrad_bf16_main<64, 32, 8>(B, in, dout, slab, Smax, S_out, st);
+            case 7: return run_up_wgrad_bf16_main<32, 32, 16>(B, in, dout, slab, Smax, S_out, st);
+        }
+    } else if (width == 128) {
+        switch (layer) {
+            case 5: return run_up_wgrad_bf16_main<128, 64, 8>(B, in, dout, slab, Smax, S_out, st);
+            case 6: return run_up_wgrad_bf16_main<64, 32, 16>(B, in, dout, slab, Smax, S_out, st);
+            case 7: return run_up_wgrad_bf16_main<32, 32, 32>(B, in, dout, slab, Smax, S_out, st);
+        }
     }
-    cvae_set_error("conv_up_wgrad_bf16: unsupported layer %d", layer);
+    cvae_set_error("conv_up_wgrad_bf16: unsupported layer %d at width %d", layer, width);
     return -2;
 }

@@ -550,7 +550,7 @@ int launch_conv_up_dgrad(int layer, int width, int B, const float* dout, const f
 
 template <int CIN, int COUT, int HS>
 static int run_up_wgrad(int B, const float* in, const float* dout, float* dw, float* dbias, float* ws, hipStream_t st,
-                        int64_t* need, int bf16_layer = 0) {
+                        int64_t* need, int bf16_layer = 0, int bf16_width = 64) {
     using T = UpTile64<HS>;
     const int numTiles = cdiv(B, T::IMGS) * T::TILES_PER_IMG;
     const int bps = (CIN / 32) * (COUT / 32);
@@ -562,7 +562,7 @@ static int run_up_wgrad(int B, const float* in, const float* dout, float* dw, fl
     // ws = [S slabs | 16 mid rows | reduced row]
     if (need) { *need = (int64_t)(S + 17) * row; return 0; }
     if (bf16_layer) {          // precision mode 1: same slab rows from the bf16-MFMA kernel (conv_bf16.hip), S' <= S of them
-        int rc = launch_up_wgrad_bf16_main(bf16_layer, B, in, dout, ws, S, &S, st);
+        int rc = launch_up_wgrad_bf16_main(bf16_layer, bf16_width, B, in, dout, ws, S, &S, st);
         if (rc) return rc;
     } else {
         UpWgradArgs a{in, dout, ws, B, numTiles, tps};
@@ -593,9 +593,9 @@ static int dispatch_up_wgrad(int layer, int width, int B, const float* in, const
     }
     if (width == 128) {
         switch (layer) {
-            case 5: return run_up_wgrad<128, 64, 8>(B, in, dout, dw, dbias, ws, st, need);
-            case 6: return run_up_wgrad<64, 32, 16>(B, in, dout, dw, dbias, ws, st, need);
-            case 7: return run_up_wgrad<32, 32, 32>(B, in, dout, dw, dbias, ws, st, need);
+            case 5: return run_up_wgrad<128, 64, 8>(B, in, dout, dw, dbias, ws, st, need, bf16 ? 5 : 0, 128);
+            case 6: return run_up_wgrad<64, 32, 16>(B, in, dout, dw, dbias, ws, st, need, bf16 ? 6 : 0, 128);
+            case 7: return run_up_wgrad<32, 32, 32>(B, in, dout, dw, dbias, ws, st, need, bf16 ? 7 : 0, 128);
         }
     }
     cvae_set_error("conv_up_wgrad: unsupported layer %d at width %d", layer, width);
@@ -608,5 +608,5 @@ int64_t conv_up_wgrad_ws_floats(int layer, int width, int B) {
 }
 int launch_conv_up_wgrad(int layer, int width, int B, const float* in, const float* dout, float* dw, float* dbias,
                          float* ws, hipStream_t st, bool bf16) {
-    return dispatch_up_wgrad(layer, width, B, in, dout, dw, dbias, ws, st, nullptr, bf16 && width == 64);
+    return dispatch_up_wgrad(layer, width, B, in, dout, dw, dbias, ws, st, nullptr, bf16);
 }

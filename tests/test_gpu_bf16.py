@@ -11,10 +11,10 @@ from critic_vae_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _oracle_step(B, seed=0):
+def _oracle_step(B, seed=0, width=64):
     from oracle import cvae_oracle as orc
-    params = synth.make_params(seed)
-    x, pred, eps = synth.make_batch(1234, 0, B)
+    params = synth.make_params(seed, width)
+    x, pred, eps = synth.make_batch(1234, 0, B, width)
     p = orc.to_torch(params, requires_grad=True)
     out = orc.train_step(p, torch.from_numpy(x), torch.from_numpy(pred), torch.from_numpy(eps), bn_state=orc.new_bn_state(p))
     return params, (x, pred, eps), p, out
@@ -25,14 +25,15 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-300))
 
 
-@pytest.mark.parametrize("B", [4, 32])
-def test_bf16_step_close_to_fp32_oracle(B):
+@pytest.mark.parametrize("B,width", [(4, 64), (32, 64), (3, 128)])
+def test_bf16_step_close_to_fp32_oracle(B, width):
+    """width 128 = BASELINE.json config 5's frame size."""
     from critic_vae_amd.nets import VariationalAutoencoder
     from critic_vae_amd.train import FusedTrainer
     from critic_vae_amd import layout as L
     dev = torch.device("cuda:0")
-    params, (x, pred, eps), p, out = _oracle_step(B)
-    vae = VariationalAutoencoder(max_batch=B, seed=0, precision="bf16").to(dev)
+    params, (x, pred, eps), p, out = _oracle_step(B, width=width)
+    vae = VariationalAutoencoder(width=width, max_batch=B, seed=0, precision="bf16").to(dev)
     assert vae.handle.precision == "bf16"
     tr = FusedTrainer(vae)
     xs, ps, es = (torch.from_numpy(v).to(dev) for v in (x, pred, eps))
@@ -82,12 +83,14 @@ def test_bf16_training_trajectory_tracks_fp32():
     assert curves["bf16"][-1] < 0.6 * curves["bf16"][0]
 
 
-def test_bf16_mode_is_width_64_only_and_rejects_unknown_precisions():
-    from critic_vae_amd.lib import Handle, CvaeError
-    with pytest.raises(CvaeError):
-        Handle(128, 4, precision="bf16")
+def test_unknown_precisions_are_rejected():
+    import ctypes as C
+    from critic_vae_amd import lib as cvlib
     with pytest.raises(ValueError):
-        Handle(64, 4, precision="fp8")
+        cvlib.Handle(64, 4, precision="fp8")
+    h = cvlib._p()
+    cfg = cvlib._Config(64, 4, 0, 7)
+    assert cvlib.load().cvae_create(C.byref(cfg), C.byref(h)) != 0
 
 
 def test_bf16_inference_path_matches_fp32_mode():

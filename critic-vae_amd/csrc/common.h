@@ -74,14 +74,14 @@ int launch_conv_dgrad(int layer, int width, int B, const float* dout, const floa
 int64_t conv_dgrad_ws_floats(int layer, int width, int B);
 // conv_bf16.hip — precision mode 1: bf16-MFMA forward / dgrad / wgrad of layers 1..7
 bool conv_bf16_supported(int layer, int width);
-int64_t conv_bf16_pack_floats();
-int launch_pack_w_bf16(const float* const w[4], float* packed, hipStream_t st);
-int launch_conv_fwd_bf16(int layer, int width, int B, const float* in, const float* packed, const float* bias, float* out,
+int64_t conv_bf16_pack_floats(int ns);
+int launch_pack_w_bf16(const float* const w[4], float* packed, int ns, hipStream_t st);     // ns = 1 (bf16) or 3 (fp32 emulation)
+int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, const float* packed, const float* bias, float* out,
                          float* bnpart, float* ws, hipStream_t st);
-int launch_conv_dgrad_bf16(int layer, int width, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st);
-int launch_pack_up_bf16(const float* const wc[3], float* packed, hipStream_t st);
-int launch_conv_up_fwd_bf16(int layer, int width, int B, const float* in, const float* packed, const float* bias, float* out, hipStream_t st);
-int launch_conv_up_dgrad_bf16(int layer, int width, int B, const float* dout, const float* packed, const float* aux, float* din, hipStream_t st);
+int launch_conv_dgrad_bf16(int layer, int width, int ns, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st);
+int launch_pack_up_bf16(const float* const wc[3], float* packed, int ns, hipStream_t st);
+int launch_conv_up_fwd_bf16(int layer, int width, int ns, int B, const float* in, const float* packed, const float* bias, float* out, hipStream_t st);
+int launch_conv_up_dgrad_bf16(int layer, int width, int ns, int B, const float* dout, const float* packed, const float* aux, float* din, hipStream_t st);
 int64_t wgrad_bf16_ws_floats(int layer, int width, int B);
 int launch_conv_wgrad_bf16(int layer, int width, int B, const float* in, const float* dout, float* dw, float* dbias, float* ws, hipStream_t st);
 int launch_splitk_bias_relu(const float* slab, const float* bias, float* out, int64_t slice, int KS, int C, hipStream_t st);

@@ -32,7 +32,22 @@ struct ConvBf16Args {
     int B;
     int64_t sliceFloats;    // KSPLIT > 1: out = slab [KSPLIT][sliceFloats]
     const float* aux;       // MODE_UP_DGRAD: forward output of the producing layer (ReLU mask), layout of `out`
+    int64_t splitStride;    // NS == 3: units between the hi / mid / lo copies of the packed weights
 };
+
+// Exact 3-way bf16 split of an fp32 value: x == hi + mid + lo (each difference is exact in fp32, RNE
+// leaves at most 8 significant bits per step), used by the fp32-emulation mode (NS == 3): the nine
+// bf16 x bf16 partial products of two split operands are exact in the fp32 accumulator, so only the
+// summation order differs from an fp32 fma chain.
+struct Split3 { __bf16 hi, mid, lo; };
+__device__ __forceinline__ Split3 split3(float x) {
+    Split3 s;
+    s.hi = (__bf16)x;
+    const float r = x - (float)s.hi;
+    s.mid = (__bf16)r;
+    s.lo = (__bf16)(r - (float)s.mid);
+    return s;
+}
 
 // MODE_STD: 5x5 (or 3x3) conv of an NHWC tensor, epilogues of conv_epilogue.h.
 // MODE_UP_FWD: Upsample(2)->Conv5x5 (vae_nets.py:119-131) as the phase-collapsed 3x3 conv of
@@ -56,18 +71,19 @@ template <int H> struct Bf16Geom {
     static constexpr int PSP = ((Tile<H>::HP + 13) / 16) * 16 + 2;
 };
 
-template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT, int KS = 5, int MODE = MODE_STD>
+template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT, int KS = 5, int MODE = MODE_STD, int NS = 1>
 __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     using T = Tile<H>;
+    static_assert(NS == 1 || NS == 3, "operand splits: 1 (bf16) or 3 (fp32 emulation, 9 MFMAs per product block)");
     constexpr int OFF = 2 - KS / 2;                   // a 3x3 window sits one pixel inside the 5x5 halo
     constexpr int COUT_UP = (MODE == MODE_UP_FWD) ? NCH / 4 : KCH / 4;   // conv channels of the upsampled layer
-    constexpr int KCB = KCH < 64 ? KCH : 64;          // channels per K chunk
+    constexpr int KCB = NS == 3 ? 16 : (KCH < 64 ? KCH : 64);          // channels per K chunk
     constexpr int KB = KCB / 16, OCT = KCB / 8, NB = NT / 32;
     constexpr int PSP = Bf16Geom<H>::PSP;
     constexpr int A_UNITS = OCT * PSP, W_UNITS = KS * KB * 2 * NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);
-    bf16x8* lds_w = lds_a + A_UNITS;
+    bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);      // [split][octet][halo pixel]
+    bf16x8* lds_w = lds_a + NS * A_UNITS;                      // [split][tap][kb][half][n]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int mt = blockIdx.x, n0 = blockIdx.y * NT;
@@ -85,7 +101,7 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
 
     // weight slab of stage (cc, r): units [s][kb][half][n] <- wp[(r*5+s)][cc*KB + kb][half][n0 + n]
     constexpr int WPT = (W_UNITS + 255) / 256;
-    bf16x8 wreg[WPT];
+    bf16x8 wreg[NS * WPT];
     auto load_w = [&](int st) {
         const int cc = st / KS, r = st % KS;
 #pragma unroll
@@ -93,7 +109,9 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
             const int q = tid + i * 256;
             if (W_UNITS % 256 == 0 || q < W_UNITS) {
                 const int n = q % NT, row = q / NT, half = row & 1, kb = (row >> 1) % KB, s = row / (2 * KB);
-                wreg[i] = a.wp[((size_t)((r * KS + s) * (KCH / 16) + cc * KB + kb) * 2 + half) * NCH + n0 + n];
+                const size_t u = ((size_t)((r * KS + s) * (KCH / 16) + cc * KB + kb) * 2 + half) * NCH + n0 + n;
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) wreg[sp * WPT + i] = a.wp[u + sp * a.splitStride];
             }
         }
     };
@@ -101,7 +119,10 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int q = tid + i * 256;
-            if (W_UNITS % 256 == 0 || q < W_UNITS) lds_w[q] = wreg[i];
+            if (W_UNITS % 256 == 0 || q < W_UNITS) {
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) lds_w[sp * W_UNITS + q] = wreg[sp * WPT + i];
+            }
         }
     };
     // input halo chunk: fp32 NHWC -> bf16 units [octet][halo pixel]
@@ -123,7 +144,18 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
                 lo = *reinterpret_cast<const f32x4*>(src);
                 hi = *reinterpret_cast<const f32x4*>(src + 4);
             }
-            lds_a[oct * PSP + hp] = to_bf16x8(lo, hi);
+            if (NS == 1) {
+                lds_a[oct * PSP + hp] = to_bf16x8(lo, hi);
+            } else {
+                bf16x8 u0, u1, u2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const Split3 sl = split3(lo[e]), sh = split3(hi[e]);
+                    u0[e] = sl.hi; u1[e] = sl.mid; u2[e] = sl.lo;
+                    u0[4 + e] = sh.hi; u1[4 + e] = sh.mid; u2[4 + e] = sh.lo;
+                }
+                lds_a[oct * PSP + hp] = u0; lds_a[A_UNITS + oct * PSP + hp] = u1; lds_a[2 * A_UNITS + oct * PSP + hp] = u2;
+            }
         }
     };
 
@@ -144,10 +176,30 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
         for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
-                const bf16x8 av = ap[(kb * 2) * PSP + s];
+                if (NS == 1) {
+                    const bf16x8 av = ap[(kb * 2) * PSP + s];
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bp[((s * KB + kb) * 2) * NT + nb * 32], acc[nb], 0, 0, 0);
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bp[((s * KB + kb) * 2) * NT + nb * 32], acc[nb], 0, 0, 0);
+                } else {
+                    bf16x8 av[3];
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp) av[sp] = ap[sp * A_UNITS + (kb * 2) * PSP + s];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        bf16x8 bv[3];
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp) bv[sp] = bp[sp * W_UNITS + ((s * KB + kb) * 2) * NT + nb * 32];
+                        // nine exact partial products, smallest magnitudes first (0 = hi, 1 = mid, 2 = lo)
+#pragma unroll
+                        for (int d = 4; d >= 0; --d)
+#pragma unroll
+                            for (int ia = 0; ia < 3; ++ia) {
+                                const int ib = d - ia;
+                                if (ib >= 0 && ib < 3) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ia], bv[ib], acc[nb], 0, 0, 0);
+                            }
+                    }
+                }
             }
     }
     float* smem = reinterpret_cast<float*>(smem_raw);
@@ -200,7 +252,7 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
 //   PACK_UPFWD  : collapsed wc[4][9][CIN][COUT]    -> k = ci, n = p*COUT + co          (9 taps)
 //   PACK_UPDGRAD: same source, taps flipped        -> k = p*COUT + co, n = ci          (9 taps)
 enum { PACK_FWD = 0, PACK_DGRAD = 1, PACK_UPFWD = 2, PACK_UPDGRAD = 3 };
-struct PackJob { const float* w; bf16x8* dst; int cin, cout, mode; };
+struct PackJob { const float* w; bf16x8* dst; int cin, cout, mode, splits; };
 struct PackJobs { PackJob j[8]; };
 
 __global__ __launch_bounds__(256) void pack_w_bf16_kernel(PackJobs jobs) {
@@ -214,7 +266,7 @@ __global__ __launch_bounds__(256) void pack_w_bf16_kernel(PackJobs jobs) {
     for (int u = blockIdx.x * 256 + threadIdx.x; u < units; u += gridDim.x * 256) {
         const int n = u % N, row = u / N, half = row & 1, kb = (row >> 1) % (K / 16), tap = row / (2 * (K / 16));
         const int k0 = kb * 16 + half * 8;
-        bf16x8 r;
+        bf16x8 r0, r1, r2;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = k0 + e;
@@ -223,55 +275,58 @@ __global__ __launch_bounds__(256) void pack_w_bf16_kernel(PackJobs jobs) {
             else if (mode == PACK_DGRAD) v = jb.w[((size_t)(24 - tap) * cin + n) * cout + k];
             else if (mode == PACK_UPFWD) v = jb.w[((size_t)((n / cout) * 9 + tap) * cin + k) * cout + n % cout];
             else v = jb.w[((size_t)((k / cout) * 9 + 8 - tap) * cin + n) * cout + k % cout];
-            r[e] = (__bf16)v;
+            if (jb.splits == 1) r0[e] = (__bf16)v;
+            else { const Split3 sv = split3(v); r0[e] = sv.hi; r1[e] = sv.mid; r2[e] = sv.lo; }
         }
-        jb.dst[u] = r;
+        jb.dst[u] = r0;
+        if (jb.splits == 3) { jb.dst[units + u] = r1; jb.dst[2 * (size_t)units + u] = r2; }
     }
 }
 
-// packed copies live in one workspace block: [fwd L1 | dgrad L1 | ... | dgrad L4 | upfwd L5 | updgrad L5 | ... L7]
+// packed copies live in one workspace block: [fwd L1 | dgrad L1 | ... | dgrad L4 | upfwd L5 | updgrad L5 | ... L7],
+// each entry = ns (1 or 3) consecutive split copies of pack_units(layer) units
 static int64_t pack_units(int layer) { return (int64_t)(layer >= 5 ? 36 : 25) * kLayers[layer].cin * kLayers[layer].cout / 8; }
-int64_t conv_bf16_pack_floats() {
+int64_t conv_bf16_pack_floats(int ns) {
     int64_t u = 0;
-    for (int l = 1; l <= 7; ++l) u += 2 * pack_units(l);
+    for (int l = 1; l <= 7; ++l) u += 2 * ns * pack_units(l);
     return u * 4;                               // 16-byte units -> floats
 }
-static bf16x8* pack_ptr(float* packed, int layer, int dgrad) {
+static bf16x8* pack_ptr(float* packed, int layer, int dgrad, int ns) {
     int64_t u = 0;
-    for (int l = 1; l < layer; ++l) u += 2 * pack_units(l);
-    if (dgrad) u += pack_units(layer);
+    for (int l = 1; l < layer; ++l) u += 2 * ns * pack_units(l);
+    if (dgrad) u += ns * pack_units(layer);
     return reinterpret_cast<bf16x8*>(packed) + u;
 }
 
-int launch_pack_w_bf16(const float* const w[4], float* packed, hipStream_t st) {
+int launch_pack_w_bf16(const float* const w[4], float* packed, int ns, hipStream_t st) {
     PackJobs jobs;
     for (int l = 1; l <= 4; ++l)
         for (int d = 0; d < 2; ++d)
-            jobs.j[(l - 1) * 2 + d] = PackJob{w[l - 1], pack_ptr(packed, l, d), kLayers[l].cin, kLayers[l].cout, d ? PACK_DGRAD : PACK_FWD};
+            jobs.j[(l - 1) * 2 + d] = PackJob{w[l - 1], pack_ptr(packed, l, d, ns), kLayers[l].cin, kLayers[l].cout, d ? PACK_DGRAD : PACK_FWD, ns};
     hipLaunchKernelGGL(pack_w_bf16_kernel, dim3(128, 8), dim3(256), 0, st, jobs);
     CVAE_CHECK_LAUNCH();
     return 0;
 }
 // collapsed weights wc[i] of D1..D3 (conv_up.hip: collapse_w_kernel must have run on `st` before)
-int launch_pack_up_bf16(const float* const wc[3], float* packed, hipStream_t st) {
+int launch_pack_up_bf16(const float* const wc[3], float* packed, int ns, hipStream_t st) {
     PackJobs jobs;
-    for (int i = 0; i < 8; ++i) jobs.j[i] = PackJob{nullptr, nullptr, 0, 0, 0};
+    for (int i = 0; i < 8; ++i) jobs.j[i] = PackJob{nullptr, nullptr, 0, 0, 0, 1};
     for (int l = 5; l <= 7; ++l)
         for (int d = 0; d < 2; ++d)
-            jobs.j[(l - 5) * 2 + d] = PackJob{wc[l - 5], pack_ptr(packed, l, d), kLayers[l].cin, kLayers[l].cout, d ? PACK_UPDGRAD : PACK_UPFWD};
+            jobs.j[(l - 5) * 2 + d] = PackJob{wc[l - 5], pack_ptr(packed, l, d, ns), kLayers[l].cin, kLayers[l].cout, d ? PACK_UPDGRAD : PACK_UPFWD, ns};
     hipLaunchKernelGGL(pack_w_bf16_kernel, dim3(32, 6), dim3(256), 0, st, jobs);
     CVAE_CHECK_LAUNCH();
     return 0;
 }
 
-template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT = 1, int KS = 5, int MODE = MODE_STD>
-static int run_bf16(const ConvBf16Args& a, hipStream_t st) {
+template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT = 1, int KS = 5, int MODE = MODE_STD, int NS = 1>
+static int run_bf16_ns(const ConvBf16Args& a, hipStream_t st) {
     using T = Tile<H>;
-    constexpr int KCB = KCH < 64 ? KCH : 64;
-    constexpr int STAGE = ((KCB / 8) * Bf16Geom<H>::PSP + KS * (KCB / 16) * 2 * NT) * 16;
+    constexpr int KCB = NS == 3 ? 16 : (KCH < 64 ? KCH : 64);
+    constexpr int STAGE = NS * ((KCB / 8) * Bf16Geom<H>::PSP + KS * (KCB / 16) * 2 * NT) * 16;
     constexpr int EPI_BYTES = (8 * NT > 4 * 32 * 36 ? 8 * NT : 4 * 32 * 36) * 4;
     constexpr int SMEM = STAGE > EPI_BYTES ? STAGE : EPI_BYTES;
-    auto kern = conv5x5_bf16_kernel<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE>;
+    auto kern = conv5x5_bf16_kernel<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, NS>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -285,11 +340,18 @@ static int run_bf16(const ConvBf16Args& a, hipStream_t st) {
     return 0;
 }
 
+// a.splitStride != 0 selects the 3-split fp32-emulation instantiation
+template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT = 1, int KS = 5, int MODE = MODE_STD>
+static int run_bf16(const ConvBf16Args& a, hipStream_t st) {
+    if (a.splitStride) return run_bf16_ns<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, 3>(a, st);
+    return run_bf16_ns<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, 1>(a, st);
+}
+
 bool conv_bf16_supported(int layer, int width) { return (width == 64 || width == 128) && layer >= 1 && layer <= 7; }
 
-int launch_conv_fwd_bf16(int layer, int width, int B, const float* in, const float* packed, const float* bias, float* out,
+int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, const float* packed, const float* bias, float* out,
                          float* bnpart, float* ws, hipStream_t st) {
-    ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0), bias, out, bnpart, B, 0, nullptr};
+    ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0, ns), bias, out, bnpart, B, 0, nullptr, ns == 3 ? pack_units(layer) : 0};
     if (width == 64) {
         switch (layer) {
             case 1: return run_bf16<32, 64, 32, 64, EPI_BIAS_BNSTAT>(a, st);
@@ -315,8 +377,8 @@ int launch_conv_fwd_bf16(int layer, int width, int B, const float* in, const flo
     return -2;
 }
 
-int launch_conv_dgrad_bf16(int layer, int width, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st) {
-    ConvBf16Args a{dout, pack_ptr(const_cast<float*>(packed), layer, 1), nullptr, din, nullptr, B, 0, nullptr};
+int launch_conv_dgrad_bf16(int layer, int width, int ns, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st) {
+    ConvBf16Args a{dout, pack_ptr(const_cast<float*>(packed), layer, 1, ns), nullptr, din, nullptr, B, 0, nullptr, ns == 3 ? pack_units(layer) : 0};
     if (width == 64) {
         switch (layer) {
             case 1: return run_bf16<64, 32, 32, 32, EPI_PLAIN>(a, st);
@@ -344,8 +406,8 @@ int launch_conv_dgrad_bf16(int layer, int width, int B, const float* dout, const
 
 // Upsample(2)->Conv5x5 of D1..D3 (layers 5..7) on the bf16 MFMA: phase-collapsed 3x3 conv at the stored
 // low resolution (see conv_up.hip for the algebra); `in` = stored low-res activation (B,HS,HS,CIN).
-int launch_conv_up_fwd_bf16(int layer, int width, int B, const float* in, const float* packed, const float* bias, float* out, hipStream_t st) {
-    ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0), bias, out, nullptr, B, 0, nullptr};
+int launch_conv_up_fwd_bf16(int layer, int width, int ns, int B, const float* in, const float* packed, const float* bias, float* out, hipStream_t st) {
+    ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0, ns), bias, out, nullptr, B, 0, nullptr, ns == 3 ? pack_units(layer) : 0};
     if (width == 64) {
         switch (layer) {
             case 5: return run_bf16<128, 256, 4, 64, EPI_PLAIN, 1, 3, MODE_UP_FWD>(a, st);
@@ -363,8 +425,8 @@ int launch_conv_up_fwd_bf16(int layer, int width, int B, const float* in, const 
     return -2;
 }
 // d_in (B,HS,HS,CIN) = relu'(aux) * sum over phases/taps of dout (B,2HS,2HS,COUT)
-int launch_conv_up_dgrad_bf16(int layer, int width, int B, const float* dout, const float* packed, const float* aux, float* din, hipStream_t st) {
-    ConvBf16Args a{dout, pack_ptr(const_cast<float*>(packed), layer, 1), nullptr, din, nullptr, B, 0, aux};
+int launch_conv_up_dgrad_bf16(int layer, int width, int ns, int B, const float* dout, const float* packed, const float* aux, float* din, hipStream_t st) {
+    ConvBf16Args a{dout, pack_ptr(const_cast<float*>(packed), layer, 1, ns), nullptr, din, nullptr, B, 0, aux, ns == 3 ? pack_units(layer) : 0};
     if (width == 64) {
         switch (layer) {
             case 5: return run_bf16<256, 128, 4, 32, EPI_PLAIN, 1, 3, MODE_UP_DGRAD>(a, st);

@@ -108,3 +108,39 @@ def test_bf16_inference_path_matches_fp32_mode():
             outs[prec] = (mu.cpu(), vae.decoder(mu, pred).cpu())
     assert (outs["bf16"][0] - outs["f32"][0]).abs().max() < 3e-2
     assert (outs["bf16"][1] - outs["f32"][1]).abs().max() < 3e-2
+
+
+@pytest.mark.parametrize("B", [4, 32])
+def test_bf16x9_emulation_meets_the_fp32_parity_bar(B):
+    """precision="bf16x9": operands split exactly into three bf16 parts, nine exact partial products per
+    fp32 product -> only the summation order differs from fp32.  Held to the fp32 bar of
+    tests/test_gpu_step.py: 1e-4 absolute everywhere; relative to each gradient tensor's max 5e-3 (the fp32
+    test allows 1e-3 for ReLU / max-pool decisions that flip within an ulp of zero; another summation
+    order flips a few other elements — measured worst case 3.9e-3 = 2.1e-6 absolute on enc2.weight)."""
+    from critic_vae_amd.nets import VariationalAutoencoder
+    from critic_vae_amd.train import FusedTrainer
+    from critic_vae_amd import layout as L
+    dev = torch.device("cuda:0")
+    params, (x, pred, eps), p, out = _oracle_step(B)
+    xs, ps, es = (torch.from_numpy(v).to(dev) for v in (x, pred, eps))
+    res = {}
+    for prec in ("bf16x9", "f32"):
+        vae = VariationalAutoencoder(max_batch=B, seed=0, precision=prec).to(dev)
+        tr = FusedTrainer(vae)
+        scal = tr.step(xs, ps, es).cpu()
+        res[prec] = (tr.mu[:B].cpu(), tr.recon[:B].cpu(), float(scal[0]), L.native_to_ref(vae.handle.layout, tr.grads.cpu()))
+    mu, recon, loss, got = res["bf16x9"]
+    assert (mu - out["mu"].detach()).abs().max() < 1e-4
+    assert (recon - out["recon"].detach()).abs().max() < 1e-4
+    assert abs(loss - float(out["total_loss"].detach())) < 1e-4
+    for k, v in p.items():
+        if v.grad is None:
+            continue
+        g, want = got[k].double(), v.grad.detach().double()
+        err = (g - want).abs().max().item()
+        assert err <= 1e-4, (k, err)
+        pre_bn_bias = k.startswith("encoder.model.") and k.endswith(".bias") and int(k.split(".")[2]) % 4 == 0
+        if not pre_bn_bias:
+            assert err <= 5e-3 * max(want.abs().max().item(), 1e-30), (k, err)
+    # and it sits as close to the fp32-MFMA mode as that mode sits to the oracle
+    assert (mu - res["f32"][0]).abs().max() < 2e-5 and (recon - res["f32"][1]).abs().max() < 2e-5

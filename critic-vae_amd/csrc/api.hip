@@ -104,12 +104,12 @@ static WsLayout carve(const cvae_handle_s* h, int B) {
     }
     w.dout4 = take((int64_t)B * 3 * W * W);
     for (int i = 0; i < 3; ++i) w.wc[i] = take(conv_up_wc_floats(5 + i));
-    w.wpack = take(h->cfg.reserved1 != 0 ? conv_bf16_pack_floats(h->cfg.reserved1 == 2 ? 3 : 1) : 0);
+    w.wpack = take(h->cfg.precision != 0 ? conv_bf16_pack_floats(h->cfg.precision == 2 ? 3 : 1) : 0);
     w.ms = take(msssim_ws_floats(W, B));
     int64_t sc = 0, scw = 0;
     auto mx = [&](int64_t v) { if (v > sc) sc = v; };
     for (int l = 1; l <= 4; ++l) { if (wgrad_ws_floats(l, W, B) > scw) scw = wgrad_ws_floats(l, W, B);
-        if (h->cfg.reserved1 == 1 && conv_bf16_supported(l, W) && wgrad_bf16_ws_floats(l, W, B) > scw) scw = wgrad_bf16_ws_floats(l, W, B);
+        if (h->cfg.precision == 1 && conv_bf16_supported(l, W) && wgrad_bf16_ws_floats(l, W, B) > scw) scw = wgrad_bf16_ws_floats(l, W, B);
         mx(conv_fwd_ws_floats(l, W, B)); mx(conv_dgrad_ws_floats(l, W, B)); }
     for (int l = 5; l <= 7; ++l) { if (conv_up_wgrad_ws_floats(l, W, B) > scw) scw = conv_up_wgrad_ws_floats(l, W, B); mx(conv_up_ws_floats(l, W, B)); }
     if (e1_wgrad_ws_floats(W, B) > scw) scw = e1_wgrad_ws_floats(W, B);
@@ -138,7 +138,7 @@ const char* cvae_last_error(void) { return g_err; }
 int cvae_create(const cvae_config* cfg, cvae_handle* out) {
     if (!cfg || !out) { cvae_set_error("cvae_create: null argument"); return CVAE_EINVAL; }
     if (cfg->width != 64 && cfg->width != 128) { cvae_set_error("cvae_create: width %d not supported (64 or 128)", cfg->width); return CVAE_EUNSUPPORTED; }
-    if (cfg->reserved1 < 0 || cfg->reserved1 > 2) { cvae_set_error("cvae_create: precision %d not supported (0 = fp32, 1 = bf16 MFMA, 2 = fp32 emulated by 3-way bf16 splits)", cfg->reserved1); return CVAE_EUNSUPPORTED; }
+    if (cfg->precision < 0 || cfg->precision > 2) { cvae_set_error("cvae_create: precision %d not supported (0 = fp32, 1 = bf16 MFMA, 2 = fp32 emulated by 3-way bf16 splits)", cfg->precision); return CVAE_EUNSUPPORTED; }
     cvae_handle_s* h = new cvae_handle_s();
     h->cfg = *cfg;
     h->param_total = 0;
@@ -212,14 +212,14 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
 #define G_(idx) (grads + h->params[(idx)].offset)
 #define RC(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
-// cvae_config.reserved1: 1 = bf16-MFMA kernels for every pass of E2..E4 / D0..D3 (conv_bf16.hip); 2 = the same
+// cvae_config.precision: 1 = bf16-MFMA kernels for every pass of E2..E4 / D0..D3 (conv_bf16.hip); 2 = the same
 // forward / input-gradient kernels with 3-way split operands (exact fp32 products, 9 MFMAs each), fp32 wgrad
 static bool use_bf16(cvae_handle h, int layer) {
-    if (h->cfg.reserved1 == 2 && layer > 4) return false;     // D1..D3: the fp32 phase-collapsed kernels beat nine bf16 MFMAs per block
-    return h->cfg.reserved1 != 0 && conv_bf16_supported(layer, h->cfg.width);
+    if (h->cfg.precision == 2 && layer > 4) return false;     // D1..D3: the fp32 phase-collapsed kernels beat nine bf16 MFMAs per block
+    return h->cfg.precision != 0 && conv_bf16_supported(layer, h->cfg.width);
 }
-static bool use_bf16_wgrad(cvae_handle h, int layer) { return h->cfg.reserved1 == 1 && conv_bf16_supported(layer, h->cfg.width); }
-static int bf16_splits(cvae_handle h) { return h->cfg.reserved1 == 2 ? 3 : 1; }
+static bool use_bf16_wgrad(cvae_handle h, int layer) { return h->cfg.precision == 1 && conv_bf16_supported(layer, h->cfg.width); }
+static int bf16_splits(cvae_handle h) { return h->cfg.precision == 2 ? 3 : 1; }
 static int pack_bf16_weights(cvae_handle h, const float* params, float* ws, const WsLayout& w, hipStream_t st) {
     if (!use_bf16(h, 1)) return 0;
     const float* wl[4] = {P_(h->enc_w[1]), P_(h->enc_w[2]), P_(h->enc_w[3]), P_(h->dec_w[0])};
@@ -332,9 +332,9 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
     const int W = h->cfg.width;
     float* sc = ws + w.scratch;
     float* scw = ws + w.scratch_w;
-    // cfg.reserved0 != 0: weight-gradient work on a lower-priority side stream (+3% at B=256, but
+    // cfg.overlap_wgrad != 0: weight-gradient work on a lower-priority side stream (+3% at B=256, but
     // per-kernel timings then overlap); default: everything in order on the caller's stream.
-    const bool overlap = h->cfg.reserved0 != 0;
+    const bool overlap = h->cfg.overlap_wgrad != 0;
     if (overlap) RC(ensure_streams(h));
     hipStream_t sd = overlap ? h->side : st;
 #define HIPRC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cvae_set_error("%s: %s", #call, hipGetErrorString(e_)); return (int)e_; } } while (0)

@@ -20,7 +20,7 @@ class CvaeError(RuntimeError):
 
 class _Config(C.Structure):
     _fields_ = [("width", C.c_int32), ("max_batch", C.c_int32),
-                ("reserved0", C.c_int32), ("reserved1", C.c_int32)]
+                ("overlap_wgrad", C.c_int32), ("precision", C.c_int32)]
 
 
 def build(verbose=False):

@@ -33,8 +33,8 @@ typedef struct cvae_handle_s* cvae_handle;
 typedef struct cvae_config {
     int32_t width;        /* frame width == height: 64 (vae_parameters.py:5) or 128 (BASELINE config 5 shape) */
     int32_t max_batch;    /* largest per-call batch the workspace is sized for                 */
-    int32_t reserved0;    /* != 0: run weight-gradient kernels on an internal low-priority side stream */
-    int32_t reserved1;    /* precision: 0 = fp32 everywhere (the 1e-4-parity path); 1 = bf16-MFMA contractions
+    int32_t overlap_wgrad;    /* != 0: run weight-gradient kernels on an internal low-priority side stream */
+    int32_t precision;    /* precision: 0 = fp32 everywhere (the 1e-4-parity path); 1 = bf16-MFMA contractions
                            * (fp32 accumulate, fp32 tensors and master weights in HBM) for every pass of the convs
                            * E2..E4 and D0..D3 (BASELINE.json configs 3-5); 2 = fp32 emulation: forward/dgrad of E2..E4 and D0 on
                            * the bf16 MFMA with exact 3-way bf16 operand splits (9 MFMAs per block), everything else as 0;

@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE.json configs[1])")
     ap.add_argument("--width", type=int, choices=[64, 128], default=64, help="frame size (128: BASELINE configs[4] shape)")
-    ap.add_argument("--precision", choices=["f32", "bf16", "bf16x9"], default="f32",
+    ap.add_argument("--precision", choices=["f32", "bf16", "bf16x9", "bf16x6"], default="f32",
                     help="f32 = the 1e-4-parity path (default, BASELINE configs[1]); bf16 = bf16-MFMA forward/dgrad "
                          "convs (configs[2]: use with --batch 2048)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -182,10 +182,13 @@ def main():
         "vs_baseline": None,
         "dtype": {"f32": "f32", "bf16": "bf16 MFMA operands (fwd+dgrad+wgrad of E2-E4, D0-D3), f32 elsewhere",
                   "bf16x9": "f32 emulated: 3-way exact bf16 operand splits, 9 bf16 MFMAs per product block (fwd+dgrad of "
-                            "E2-E4, D0-D3), f32 MFMA wgrad, f32 elsewhere"}[args.precision],
+                            "E2-E4, D0), f32 MFMA wgrad, f32 elsewhere",
+                  "bf16x6": "f32 emulated: 3-way exact bf16 operand splits, the 6 leading partial products (fwd+dgrad of "
+                            "E2-E4, D0), f32 MFMA wgrad, f32 elsewhere"}[args.precision],
         "data": "synthetic",
         "config": {"workload": ({"f32": "BASELINE.json configs[1]: fp32", "bf16": "BASELINE.json configs[2]: bf16-MFMA",
-                                 "bf16x9": "BASELINE.json configs[1] workload, fp32 emulated by 3-way bf16 splits"}[args.precision]
+                                 "bf16x9": "BASELINE.json configs[1] workload, fp32 emulated by 3-way bf16 splits",
+                                 "bf16x6": "BASELINE.json configs[1] workload, fp32 emulated by 3-way bf16 splits (6 products)"}[args.precision]
                                 if Wd == 64 else f"BASELINE.json configs[4] frame size (128x128), {args.precision}")
                                + " train step (fwd+MS-SSIM/KLD loss+bwd+Adam), "
                                f"batch {B}/GPU, {Wd}x{Wd}x3 frames + critic scalars", "global_batch": world * B,
@@ -201,7 +204,7 @@ def main():
             H.probe_config([])
             sec = sum(ms) / len(ms) * 1e-3
             fl = conv_flops(dominant % 9, B, Wd)
-            on_bf16 = (args.precision == "bf16" and 1 <= dominant % 9 <= 7) or (args.precision == "bf16x9" and dominant // 9 < 2 and 1 <= dominant % 9 <= 7)
+            on_bf16 = (args.precision == "bf16" and 1 <= dominant % 9 <= 7) or (args.precision in ("bf16x9", "bf16x6") and dominant // 9 < 2 and 1 <= dominant % 9 <= 4)
             peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
             res["roofline"] = {
                 "bound": "mfma", "kernel": probe_name(dominant), "achieved": round(fl / sec / 1e12, 2),

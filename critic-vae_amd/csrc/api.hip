@@ -104,7 +104,7 @@ static WsLayout carve(const cvae_handle_s* h, int B) {
     }
     w.dout4 = take((int64_t)B * 3 * W * W);
     for (int i = 0; i < 3; ++i) w.wc[i] = take(conv_up_wc_floats(5 + i));
-    w.wpack = take(h->cfg.precision != 0 ? conv_bf16_pack_floats(h->cfg.precision == 2 ? 3 : 1) : 0);
+    w.wpack = take(h->cfg.precision != 0 ? conv_bf16_pack_floats(h->cfg.precision >= 2 ? 3 : 1) : 0);
     w.ms = take(msssim_ws_floats(W, B));
     int64_t sc = 0, scw = 0;
     auto mx = [&](int64_t v) { if (v > sc) sc = v; };
@@ -138,7 +138,7 @@ const char* cvae_last_error(void) { return g_err; }
 int cvae_create(const cvae_config* cfg, cvae_handle* out) {
     if (!cfg || !out) { cvae_set_error("cvae_create: null argument"); return CVAE_EINVAL; }
     if (cfg->width != 64 && cfg->width != 128) { cvae_set_error("cvae_create: width %d not supported (64 or 128)", cfg->width); return CVAE_EUNSUPPORTED; }
-    if (cfg->precision < 0 || cfg->precision > 2) { cvae_set_error("cvae_create: precision %d not supported (0 = fp32, 1 = bf16 MFMA, 2 = fp32 emulated by 3-way bf16 splits)", cfg->precision); return CVAE_EUNSUPPORTED; }
+    if (cfg->precision < 0 || cfg->precision > 3) { cvae_set_error("cvae_create: precision %d not supported (0 = fp32, 1 = bf16 MFMA, 2 = fp32 emulated by 3-way bf16 splits)", cfg->precision); return CVAE_EUNSUPPORTED; }
     cvae_handle_s* h = new cvae_handle_s();
     h->cfg = *cfg;
     h->param_total = 0;
@@ -215,11 +215,12 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
 // cvae_config.precision: 1 = bf16-MFMA kernels for every pass of E2..E4 / D0..D3 (conv_bf16.hip); 2 = the same
 // forward / input-gradient kernels with 3-way split operands (exact fp32 products, 9 MFMAs each), fp32 wgrad
 static bool use_bf16(cvae_handle h, int layer) {
-    if (h->cfg.precision == 2 && layer > 4) return false;     // D1..D3: the fp32 phase-collapsed kernels beat nine bf16 MFMAs per block
+    if (h->cfg.precision >= 2 && layer > 4) return false;     // D1..D3: the fp32 phase-collapsed kernels beat nine bf16 MFMAs per block
     return h->cfg.precision != 0 && conv_bf16_supported(layer, h->cfg.width);
 }
 static bool use_bf16_wgrad(cvae_handle h, int layer) { return h->cfg.precision == 1 && conv_bf16_supported(layer, h->cfg.width); }
-static int bf16_splits(cvae_handle h) { return h->cfg.precision == 2 ? 3 : 1; }
+static int bf16_splits(cvae_handle h) { return h->cfg.precision >= 2 ? 3 : 1; }          // packed weight copies
+static int bf16_mode(cvae_handle h) { return h->cfg.precision == 2 ? 3 : (h->cfg.precision == 3 ? 6 : 1); }   // launcher code: 1 bf16, 3 x9, 6 x6
 static int pack_bf16_weights(cvae_handle h, const float* params, float* ws, const WsLayout& w, hipStream_t st) {
     if (!use_bf16(h, 1)) return 0;
     const float* wl[4] = {P_(h->enc_w[1]), P_(h->enc_w[2]), P_(h->enc_w[3]), P_(h->dec_w[0])};
@@ -244,7 +245,7 @@ int cvae_forward(cvae_handle h, int32_t B, const float* x, const float* pred, co
     RC(pack_bf16_weights(h, params, ws, w, st));
     for (int l = 0; l < 4; ++l) {
         if (l == 0) RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], ws + w.bnpart[0], st));
-        else if (use_bf16(h, l)) { ProbeArm pa(h, 0, l); RC(launch_conv_fwd_bf16(l, W, bf16_splits(h), B, ws + w.a[l - 1], ws + w.wpack, P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st)); }
+        else if (use_bf16(h, l)) { ProbeArm pa(h, 0, l); RC(launch_conv_fwd_bf16(l, W, bf16_mode(h), B, ws + w.a[l - 1], ws + w.wpack, P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st)); }
         else { ProbeArm pa(h, 0, l); RC(launch_conv_fwd(l, W, B, ws + w.a[l - 1], P_(h->enc_w[l]), P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st)); }
         RC(launch_bn_fwd_finalize(l, W, B, ws + w.bnpart[l], P_(h->enc_g[l]), P_(h->enc_be[l]), bn_state + kBnOff[l],
                                   bn_state + 480 + kBnOff[l], ws + w.coef[l], ws + w.scratch, train, st));
@@ -278,10 +279,10 @@ int cvae_decode(cvae_handle h, int32_t B, const float* zcat, const float* params
     for (int i = 0; i < 4; ++i) {
         ProbeArm pa(h, 0, 4 + i);
         if (i == 0) {
-            if (use_bf16(h, 4)) RC(launch_conv_fwd_bf16(4, W, bf16_splits(h), B, ws + w.h, ws + w.wpack, P_(h->dec_b[0]), ws + w.o[0], nullptr, ws + w.scratch, st));
+            if (use_bf16(h, 4)) RC(launch_conv_fwd_bf16(4, W, bf16_mode(h), B, ws + w.h, ws + w.wpack, P_(h->dec_b[0]), ws + w.o[0], nullptr, ws + w.scratch, st));
             else RC(launch_conv_fwd(4, W, B, ws + w.h, P_(h->dec_w[0]), P_(h->dec_b[0]), ws + w.o[0], nullptr, ws + w.scratch, st));
         } else if (use_bf16(h, 4 + i)) {
-            RC(launch_conv_up_fwd_bf16(4 + i, W, bf16_splits(h), B, ws + w.o[i - 1], ws + w.wpack, P_(h->dec_b[i]), ws + w.o[i], st));
+            RC(launch_conv_up_fwd_bf16(4 + i, W, bf16_mode(h), B, ws + w.o[i - 1], ws + w.wpack, P_(h->dec_b[i]), ws + w.o[i], st));
         } else {
             RC(launch_conv_up_fwd(4 + i, W, B, ws + w.o[i - 1], ws + w.wc[i - 1], P_(h->dec_b[i]), ws + w.o[i], ws + w.scratch, st));
         }
@@ -365,12 +366,12 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
               if (use_bf16_wgrad(h, 4)) RC(launch_conv_wgrad_bf16(4, W, B, in, ws + w.d_o[0], G_(h->dec_w[0]), G_(h->dec_b[0]), scw, sd));
               else RC(launch_conv_wgrad(l, W, B, in, ws + w.d_o[0], G_(h->dec_w[0]), G_(h->dec_b[0]), scw, sd)); }
             { ProbeArm pa(h, 1, l);
-              if (use_bf16(h, 4)) RC(launch_conv_dgrad_bf16(4, W, bf16_splits(h), B, ws + w.d_o[0], ws + w.wpack, ws + w.d_h, ws + w.scratch, st));
+              if (use_bf16(h, 4)) RC(launch_conv_dgrad_bf16(4, W, bf16_mode(h), B, ws + w.d_o[0], ws + w.wpack, ws + w.d_h, ws + w.scratch, st));
               else RC(launch_conv_dgrad(l, W, B, ws + w.d_o[0], P_(h->dec_w[0]), nullptr, ws + w.d_h, ws + w.scratch, st)); }
         } else {
             { ProbeArm pa(h, 2, l); RC(launch_conv_up_wgrad(l, W, B, in, ws + w.d_o[i], G_(h->dec_w[i]), G_(h->dec_b[i]), scw, sd, use_bf16_wgrad(h, l))); }
             { ProbeArm pa(h, 1, l);
-              if (use_bf16(h, l)) RC(launch_conv_up_dgrad_bf16(l, W, bf16_splits(h), B, ws + w.d_o[i], ws + w.wpack, ws + w.o[i - 1], ws + w.d_o[i - 1], st));
+              if (use_bf16(h, l)) RC(launch_conv_up_dgrad_bf16(l, W, bf16_mode(h), B, ws + w.d_o[i], ws + w.wpack, ws + w.o[i - 1], ws + w.d_o[i - 1], st));
               else RC(launch_conv_up_dgrad(l, W, B, ws + w.d_o[i], ws + w.wc[i - 1], ws + w.o[i - 1], ws + w.d_o[i - 1], sc, st)); }
         }
     }
@@ -395,7 +396,7 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
               if (use_bf16_wgrad(h, l)) RC(launch_conv_wgrad_bf16(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd));
               else RC(launch_conv_wgrad(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd)); }
             { ProbeArm pa(h, 1, l);
-              if (use_bf16(h, l)) RC(launch_conv_dgrad_bf16(l, W, bf16_splits(h), B, ws + w.d_y[l], ws + w.wpack, ws + w.d_a[l - 1], ws + w.scratch, st));
+              if (use_bf16(h, l)) RC(launch_conv_dgrad_bf16(l, W, bf16_mode(h), B, ws + w.d_y[l], ws + w.wpack, ws + w.d_a[l - 1], ws + w.scratch, st));
               else RC(launch_conv_dgrad(l, W, B, ws + w.d_y[l], P_(h->enc_w[l]), nullptr, ws + w.d_a[l - 1], nullptr, st)); }
         }
         if (l == 3 || l == 0) RC(join());               // end of phase 1 / phase 2

@@ -33,6 +33,7 @@ struct ConvBf16Args {
     int64_t sliceFloats;    // KSPLIT > 1: out = slab [KSPLIT][sliceFloats]
     const float* aux;       // MODE_UP_DGRAD: forward output of the producing layer (ReLU mask), layout of `out`
     int64_t splitStride;    // NS == 3: units between the hi / mid / lo copies of the packed weights
+    int products;           // NS == 3: 9 (all partial products) or 6
 };
 
 // Exact 3-way bf16 split of an fp32 value: x == hi + mid + lo (each difference is exact in fp32, RNE
@@ -71,7 +72,7 @@ template <int H> struct Bf16Geom {
     static constexpr int PSP = ((Tile<H>::HP + 13) / 16) * 16 + 2;
 };
 
-template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT, int KS = 5, int MODE = MODE_STD, int NS = 1>
+template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT, int KS = 5, int MODE = MODE_STD, int NS = 1, int DMAX = 4>
 __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     using T = Tile<H>;
     static_assert(NS == 1 || NS == 3, "operand splits: 1 (bf16) or 3 (fp32 emulation, 9 MFMAs per product block)");
@@ -190,9 +191,10 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
                         bf16x8 bv[3];
 #pragma unroll
                         for (int sp = 0; sp < 3; ++sp) bv[sp] = bp[sp * W_UNITS + ((s * KB + kb) * 2) * NT + nb * 32];
-                        // nine exact partial products, smallest magnitudes first (0 = hi, 1 = mid, 2 = lo)
+                        // exact partial products, smallest magnitudes first (0 = hi, 1 = mid, 2 = lo); DMAX = 4: all
+                        // nine; DMAX = 2: the six of relative weight >= 2^-16 (drops mid*lo, lo*mid, lo*lo <= 3*2^-24)
 #pragma unroll
-                        for (int d = 4; d >= 0; --d)
+                        for (int d = DMAX; d >= 0; --d)
 #pragma unroll
                             for (int ia = 0; ia < 3; ++ia) {
                                 const int ib = d - ia;
@@ -319,14 +321,14 @@ int launch_pack_up_bf16(const float* const wc[3], float* packed, int ns, hipStre
     return 0;
 }
 
-template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT = 1, int KS = 5, int MODE = MODE_STD, int NS = 1>
+template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT = 1, int KS = 5, int MODE = MODE_STD, int NS = 1, int DMAX = 4>
 static int run_bf16_ns(const ConvBf16Args& a, hipStream_t st) {
     using T = Tile<H>;
     constexpr int KCB = NS == 3 ? 16 : (KCH < 64 ? KCH : 64);
     constexpr int STAGE = NS * ((KCB / 8) * Bf16Geom<H>::PSP + KS * (KCB / 16) * 2 * NT) * 16;
     constexpr int EPI_BYTES = (8 * NT > 4 * 32 * 36 ? 8 * NT : 4 * 32 * 36) * 4;
     constexpr int SMEM = STAGE > EPI_BYTES ? STAGE : EPI_BYTES;
-    auto kern = conv5x5_bf16_kernel<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, NS>;
+    auto kern = conv5x5_bf16_kernel<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, NS, DMAX>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -343,7 +345,8 @@ static int run_bf16_ns(const ConvBf16Args& a, hipStream_t st) {
 // a.splitStride != 0 selects the 3-split fp32-emulation instantiation
 template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT = 1, int KS = 5, int MODE = MODE_STD>
 static int run_bf16(const ConvBf16Args& a, hipStream_t st) {
-    if (a.splitStride) return run_bf16_ns<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, 3>(a, st);
+    if (a.splitStride && a.products == 6) return run_bf16_ns<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, 3, 2>(a, st);
+    if (a.splitStride) return run_bf16_ns<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, 3, 4>(a, st);
     return run_bf16_ns<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, 1>(a, st);
 }
 
@@ -351,7 +354,7 @@ bool conv_bf16_supported(int layer, int width) { return (width == 64 || width ==
 
 int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, const float* packed, const float* bias, float* out,
                          float* bnpart, float* ws, hipStream_t st) {
-    ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0, ns), bias, out, bnpart, B, 0, nullptr, ns == 3 ? pack_units(layer) : 0};
+    ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0, ns >= 3 ? 3 : 1), bias, out, bnpart, B, 0, nullptr, ns >= 3 ? pack_units(layer) : 0, ns == 6 ? 6 : 9};
     if (width == 64) {
         switch (layer) {
             case 1: return run_bf16<32, 64, 32, 64, EPI_BIAS_BNSTAT>(a, st);
@@ -378,7 +381,7 @@ int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, c
 }
 
 int launch_conv_dgrad_bf16(int layer, int width, int ns, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st) {
-    ConvBf16Args a{dout, pack_ptr(const_cast<float*>(packed), layer, 1, ns), nullptr, din, nullptr, B, 0, nullptr, ns == 3 ? pack_units(layer) : 0};
+    ConvBf16Args a{dout, pack_ptr(const_cast<float*>(packed), layer, 1, ns >= 3 ? 3 : 1), nullptr, din, nullptr, B, 0, nullptr, ns >= 3 ? pack_units(layer) : 0, ns == 6 ? 6 : 9};
     if (width == 64) {
         switch (layer) {
             case 1: return run_bf16<64, 32, 32, 32, EPI_PLAIN>(a, st);
@@ -407,7 +410,7 @@ int launch_conv_dgrad_bf16(int layer, int width, int ns, int B, const float* dou
 // Upsample(2)->Conv5x5 of D1..D3 (layers 5..7) on the bf16 MFMA: phase-collapsed 3x3 conv at the stored
 // low resolution (see conv_up.hip for the algebra); `in` = stored low-res activation (B,HS,HS,CIN).
 int launch_conv_up_fwd_bf16(int layer, int width, int ns, int B, const float* in, const float* packed, const float* bias, float* out, hipStream_t st) {
-    ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0, ns), bias, out, nullptr, B, 0, nullptr, ns == 3 ? pack_units(layer) : 0};
+    ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0, ns >= 3 ? 3 : 1), bias, out, nullptr, B, 0, nullptr, ns >= 3 ? pack_units(layer) : 0, ns == 6 ? 6 : 9};
     if (width == 64) {
         switch (layer) {
             case 5: return run_bf16<128, 256, 4, 64, EPI_PLAIN, 1, 3, MODE_UP_FWD>(a, st);
@@ -426,7 +429,7 @@ int launch_conv_up_fwd_bf16(int layer, int width, int ns, int B, const float* in
 }
 // d_in (B,HS,HS,CIN) = relu'(aux) * sum over phases/taps of dout (B,2HS,2HS,COUT)
 int launch_conv_up_dgrad_bf16(int layer, int width, int ns, int B, const float* dout, const float* packed, const float* aux, float* din, hipStream_t st) {
-    ConvBf16Args a{dout, pack_ptr(const_cast<float*>(packed), layer, 1, ns), nullptr, din, nullptr, B, 0, aux, ns == 3 ? pack_units(layer) : 0};
+    ConvBf16Args a{dout, pack_ptr(const_cast<float*>(packed), layer, 1, ns >= 3 ? 3 : 1), nullptr, din, nullptr, B, 0, aux, ns >= 3 ? pack_units(layer) : 0, ns == 6 ? 6 : 9};
     if (width == 64) {
         switch (layer) {
             case 5: return run_bf16<256, 128, 4, 32, EPI_PLAIN, 1, 3, MODE_UP_DGRAD>(a, st);

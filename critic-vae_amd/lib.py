@@ -108,7 +108,7 @@ def _stream():
 class Handle:
     """Opaque library handle + the flat-parameter layout it reports."""
 
-    PRECISIONS = {"f32": 0, "bf16": 1, "bf16x9": 2}
+    PRECISIONS = {"f32": 0, "bf16": 1, "bf16x9": 2, "bf16x6": 3}
 
     def __init__(self, width=64, max_batch=256, overlap_wgrad=False, precision="f32"):
         """precision "f32": every contraction on the exact-fp32 MFMA (the 1e-4 parity path).
@@ -116,7 +116,8 @@ class Handle:
         fp32 tensors in HBM; BASELINE.json configs 3-5).
         "bf16x9": fp32 emulation — forward / input-gradient convs on the bf16 MFMA with both operands split
         exactly into three bf16 parts (nine exact partial products per fp32 product, fp32 accumulate);
-        weight gradients on the fp32 MFMA.  Meets the same 1e-4 parity bar as "f32"."""
+        weight gradients on the fp32 MFMA.  Meets the same 1e-4 parity bar as "f32".
+        "bf16x6": as "bf16x9" with the six leading partial products (drops <= 3*2^-24 of each product)."""
         self.lib = load()
         if precision not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")

@@ -37,8 +37,8 @@ typedef struct cvae_config {
     int32_t precision;    /* precision: 0 = fp32 everywhere (the 1e-4-parity path); 1 = bf16-MFMA contractions
                            * (fp32 accumulate, fp32 tensors and master weights in HBM) for every pass of the convs
                            * E2..E4 and D0..D3 (BASELINE.json configs 3-5); 2 = fp32 emulation: forward/dgrad of E2..E4 and D0 on
-                           * the bf16 MFMA with exact 3-way bf16 operand splits (9 MFMAs per block), everything else as 0;
-                           * other values are rejected */
+                           * the bf16 MFMA with exact 3-way bf16 operand splits (9 MFMAs per block), everything else as 0; 3 = as 2 with the six leading
+                           * partial products only; other values are rejected */
 } cvae_config;
 
 enum { CVAE_OK = 0, CVAE_EINVAL = -1, CVAE_EUNSUPPORTED = -2, CVAE_ENOWS = -3 };

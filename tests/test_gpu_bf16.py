@@ -110,10 +110,12 @@ def test_bf16_inference_path_matches_fp32_mode():
     assert (outs["bf16"][1] - outs["f32"][1]).abs().max() < 3e-2
 
 
+@pytest.mark.parametrize("mode", ["bf16x9", "bf16x6"])
 @pytest.mark.parametrize("B", [4, 32])
-def test_bf16x9_emulation_meets_the_fp32_parity_bar(B):
+def test_bf16x9_emulation_meets_the_fp32_parity_bar(B, mode):
     """precision="bf16x9": operands split exactly into three bf16 parts, nine exact partial products per
-    fp32 product -> only the summation order differs from fp32.  Held to the fp32 bar of
+    fp32 product -> only the summation order differs from fp32 ("bf16x6" keeps the six leading products and
+    drops three terms of relative size <= 2^-24 each — the size of one fp32 rounding).  Held to the fp32 bar of
     tests/test_gpu_step.py: 1e-4 absolute everywhere; relative to each gradient tensor's max 5e-3 (the fp32
     test allows 1e-3 for ReLU / max-pool decisions that flip within an ulp of zero; another summation
     order flips a few other elements — measured worst case 3.9e-3 = 2.1e-6 absolute on enc2.weight)."""
@@ -124,12 +126,12 @@ def test_bf16x9_emulation_meets_the_fp32_parity_bar(B):
     params, (x, pred, eps), p, out = _oracle_step(B)
     xs, ps, es = (torch.from_numpy(v).to(dev) for v in (x, pred, eps))
     res = {}
-    for prec in ("bf16x9", "f32"):
+    for prec in (mode, "f32"):
         vae = VariationalAutoencoder(max_batch=B, seed=0, precision=prec).to(dev)
         tr = FusedTrainer(vae)
         scal = tr.step(xs, ps, es).cpu()
         res[prec] = (tr.mu[:B].cpu(), tr.recon[:B].cpu(), float(scal[0]), L.native_to_ref(vae.handle.layout, tr.grads.cpu()))
-    mu, recon, loss, got = res["bf16x9"]
+    mu, recon, loss, got = res[mode]
     assert (mu - out["mu"].detach()).abs().max() < 1e-4
     assert (recon - out["recon"].detach()).abs().max() < 1e-4
     assert abs(loss - float(out["total_loss"].detach())) < 1e-4

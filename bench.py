@@ -102,8 +102,8 @@ def cpu_baseline(B, steps=5, width=64):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE.json configs[1])")
     ap.add_argument("--width", type=int, choices=[64, 128], default=64, help="frame size (128: BASELINE configs[4] shape)")
     ap.add_argument("--precision", choices=["f32", "bf16", "bf16x9", "bf16x6"], default="f32",
@@ -194,7 +194,8 @@ def main():
                                f"batch {B}/GPU, {Wd}x{Wd}x3 frames + critic scalars", "global_batch": world * B,
                    "frame": f"{Wd}x{Wd}x3", "parallelism": f"dp{world}", "optimizer": "fused flat Adam",
                    "grad_allreduce": ("3 buckets overlapped with backward" if tr.overlap else "single, after backward") if world > 1 else "none",
-                   "final_loss": loss, "loss_finite": bool(loss == loss and abs(loss) != float("inf"))},
+                   "final_loss": loss, "loss_finite": bool(loss == loss and abs(loss) != float("inf")),
+                   },
     }
     if rank == 0 and world == 1:
         res["config"]["whole_step_algorithmic_TFLOPs"] = round(B * args.steps / dt * FLOP_PER_IMG[Wd] / 1e12, 2)
@@ -225,6 +226,24 @@ def main():
                     "algorithmic_bytes_per_launch": by}
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(B, width=Wd)
+    # SURVEY 8d also asks for the C-ABI path proper (forward + loss + backward, no all-reduce / optimizer)
+    fb_steps = max(5, args.steps // 4)
+    x0, p0, e0 = pool[0]
+    theta = vae.theta.data
+
+    def fwd_loss_bwd():
+        H.forward(B, x0, p0, e0, theta, vae.bn_state, tr.mu, tr.logvar, tr.recon, tr.ws, train=True)
+        H.loss(B, x0, tr.mu, tr.logvar, tr.recon, tr.ws, tr.scalars, tr.d_recon, tr.d_mu, tr.d_logvar)
+        H.backward(B, x0, p0, e0, theta, tr.logvar, tr.recon, tr.d_recon, tr.d_mu, tr.d_logvar, tr.ws, tr.grads)
+
+    fwd_loss_bwd()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(fb_steps):
+        fwd_loss_bwd()
+    torch.cuda.synchronize()
+    res["config"]["fwd_loss_bwd_only_images_per_s_per_gpu"] = round(B * fb_steps / (time.perf_counter() - t1), 1)
+
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

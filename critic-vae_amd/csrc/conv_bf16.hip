@@ -126,15 +126,19 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
             }
         }
     };
-    // input halo chunk: fp32 NHWC -> bf16 units [octet][halo pixel]
-    auto stage_input = [&](int cc) {
-        constexpr int NQ = T::HP * OCT;
-        for (int q = tid; q < NQ; q += 256) {
+    // input halo chunk: fp32 NHWC -> registers (one chunk ahead, in flight during the MFMAs of the
+    // current chunk) -> bf16 units [octet][halo pixel] (split into hi/mid/lo planes when NS == 3)
+    constexpr int NQ = T::HP * OCT, IPT = (NQ + 255) / 256;
+    f32x4 ireg[2 * IPT];
+    auto load_input = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int q = tid + i * 256;
             const int oct = q % OCT, hp = q / OCT;
             const int img = hp / T::HPI, rem = hp - img * T::HPI;
             const int gy = ty0 + rem / T::HTW - 2, gx = tx0 + rem % T::HTW - 2, ib = img0 + img;
             f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B) {
+            if ((NQ % 256 == 0 || q < NQ) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B) {
                 const float* src;
                 if (MODE == MODE_UP_DGRAD) {        // channel k = p*COUT + co of the low-res view = dout[2y+py][2x+px][co]
                     const int k0 = cc * KCB + oct * 8, p = k0 / COUT_UP, co = k0 % COUT_UP;
@@ -145,6 +149,16 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
                 lo = *reinterpret_cast<const f32x4*>(src);
                 hi = *reinterpret_cast<const f32x4*>(src + 4);
             }
+            ireg[2 * i] = lo; ireg[2 * i + 1] = hi;
+        }
+    };
+    auto store_input = [&]() {
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int q = tid + i * 256;
+            if (!(NQ % 256 == 0 || q < NQ)) continue;
+            const int oct = q % OCT, hp = q / OCT;
+            const f32x4 lo = ireg[2 * i], hi = ireg[2 * i + 1];
             if (NS == 1) {
                 lds_a[oct * PSP + hp] = to_bf16x8(lo, hi);
             } else {
@@ -164,11 +178,15 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     constexpr int NST = (KCH / KCB) / KSPLIT * KS;
     const int st0 = blockIdx.z * NST, st1 = st0 + NST;
     load_w(st0);
+    load_input(st0 / KS);
     for (int st = st0; st < st1; ++st) {
         const int r = st % KS;
         __syncthreads();                       // everyone finished reading the previous stage
-        if (r == 0) stage_input(st / KS);
+        if (r == 0) store_input();
         store_w();
+        // issue order: vmcnt retires in order, so the (older) halo loads must not sit between a weight
+        // load and the store_w that waits for it (see conv_mfma.hip)
+        if (r == 0 && st + KS < st1) load_input(st / KS + 1);
         if (st + 1 < st1) load_w(st + 1);      // in flight while this stage computes
         __syncthreads();
         const bf16x8* ap = lds_a + lh * PSP + aPix + (r + OFF) * T::HTW + OFF;

@@ -333,8 +333,8 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
     const int W = h->cfg.width;
     float* sc = ws + w.scratch;
     float* scw = ws + w.scratch_w;
-    // cfg.overlap_wgrad != 0: weight-gradient work on a lower-priority side stream (+3% at B=256, but
-    // per-kernel timings then overlap); default: everything in order on the caller's stream.
+    // cfg.overlap_wgrad != 0: weight-gradient work on a lower-priority side stream (+3% with the early kernels,
+    // -1.5% with the current ones); default: everything in order on the caller's stream.
     const bool overlap = h->cfg.overlap_wgrad != 0;
     if (overlap) RC(ensure_streams(h));
     hipStream_t sd = overlap ? h->side : st;

@@ -111,6 +111,7 @@ def main():
                          "convs (configs[2]: use with --batch 2048)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--no-fwd-bwd-rate", action="store_true", help="skip the extra forward+loss+backward-only loop (profiling runs)")
     args = ap.parse_args()
 
     from critic_vae_amd import dp
@@ -227,7 +228,7 @@ def main():
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(B, width=Wd)
     # SURVEY 8d also asks for the C-ABI path proper (forward + loss + backward, no all-reduce / optimizer)
-    fb_steps = max(5, args.steps // 4)
+    fb_steps = 0 if args.no_fwd_bwd_rate else max(5, args.steps // 4)
     x0, p0, e0 = pool[0]
     theta = vae.theta.data
 
@@ -236,13 +237,14 @@ def main():
         H.loss(B, x0, tr.mu, tr.logvar, tr.recon, tr.ws, tr.scalars, tr.d_recon, tr.d_mu, tr.d_logvar)
         H.backward(B, x0, p0, e0, theta, tr.logvar, tr.recon, tr.d_recon, tr.d_mu, tr.d_logvar, tr.ws, tr.grads)
 
-    fwd_loss_bwd()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(fb_steps):
+    if fb_steps:
         fwd_loss_bwd()
-    torch.cuda.synchronize()
-    res["config"]["fwd_loss_bwd_only_images_per_s_per_gpu"] = round(B * fb_steps / (time.perf_counter() - t1), 1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(fb_steps):
+            fwd_loss_bwd()
+        torch.cuda.synchronize()
+        res["config"]["fwd_loss_bwd_only_images_per_s_per_gpu"] = round(B * fb_steps / (time.perf_counter() - t1), 1)
 
     if rank == 0:
         print(json.dumps(res), flush=True)

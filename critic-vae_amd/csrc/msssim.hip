@@ -47,6 +47,27 @@ template <int S, int NMAP>
 __device__ __forceinline__ void ms_load(const float* const (&src)[NMAP], float* dst, int plane0, int P, int r0) {
     using G = MsGeom<S>;
     constexpr int PER = G::PPB * G::HR * G::HC;
+    if constexpr (S >= 32) {          // one plane per workgroup: 16-byte row loads of the interior + zeroed 5-column borders
+        constexpr int C4 = S / 4;
+        const bool plane_ok = plane0 < P;
+        for (int q = threadIdx.x; q < G::HR * C4; q += 256) {
+            const int rr = q / C4, c = (q % C4) * 4, r = r0 - 5 + rr;
+            const bool ok = plane_ok && (unsigned)r < (unsigned)S;
+#pragma unroll
+            for (int mI = 0; mI < NMAP; ++mI) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) v = *reinterpret_cast<const f32x4*>(src[mI] + ((size_t)plane0 * S + r) * S + c);
+                float* d = dst + mI * PER + rr * G::HC + 5 + c;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        }
+        for (int q = threadIdx.x; q < G::HR * 10; q += 256) {
+            const int rr = q / 10, k = q % 10, col = k < 5 ? k : S + k;       // columns 0..4 and S+5..S+9
+#pragma unroll
+            for (int mI = 0; mI < NMAP; ++mI) dst[mI * PER + rr * G::HC + col] = 0.f;
+        }
+        return;
+    }
     for (int q = threadIdx.x; q < PER; q += 256) {
         const int pl = q / (G::HR * G::HC), rem = q % (G::HR * G::HC);
         const int r = r0 - 5 + rem / G::HC, c = rem % G::HC - 5;

@@ -176,21 +176,25 @@ __global__ __launch_bounds__(256) void decin_bwd_dz_kernel(const float* __restri
 // slab[bs][i][j] (i<33: dWd, i==33: dbd) = sum over the batch slice bs
 __global__ __launch_bounds__(256) void decin_bwd_dw_kernel(const float* __restrict__ zcat, const float* __restrict__ dh,
                                                            float* __restrict__ slab, int B, int K, int bPerSplit) {
-    __shared__ float z[33];
+    constexpr int ZB = 16;                          // batch rows staged per barrier pair
+    __shared__ float z[ZB * 33];
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int b0 = blockIdx.y * bPerSplit;
     int b1 = b0 + bPerSplit; if (b1 > B) b1 = B;
     float acc[34];
 #pragma unroll
     for (int i = 0; i < 34; ++i) acc[i] = 0.f;
-    for (int b = b0; b < b1; ++b) {
+    for (int bb = b0; bb < b1; bb += ZB) {
+        const int nb = b1 - bb < ZB ? b1 - bb : ZB;
         __syncthreads();
-        if (threadIdx.x < 33) z[threadIdx.x] = zcat[b * 33 + threadIdx.x];
+        for (int q = threadIdx.x; q < nb * 33; q += 256) z[q] = zcat[bb * 33 + q];
         __syncthreads();
-        const float g = dh[(size_t)b * K + j];
+        for (int r = 0; r < nb; ++r) {
+            const float g = dh[(size_t)(bb + r) * K + j];
 #pragma unroll
-        for (int i = 0; i < 33; ++i) acc[i] = fmaf(z[i], g, acc[i]);
-        acc[33] += g;
+            for (int i = 0; i < 33; ++i) acc[i] = fmaf(z[r * 33 + i], g, acc[i]);
+            acc[33] += g;
+        }
     }
     float* o = slab + (size_t)blockIdx.y * 34 * K;
 #pragma unroll
@@ -231,14 +235,20 @@ __global__ __launch_bounds__(256) void fc_bwd_dflat_kernel(const float* __restri
     }
 }
 
-// dWfc[k][n] = sum_b flat[b][k] * dml[b][n]    (4 k-rows per workgroup, all of the batch)
+// dWfc[k][n] = sum_b flat[b][k] * dml[b][n]    (16 k-rows per workgroup: each wave 4 rows x 64 columns, all of
+// the batch; the four flat values of a row group are one 16-byte wave-uniform load per image)
 __global__ __launch_bounds__(256) void fc_bwd_dw_kernel(const float* __restrict__ flat, const float* __restrict__ dml,
                                                         float* __restrict__ dwfc, int B, int K) {
-    const int n = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    float acc = 0.f;
+    const int n = threadIdx.x & 63, k = blockIdx.x * 16 + (threadIdx.x >> 6) * 4;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll 8
-    for (int b = 0; b < B; ++b) acc = fmaf(flat[(size_t)b * K + k], dml[(size_t)b * 64 + n], acc);
-    dwfc[(size_t)k * 64 + n] = acc;
+    for (int b = 0; b < B; ++b) {
+        const f32x4 f = *reinterpret_cast<const f32x4*>(flat + (size_t)b * K + k);
+        const float d = dml[(size_t)b * 64 + n];
+        a0 = fmaf(f.x, d, a0); a1 = fmaf(f.y, d, a1); a2 = fmaf(f.z, d, a2); a3 = fmaf(f.w, d, a3);
+    }
+    dwfc[(size_t)k * 64 + n] = a0; dwfc[(size_t)(k + 1) * 64 + n] = a1;
+    dwfc[(size_t)(k + 2) * 64 + n] = a2; dwfc[(size_t)(k + 3) * 64 + n] = a3;
 }
 
 static inline int bott(int width) { return 256 * (width / 16) * (width / 16); }
@@ -297,7 +307,7 @@ int launch_fc_bwd(int width, int B, const float* flat, const float* wfc, const f
     if (rc) return rc;
     hipLaunchKernelGGL(fc_bwd_dflat_kernel, dim3(cdiv(B, 8), K / 256), dim3(256), 0, st, dml, wfc, dflat, B, K);
     CVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(fc_bwd_dw_kernel, dim3(K / 4), dim3(256), 0, st, flat, dml, dwfc, B, K);
+    hipLaunchKernelGGL(fc_bwd_dw_kernel, dim3(K / 16), dim3(256), 0, st, flat, dml, dwfc, B, K);
     CVAE_CHECK_LAUNCH();
     return 0;
 }

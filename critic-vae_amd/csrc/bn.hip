@@ -235,13 +235,16 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_relu_kernel(const float* __r
 
 // rows[r] = [sum g | sum g*xhat] partials (R <= 64 rows left by launch_col_reduce_partial), summed
 // here in fixed order -> dgamma, dbeta, bcoef = (s1/N, s2/N)
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ rows, int R, int64_t stride, int C, float invN,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ bcoef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ rows, int R, int64_t stride, int C, float invN,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ bcoef) {
+    // 16 lanes per channel: lane q adds rows q, q+16, q+32, q+48, then a fixed xor-shuffle tree
+    const int c = blockIdx.x * 16 + (threadIdx.x >> 4), q = threadIdx.x & 15;
     float s1 = 0.f, s2 = 0.f;
-    for (int r = 0; r < R; ++r) { s1 += rows[(size_t)r * stride + c]; s2 += rows[(size_t)r * stride + C + c]; }
-    dgamma[c] = s2; dbeta[c] = s1; bcoef[c * 2] = s1 * invN; bcoef[c * 2 + 1] = s2 * invN;
+    if (c < C)
+        for (int r = q; r < R; r += 16) { s1 += rows[(size_t)r * stride + c]; s2 += rows[(size_t)r * stride + C + c]; }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (c < C && q == 0) { dgamma[c] = s2; dbeta[c] = s1; bcoef[c * 2] = s1 * invN; bcoef[c * 2 + 1] = s2 * invN; }
 }
 
 static constexpr int BN_RA = 32;
@@ -309,7 +312,7 @@ int launch_bn_pool_act_bwd(int layer, int width, int B, const float* y, const fl
     CVAE_CHECK_LAUNCH();
     const float* rows; int R; int64_t rstride;
     { int rc = launch_col_reduce_partial(part, nblk, 2 * g.C, 2 * g.C, crws, st, &rows, &R, &rstride); if (rc) return rc; }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(g.C, 64)), dim3(64), 0, st, rows, R, rstride, g.C, invN, dgamma, dbeta, bcoef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(g.C, 16)), dim3(256), 0, st, rows, R, rstride, g.C, invN, dgamma, dbeta, bcoef);
     CVAE_CHECK_LAUNCH();
     cvae_probe_begin(st);                       // the apply pass: reads y, a, da, writes dy — the step's largest HBM-bound kernel
     if (g.act) hipLaunchKernelGGL((bn_bwd_kernel<1, 1>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, bcoef, dy, part, g.C, g.H, totalPx, ppb);

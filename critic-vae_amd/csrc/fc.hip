@@ -76,7 +76,12 @@ __global__ __launch_bounds__(256) void decin_dz_finish_kernel(const float* __res
     if (idx >= B * 33) return;
     const int b = idx / 33, i = idx % 33;
     float acc = 0.f;
-    for (int ks = 0; ks < KS; ++ks) acc += slab[((size_t)ks * B + b) * 64 + i];
+    if (KS == FC_KS) {                      // the split count the launchers use: all loads in flight at once
+#pragma unroll
+        for (int ks = 0; ks < FC_KS; ++ks) acc += slab[((size_t)ks * B + b) * 64 + i];
+    } else {
+        for (int ks = 0; ks < KS; ++ks) acc += slab[((size_t)ks * B + b) * 64 + i];
+    }
     dzcat[idx] = acc;
 }
 

@@ -271,7 +271,11 @@ int cvae_decode(cvae_handle h, int32_t B, const float* zcat, const float* params
     }
     RC(launch_decin_fwd(W, B, ws + w.zcat, P_(h->di_w), P_(h->di_b), ws + w.h, st));
     // Upsample -> Conv of D1..D3 runs at the low resolution with phase-collapsed weights (conv_up.hip)
-    for (int i = 1; i < 4; ++i) RC(launch_collapse_w(4 + i, P_(h->dec_w[i]), ws + w.wc[i - 1], st));
+    {
+        const float* wsrc[3] = {P_(h->dec_w[1]), P_(h->dec_w[2]), P_(h->dec_w[3])};
+        float* wdst[3] = {ws + w.wc[0], ws + w.wc[1], ws + w.wc[2]};
+        RC(launch_collapse_w3(wsrc, wdst, st));
+    }
     if (use_bf16(h, 5)) {
         const float* wcs[3] = {ws + w.wc[0], ws + w.wc[1], ws + w.wc[2]};
         RC(launch_pack_up_bf16(wcs, ws + w.wpack, bf16_splits(h), st));

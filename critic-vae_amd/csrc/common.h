@@ -113,6 +113,7 @@ int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const
 // conv_up.hip (phase-collapsed Upsample->Conv blocks D1..D3, layers 5..7)
 int64_t conv_up_wc_floats(int layer);
 int launch_collapse_w(int layer, const float* w, float* wc, hipStream_t st);
+int launch_collapse_w3(const float* const w[3], float* const wc[3], hipStream_t st);     // D1..D3 in one launch
 int64_t conv_up_ws_floats(int layer, int width, int B);
 int launch_conv_up_fwd(int layer, int width, int B, const float* in, const float* wc, const float* bias,
                        float* out, float* ws, hipStream_t st);

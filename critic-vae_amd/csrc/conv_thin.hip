@@ -233,8 +233,20 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
     thin_slab_out(acc, smem, a.slab + (size_t)blockIdx.x * 96 * 32, bsum, true);
 }
 
-// dst (W4 [tap][ci][co]) <- reduced slab row (k = tap*3+co, col ci)
-__global__ __launch_bounds__(256) void d4_perm_kernel(const float* __restrict__ red, float* __restrict__ dst) {
+// dst (W4 [tap][ci][co]) <- reduced slab row (k = tap*3+co, col ci); the last workgroup also sums the
+// per-plane dOut sums into the three bias gradients (one launch instead of two)
+__global__ __launch_bounds__(256) void d4_perm_kernel(const float* __restrict__ red, float* __restrict__ dst,
+                                                      const float* __restrict__ part, float* __restrict__ db, int B) {
+    if (blockIdx.x == gridDim.x - 1) {
+        const int co = threadIdx.x >> 6, lane = threadIdx.x & 63;      // waves 0..2 = the three output channels
+        if (co < 3) {
+            float acc = 0.f;
+            for (int b = lane; b < B; b += 64) acc += part[b * 3 + co];
+            acc = wave_sum(acc);
+            if (lane == 0) db[co] = acc;
+        }
+        return;
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= 2400) return;
     const int co = i % 3, ci = (i / 3) % 32, tap = i / 96;
@@ -386,14 +398,6 @@ __global__ __launch_bounds__(256) void d4_actbwd_kernel(const float* __restrict_
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-}
-
-__global__ void d4_dbias_kernel(const float* __restrict__ part, float* __restrict__ db, int B) {
-    const int co = threadIdx.x >> 6, lane = threadIdx.x & 63;      // 3 waves
-    float acc = 0.f;
-    for (int b = lane; b < B; b += 64) acc += part[b * 3 + co];
-    acc = wave_sum(acc);
-    if (lane == 0) db[co] = acc;
 }
 
 // tile mt of the D4 backward into registers: dOut halo planes [3][20][36] (zero padded) and the o3 tile
@@ -559,9 +563,7 @@ int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const
     CVAE_CHECK_LAUNCH();
     float* red = plane_sums + align_up((int64_t)B * 3, 64);
     { int rc = launch_col_reduce(ws, S, 3072, 3072, red, red + 3072, st); if (rc) return rc; }
-    hipLaunchKernelGGL(d4_perm_kernel, dim3(cdiv(2400, 256)), dim3(256), 0, st, red, dw);
-    CVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(d4_dbias_kernel, dim3(1), dim3(192), 0, st, plane_sums, db, B);
+    hipLaunchKernelGGL(d4_perm_kernel, dim3(cdiv(2400, 256) + 1), dim3(256), 0, st, red, dw, plane_sums, db, B);
     CVAE_CHECK_LAUNCH();
     return 0;
 }

@@ -35,8 +35,13 @@ __device__ __forceinline__ int phase_lo(int ph, int a) { return ph == 0 ? (a == 
 __device__ __forceinline__ int phase_hi(int ph, int a) { return ph == 0 ? (a == 0 ? 1 : a == 1 ? 3 : 4) : (a == 0 ? 0 : a == 1 ? 2 : 4); }
 __device__ __forceinline__ int phase_of(int ph, int r) { return ph == 0 ? (r >> 1) : ((r + 1) >> 1); }   // a(py, r)
 
-// wc[((py*2+px)*9 + a*3+b)*n + i] = sum W[(r*5+s)*n + i],  n = Cin*Cout
-__global__ __launch_bounds__(256) void collapse_w_kernel(const float* __restrict__ w, float* __restrict__ wc, int n) {
+// wc[((py*2+px)*9 + a*3+b)*n + i] = sum W[(r*5+s)*n + i],  n = Cin*Cout; blockIdx.z selects one of up to
+// three layers so that D1..D3 collapse in ONE launch
+struct CollapseJobs { const float* w[3]; float* wc[3]; int n[3]; };
+__global__ __launch_bounds__(256) void collapse_w_kernel(CollapseJobs jobs) {
+    const float* __restrict__ w = jobs.w[blockIdx.z];
+    float* __restrict__ wc = jobs.wc[blockIdx.z];
+    const int n = jobs.n[blockIdx.z];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int t = blockIdx.y, p = t / 9, a = (t % 9) / 3, b = t % 3, py = p >> 1, px = p & 1;
@@ -458,7 +463,20 @@ int64_t conv_up_wc_floats(int layer) { return (int64_t)36 * kLayers[layer].cin *
 
 int launch_collapse_w(int layer, const float* w, float* wc, hipStream_t st) {
     const int n = kLayers[layer].cin * kLayers[layer].cout;
-    hipLaunchKernelGGL(collapse_w_kernel, dim3(cdiv(n, 256), 36), dim3(256), 0, st, w, wc, n);
+    CollapseJobs jobs{{w, nullptr, nullptr}, {wc, nullptr, nullptr}, {n, 0, 0}};
+    hipLaunchKernelGGL(collapse_w_kernel, dim3(cdiv(n, 256), 36, 1), dim3(256), 0, st, jobs);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}
+// D1..D3 (layers 5..7) in one launch
+int launch_collapse_w3(const float* const w[3], float* const wc[3], hipStream_t st) {
+    CollapseJobs jobs;
+    int nmax = 0;
+    for (int i = 0; i < 3; ++i) {
+        jobs.w[i] = w[i]; jobs.wc[i] = wc[i]; jobs.n[i] = kLayers[5 + i].cin * kLayers[5 + i].cout;
+        if (jobs.n[i] > nmax) nmax = jobs.n[i];
+    }
+    hipLaunchKernelGGL(collapse_w_kernel, dim3(cdiv(nmax, 256), 36, 3), dim3(256), 0, st, jobs);
     CVAE_CHECK_LAUNCH();
     return 0;
 }

@@ -182,18 +182,39 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     *reinterpret_cast<float4*>(dst + (size_t)blockIdx.y * n + i) = acc;
 }
 
-// `slab`, `stride` and n must keep 16-byte alignment (n % 4 == 0).  When S > 32 a first pass
-// reduces 16 row-chunks into `mid` (16*n floats), a second pass sums those.
+// One launch for many slabs: a workgroup owns 16 consecutive float4 outputs; its 16 thread groups add
+// disjoint row sets (rows g, g+16, ..) and an LDS pass adds the 16 group sums in fixed order.
+__global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __restrict__ slab, float* __restrict__ dst,
+                                                                int64_t n4, int S, int64_t stride) {
+    __shared__ f32x4 red[16][16];
+    const int oi = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int64_t o = (int64_t)blockIdx.x * 16 + oi;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (o < n4) {
+#pragma unroll 4
+        for (int r = g; r < S; r += 16) acc += *reinterpret_cast<const f32x4*>(slab + (size_t)r * stride + o * 4);
+    }
+    red[g][oi] = acc;
+    __syncthreads();
+    if (g == 0 && o < n4) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) acc += red[k][oi];
+        *reinterpret_cast<f32x4*>(dst + o * 4) = acc;
+    }
+}
+
+// `slab`, `stride` and n must keep 16-byte alignment (n % 4 == 0).  S <= 32: one thread per output adds
+// all rows; larger S: the wide kernel above (`mid` is kept in the signature for callers that size it,
+// it is no longer written).
 int launch_reduce_slabs(const float* slab, float* dst, int64_t n, int S, int64_t stride, hipStream_t st, float* mid) {
-    const unsigned gx = (unsigned)((n / 4 + 255) / 256);
-    if (mid != nullptr && S > 32) {
-        const int RA = 16, per = cdiv(S, RA), ra = cdiv(S, per);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, ra), dim3(256), 0, st, slab, mid, n, S, stride, per);
-        CVAE_CHECK_LAUNCH();
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, 1), dim3(256), 0, st, mid, dst, n, ra, n, ra);
+    (void)mid;
+    if (S > 32) {
+        const int64_t n4 = n / 4;
+        hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, slab, dst, n4, S, stride);
         CVAE_CHECK_LAUNCH();
         return 0;
     }
+    const unsigned gx = (unsigned)((n / 4 + 255) / 256);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, 1), dim3(256), 0, st, slab, dst, n, S, stride, S);
     CVAE_CHECK_LAUNCH();
     return 0;

@@ -47,3 +47,13 @@ def test_phased_backward_equals_single_call():
         covered[off:off + n] = True
     assert covered.all()
     assert torch.equal(tr.grads[used], whole[used])
+
+
+def test_bucketed_allreduce_path_on_rccl_single_rank():
+    """The exact N>1 code path (phased backward, async all_reduce per bucket, wait, Adam with 1/N) on
+    the real nccl (= RCCL) backend with one rank."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_nccl_worker.py")], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "DP_NCCL_OK" in r.stdout

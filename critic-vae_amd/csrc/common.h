@@ -34,6 +34,12 @@ struct Tile {
 };
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Workgroups are dealt to the 8 XCDs round-robin by linear id, and every XCD has its own L2.  Map
+// workgroup x of a grid of G (G % 8 == 0) to tile (x % 8) * (G / 8) + x / 8: each XCD then owns a
+// contiguous range of tiles — neighbouring tiles share their halo rows in ONE L2, and the workgroups of
+// the other output-channel tiles (blockIdx.y) that re-read the same input tile sit on the same XCD.
+__device__ __forceinline__ int xcd_tile(int x, int G) { return (G & 7) ? x : (x & 7) * (G >> 3) + (x >> 3); }
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     bf16x8* lds_w = lds_a + NS * A_UNITS;                      // [split][tap][kb][half][n]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int mt = blockIdx.x, n0 = blockIdx.y * NT;
+    const int mt = xcd_tile(blockIdx.x, gridDim.x), n0 = blockIdx.y * NT;
     const int tileInImg = mt % T::TILES_PER_IMG, img0 = (mt / T::TILES_PER_IMG) * T::IMGS;
     const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;
     const int m = wave * 32 + li;

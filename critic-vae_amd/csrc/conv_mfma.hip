@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int mt = blockIdx.x, n0 = blockIdx.y * NT;
+    const int mt = xcd_tile(blockIdx.x, gridDim.x), n0 = blockIdx.y * NT;
     const int tileInImg = mt % T::TILES_PER_IMG;
     const int img0 = (mt / T::TILES_PER_IMG) * T::IMGS;
     const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;

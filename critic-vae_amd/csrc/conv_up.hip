@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void conv_up_fwd_kernel(UpArgs a) {
     float* lds_in = smem;
     float* lds_w = smem + IN_FLOATS;           // [phase*3+b][kc][n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int mt = blockIdx.x, n0 = blockIdx.y * NT;
+    const int mt = xcd_tile(blockIdx.x, gridDim.x), n0 = blockIdx.y * NT;
     const int tileInImg = mt % T::TILES_PER_IMG, img0 = (mt / T::TILES_PER_IMG) * T::IMGS;
     const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;
     const int m = wave * 32 + li;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_up_dgrad_kernel(UpArgs a) {
     float* lds_in = smem;
     float* lds_w = smem + IN_FLOATS;           // [tap][n][KCP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int mt = blockIdx.x, n0 = blockIdx.y * NT;
+    const int mt = xcd_tile(blockIdx.x, gridDim.x), n0 = blockIdx.y * NT;
     const int tileInImg = mt % T::TILES_PER_IMG, img0 = (mt / T::TILES_PER_IMG) * T::IMGS;
     const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;
     const int m = wave * 32 + li;

@@ -6,6 +6,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));     // one v_mfma_f32_32x32x16_bf16 operand fragment
 
 #define CVAE_LATENT 32
 #define CVAE_ZCAT 33
@@ -106,9 +107,9 @@ int launch_col_reduce_partial(const float* in, int R, int W, int64_t stride, flo
 int launch_col_reduce(const float* in, int R, int W, int64_t stride, float* out, float* ws, hipStream_t st);
 // conv_thin.hip (E1 / D4)
 int launch_e1_fwd(int width, int B, const float* x, const float* w, const float* bias, float* y,
-                  float* bnpart, hipStream_t st);
+                  float* bnpart, hipStream_t st, bool bf16 = false);
 int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw, float* dbias, float* ws,
-                    hipStream_t st);
+                    hipStream_t st, bool bf16 = false);
 int64_t e1_wgrad_ws_floats(int width, int B);
 int launch_d4_fwd(int width, int B, const float* in, const float* w, const float* bias, float* recon,
                   hipStream_t st);

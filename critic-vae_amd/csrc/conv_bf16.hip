@@ -21,7 +21,6 @@
 #include "common.h"
 #include "conv_epilogue.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct ConvBf16Args {
     const float* in;        // fp32 NHWC, KCH channels

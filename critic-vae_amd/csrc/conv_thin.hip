@@ -24,7 +24,10 @@ __device__ __forceinline__ constexpr int e1_off(int k) {
 // (four 32-pixel accumulator tiles).  The whole B operand (76 x 32 weights) lives in 38 registers per
 // lane, read once from global; the x halo (3 planes) is staged once per strip.  Epilogue: bias,
 // NHWC store, and the strip's BatchNorm partial (sum, M2 about the strip mean).
-template <int H>
+// BF16 (precision mode 1): the same kernel with the contraction on v_mfma_f32_32x32x16_bf16 — the lane gathers
+// its 8 consecutive k = (tap, channel) values from the fp32 planes and rounds them to bf16 (K = 75 padded to
+// 80: 5 MFMAs per 32 pixels instead of 38), which leaves the kernel bound by the y1 store.
+template <int H, bool BF16 = false>
 __global__ __launch_bounds__(256) void e1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ y,
                                                      float* __restrict__ bnpart, int B) {
@@ -36,9 +39,20 @@ __global__ __launch_bounds__(256) void e1_fwd_kernel(const float* __restrict__ x
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int ib = blockIdx.x / (SX * SY), t = blockIdx.x % (SX * SY);
     const int ty0 = (t / SX) * SR, tx0 = (t % SX) * SW;
-    float bw[38];
+    float bw[BF16 ? 1 : 38];
+    bf16x8 bwb[BF16 ? 5 : 1];
+    if (BF16) {
 #pragma unroll
-    for (int j = 0; j < 38; ++j) bw[j] = (2 * j + lh < 75) ? w[(2 * j + lh) * 32 + li] : 0.f;
+        for (int kb = 0; kb < 5; ++kb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * kb + 8 * lh + j;
+                bwb[kb][j] = (__bf16)(k < 75 ? w[k * 32 + li] : 0.f);
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 38; ++j) bw[j] = (2 * j + lh < 75) ? w[(2 * j + lh) * 32 + li] : 0.f;
+    }
     for (int q = tid; q < 3 * HW_ * HR_; q += 256) {
         const int c = q / (HW_ * HR_), hp = q % (HW_ * HR_);
         const int gy = ty0 + hp / HW_ - 2, gx = tx0 + hp % HW_ - 2;
@@ -53,12 +67,27 @@ __global__ __launch_bounds__(256) void e1_fwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[r][v] = 0.f;
     const int aBase = (wave * 4) * HW_ + li;
-#pragma unroll
-    for (int j = 0; j < 38; ++j) {
-        const int off = lh ? e1_off<PS, HW_>(2 * j + 1) : e1_off<PS, HW_>(2 * j);
+    if (BF16) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds_x[aBase + r * HW_ + off], bw[j], acc[r], 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < 5; ++kb) {
+                bf16x8 av;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {       // k >= 75 reads offset 0 (finite pixels) against a zero weight
+                    const int off = lh ? e1_off<PS, HW_>(16 * kb + 8 + j) : e1_off<PS, HW_>(16 * kb + j);
+                    av[j] = (__bf16)lds_x[aBase + r * HW_ + off];
+                }
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bwb[kb], acc[r], 0, 0, 0);
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 38; ++j) {
+            const int off = lh ? e1_off<PS, HW_>(2 * j + 1) : e1_off<PS, HW_>(2 * j);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds_x[aBase + r * HW_ + off], bw[j], acc[r], 0, 0, 0);
+        }
     }
     // epilogue: element v of lane (li, lh) in tile r = pixel column (v&3)+8*(v>>2)+4*lh of row 4*wave+r, channel li
     const float bv = bias[li];
@@ -169,7 +198,10 @@ __device__ __forceinline__ void e1_wgrad_fetch(const ThinWgradArgs& a, int mt, f
     }
 }
 
-template <int H>
+// BF16 (precision mode 1): k of the MFMA runs over 8 consecutive pixels of a tile row per lane half
+// (v_mfma_f32_32x32x16_bf16: 6 instructions per 128-pixel tile and wave instead of 48); operands are
+// rounded to bf16 as they leave LDS, the bias gradient is still summed from the fp32 values.
+template <int H, bool BF16 = false>
 __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
     using T = Tile<H>;
     constexpr int X_FLOATS = ((3 * T::PS + 3) / 4) * 4;
@@ -213,6 +245,27 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
         }
         __syncthreads();
         if (mt + 1 < t1) e1_wgrad_fetch<H>(a, mt + 1, rx, rd);
+        if (BF16) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int mm0 = wave * 32 + 16 * ks + 8 * lh;          // this lane half's 8 consecutive pixels
+                const int poff0 = (mm0 / T::TW) * T::HTW + mm0 % T::TW;
+                bf16x8 bvv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = lds_d[(mm0 + j) * 32 + li];
+                    bsum += d;
+                    bvv[j] = (__bf16)d;
+                }
+#pragma unroll
+                for (int mb = 0; mb < 3; ++mb) {
+                    bf16x8 av;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) av[j] = (__bf16)lds_x[aoff[mb] + poff0 + j];
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bvv, acc[mb], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const int mm = wave * 32 + 2 * kk + lh;
@@ -222,6 +275,7 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
 #pragma unroll
             for (int mb = 0; mb < 3; ++mb)
                 acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds_x[aoff[mb] + poff], bv, acc[mb], 0, 0, 0);
+        }
         }
     }
     // each wave summed its own 32 pixels per tile: total over the 4 waves
@@ -265,21 +319,25 @@ int64_t e1_wgrad_ws_floats(int width, int B) {
 }
 
 int launch_e1_fwd(int width, int B, const float* x, const float* w, const float* bias, float* y,
-                  float* bnpart, hipStream_t st) {
-    if (width == 64) hipLaunchKernelGGL(e1_fwd_kernel<64>, dim3(B * 8), dim3(256), 0, st, x, w, bias, y, bnpart, B);
-    else if (width == 128) hipLaunchKernelGGL(e1_fwd_kernel<128>, dim3(B * 32), dim3(256), 0, st, x, w, bias, y, bnpart, B);
+                  float* bnpart, hipStream_t st, bool bf16) {
+    if (width == 64 && bf16) hipLaunchKernelGGL((e1_fwd_kernel<64, true>), dim3(B * 8), dim3(256), 0, st, x, w, bias, y, bnpart, B);
+    else if (width == 128 && bf16) hipLaunchKernelGGL((e1_fwd_kernel<128, true>), dim3(B * 32), dim3(256), 0, st, x, w, bias, y, bnpart, B);
+    else if (width == 64) hipLaunchKernelGGL((e1_fwd_kernel<64, false>), dim3(B * 8), dim3(256), 0, st, x, w, bias, y, bnpart, B);
+    else if (width == 128) hipLaunchKernelGGL((e1_fwd_kernel<128, false>), dim3(B * 32), dim3(256), 0, st, x, w, bias, y, bnpart, B);
     else { cvae_set_error("e1_fwd: width %d unsupported", width); return -2; }
     CVAE_CHECK_LAUNCH();
     return 0;
 }
 
-int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw, float* dbias, float* ws, hipStream_t st) {
+int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw, float* dbias, float* ws, hipStream_t st, bool bf16) {
     if (width != 64 && width != 128) { cvae_set_error("e1_wgrad: width %d unsupported", width); return -2; }
     int tps; const int tiles = B * (width / 4) * (width / 32);
     const int S = thin_splits(tiles, &tps);
     ThinWgradArgs a{x, dy, nullptr, nullptr, ws, B, tiles, tps};
-    if (width == 64) hipLaunchKernelGGL(e1_wgrad_kernel<64>, dim3(S), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(e1_wgrad_kernel<128>, dim3(S), dim3(256), 0, st, a);
+    if (width == 64 && bf16) hipLaunchKernelGGL((e1_wgrad_kernel<64, true>), dim3(S), dim3(256), 0, st, a);
+    else if (bf16) hipLaunchKernelGGL((e1_wgrad_kernel<128, true>), dim3(S), dim3(256), 0, st, a);
+    else if (width == 64) hipLaunchKernelGGL((e1_wgrad_kernel<64, false>), dim3(S), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((e1_wgrad_kernel<128, false>), dim3(S), dim3(256), 0, st, a);
     CVAE_CHECK_LAUNCH();
     // slab row = [75 x 32 weights | 32 zeros (K pad) | 32 bias partials]: in the flat buffer enc0.b sits at
     // enc0.w + 2432 (2400 weights padded to 64 floats), so ONE column reduction fills both

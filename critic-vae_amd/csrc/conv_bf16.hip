@@ -65,10 +65,11 @@ __device__ __forceinline__ bf16x8 to_bf16x8(f32x4 lo, f32x4 hi) {
     return r;
 }
 
-template <int H> struct Bf16Geom {
-    // halo plane stride in 16-byte units: >= HP and == 2 (mod 16) so that the 16 lanes of one
-    // b128 write phase (8 octets x 2 pixels) land in 16 different 16-byte bank groups
-    static constexpr int PSP = ((Tile<H>::HP + 13) / 16) * 16 + 2;
+template <int H, int OCT> struct Bf16Geom {
+    // halo plane stride in 16-byte units: >= HP and == 16/OCT (mod 16) so that the 16 lanes of one b128
+    // write phase (OCT octets x 16/OCT pixels) land in 16 different 16-byte bank groups
+    static constexpr int PAD = OCT >= 8 ? 2 : (OCT == 4 ? 4 : 8);
+    static constexpr int PSP = ((Tile<H>::HP + 15 - PAD) / 16) * 16 + PAD;
 };
 
 template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT, int KS = 5, int MODE = MODE_STD, int NS = 1, int DMAX = 4>
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     constexpr int COUT_UP = (MODE == MODE_UP_FWD) ? NCH / 4 : KCH / 4;   // conv channels of the upsampled layer
     constexpr int KCB = NS == 3 ? 16 : (KCH < 64 ? KCH : 64);          // channels per K chunk
     constexpr int KB = KCB / 16, OCT = KCB / 8, NB = NT / 32;
-    constexpr int PSP = Bf16Geom<H>::PSP;
+    constexpr int PSP = Bf16Geom<H, OCT>::PSP;
     constexpr int A_UNITS = OCT * PSP, W_UNITS = KS * KB * 2 * NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);      // [split][octet][halo pixel]
@@ -342,7 +343,7 @@ template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT = 1, int KS = 5, 
 static int run_bf16_ns(const ConvBf16Args& a, hipStream_t st) {
     using T = Tile<H>;
     constexpr int KCB = NS == 3 ? 16 : (KCH < 64 ? KCH : 64);
-    constexpr int STAGE = NS * ((KCB / 8) * Bf16Geom<H>::PSP + KS * (KCB / 16) * 2 * NT) * 16;
+    constexpr int STAGE = NS * ((KCB / 8) * Bf16Geom<H, KCB / 8>::PSP + KS * (KCB / 16) * 2 * NT) * 16;
     constexpr int EPI_BYTES = (8 * NT > 4 * 32 * 36 ? 8 * NT : 4 * 32 * 36) * 4;
     constexpr int SMEM = STAGE > EPI_BYTES ? STAGE : EPI_BYTES;
     auto kern = conv5x5_bf16_kernel<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, NS, DMAX>;

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — Critic-VAE train-step images/sec on synthetic 64x64x3 frames (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu] [--preset config2|config4|config5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+`python bench.py --gpus N` with N > 1 and no torchrun environment launches the second form itself (N fresh
+child processes, started before this process touches a GPU) and relays rank 0's JSON line + exit code.
 
 One step = forward + vae_loss + backward + (one RCCL all-reduce of the flat gradient when N>1) +
 Adam, through the C-ABI (critic-vae_amd FusedTrainer), inputs resident in HBM.  Workload =
@@ -17,6 +20,8 @@ Rank 0 prints ONE JSON line.  At N=1 it also reports
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -62,19 +67,28 @@ def bn_apply_bytes(layer, B, width=64):
 
 def measured_traffic(name):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/: separate --pmc runs,
-    FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950), or None."""
+    FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950).  The JSON carries the sha256
+    of the kernel sources it was measured on; if the sources have changed since, the figure is stale and
+    None is returned (never a number measured on other kernels)."""
     try:
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        from source_stamp import kernel_source_sha
         with open(TRAFFIC_JSON) as f:
-            return json.load(f)["bytes_per_launch"].get(name)
-    except (OSError, ValueError, KeyError):
+            j = json.load(f)
+        if j.get("kernel_source_sha256") != kernel_source_sha(ROOT):
+            return None
+        return j["bytes_per_launch"].get(name)
+    except (OSError, ValueError, KeyError, ImportError):
         return None
 
 
-def cpu_baseline(B, steps=5, width=64):
+def cpu_baseline(B, steps=None, width=64):
     """The oracle's training step (same ATen CPU kernels as the reference, equality pinned by
     tests/golden) timed on this host: bounded sample of the same workload."""
     from critic_vae_amd import synth
     from oracle import cvae_oracle as orc
+    if steps is None:                                   # about 10-30 s of CPU work whatever the batch
+        steps = max(1, min(5, 1280 * 64 * 64 // (B * width * width)))
     threads = min(len(os.sched_getaffinity(0)), 16)     # the 1-GPU box's CPU share is 16 cores
     torch.set_num_threads(threads)
     p = orc.to_torch(synth.make_params(0, width), requires_grad=True)
@@ -99,6 +113,26 @@ def cpu_baseline(B, steps=5, width=64):
                                       f"after 1 warm-up; {dt:.1f}s of CPU work"}
 
 
+PRESETS = {   # BASELINE.json configs beyond the default (configs[1] = fp32, 256/GPU, 64x64)
+    "config2": dict(precision="bf16", batch=2048, width=64),     # configs[2]: 1 GPU bf16-MFMA, batch 2048
+    "config4": dict(precision="bf16", batch=2048, width=64),     # configs[3]: 8 GPUs, 2048/GPU (global 16384)
+    "config5": dict(precision="bf16", batch=1024, width=128),    # configs[4]: 8 GPUs, 128x128, 1024/GPU (global 8192)
+}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` outside torchrun: start N ranks as CHILD processes (one per GPU) through
+    torch.distributed.run and pass their output and exit code through.  Called before anything in this
+    process initialises HIP — a process that has touched the GPU is never exec'd or re-used."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,10 +143,17 @@ def main():
     ap.add_argument("--precision", choices=["f32", "bf16", "bf16x9", "bf16x6"], default="f32",
                     help="f32 = the 1e-4-parity path (default, BASELINE configs[1]); bf16 = bf16-MFMA forward/dgrad "
                          "convs (configs[2]: use with --batch 2048)")
+    ap.add_argument("--preset", choices=sorted(PRESETS), default=None,
+                    help="BASELINE.json configs[2..4] workloads: sets --precision/--batch/--width")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--no-fwd-bwd-rate", action="store_true", help="skip the extra forward+loss+backward-only loop (profiling runs)")
     args = ap.parse_args()
+    if args.preset:
+        for k, v in PRESETS[args.preset].items():
+            setattr(args, k, v)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     from critic_vae_amd import dp
     from critic_vae_amd.nets import VariationalAutoencoder
@@ -135,6 +176,7 @@ def main():
     Wd = args.width
     vae = VariationalAutoencoder(width=Wd, max_batch=B, seed=0, precision=args.precision).to(dev)
     tr = FusedTrainer(vae, world_size=world)
+    tr.measure_exposed = world > 1
     H = vae.handle
     # synthetic inputs, resident in HBM before the timed region; each rank its own shard
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -163,6 +205,7 @@ def main():
         dominant_hbm = max((p for p in survey if p >= 27), key=survey.get)
         H.probe_config([dominant, dominant_hbm])      # timed region: the dominant MFMA and HBM kernels only
         note(f"dominant kernel {probe_name(dominant)} ({survey[dominant] * 1e3:.1f} us)")
+    tr.exposed_us()                       # drop the warm-up samples
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -173,6 +216,19 @@ def main():
     torch.cuda.synchronize()
     dt = dp.max_over_ranks(time.perf_counter() - t0, dev)
     loss = float(scal[0].item())
+    exposed = tr.exposed_us()
+    dist_info = None
+    if world > 1:
+        # what the collectives really ran on: ranks counted by an all-reduce, backend, device of every rank
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones)
+        mine = torch.zeros(world, dtype=torch.int64, device=dev)
+        mine[rank] = dev.index
+        torch.distributed.all_reduce(mine)
+        dist_info = {"backend": torch.distributed.get_backend(), "ranks_counted_by_allreduce": int(ones.item()),
+                     "world_size": torch.distributed.get_world_size(), "rank_devices": [int(v) for v in mine.tolist()],
+                     "allreduce_exposed_us": None if exposed is None else round(exposed, 1),
+                     "allreduce_bytes": int(tr.grads.numel() * 4)}
     note(f"timed {args.steps} steps in {dt:.3f}s, loss {loss}")
 
     res = {
@@ -187,7 +243,7 @@ def main():
                   "bf16x6": "f32 emulated: 3-way exact bf16 operand splits, the 6 leading partial products (fwd+dgrad of "
                             "E2-E4, D0), f32 MFMA wgrad, f32 elsewhere"}[args.precision],
         "data": "synthetic",
-        "config": {"workload": ({"f32": "BASELINE.json configs[1]: fp32", "bf16": "BASELINE.json configs[2]: bf16-MFMA",
+        "config": {"workload": ({"f32": "BASELINE.json configs[1]: fp32", "bf16": "BASELINE.json configs[2]" + ("/configs[3] per-GPU" if world > 1 else "") + ": bf16-MFMA",
                                  "bf16x9": "BASELINE.json configs[1] workload, fp32 emulated by 3-way bf16 splits",
                                  "bf16x6": "BASELINE.json configs[1] workload, fp32 emulated by 3-way bf16 splits (6 products)"}[args.precision]
                                 if Wd == 64 else f"BASELINE.json configs[4] frame size (128x128), {args.precision}")
@@ -198,6 +254,9 @@ def main():
                    "final_loss": loss, "loss_finite": bool(loss == loss and abs(loss) != float("inf")),
                    },
     }
+    if dist_info:
+        res["config"]["distributed"] = dist_info
+        res["rccl_ranks"] = dist_info["ranks_counted_by_allreduce"] if dist_info["backend"] == "nccl" else 0
     if rank == 0 and world == 1:
         res["config"]["whole_step_algorithmic_TFLOPs"] = round(B * args.steps / dt * FLOP_PER_IMG[Wd] / 1e12, 2)
         if dominant is not None:
@@ -227,6 +286,8 @@ def main():
                     "algorithmic_bytes_per_launch": by}
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(B, width=Wd)
+            if B != 32:       # the reference's own CPU-runnable case (configs[0], batch 32) beside it
+                res["cpu_baseline"]["batch32"] = cpu_baseline(32, steps=10, width=Wd)
     # SURVEY 8d also asks for the C-ABI path proper (forward + loss + backward, no all-reduce / optimizer)
     fb_steps = 0 if args.no_fwd_bwd_rate else max(5, args.steps // 4)
     x0, p0, e0 = pool[0]

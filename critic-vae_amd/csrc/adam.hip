@@ -55,3 +55,36 @@ int launch_zero(float* p, int64_t n, hipStream_t st) {
     CVAE_CHECK_LAUNCH();
     return 0;
 }
+
+// Alignment padding between the tensors of the flat gradient buffer (<= 63 floats each): written as 0 so a
+// caller may hand cvae_backward an uninitialised buffer (phase bit 3).  One workgroup per tensor gap.
+__global__ __launch_bounds__(64) void zero_gaps_kernel(float* __restrict__ g, PadGaps gaps) {
+    const int64_t o = gaps.off[blockIdx.x];
+    if ((int)threadIdx.x < gaps.len[blockIdx.x]) g[o + threadIdx.x] = 0.f;
+}
+int launch_zero_gaps(float* grads, const PadGaps& gaps, hipStream_t st) {
+    if (gaps.n == 0) return 0;
+    hipLaunchKernelGGL(zero_gaps_kernel, dim3(gaps.n), dim3(64), 0, st, grads, gaps);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}
+
+// out_k = in_k * g[0] for the three loss gradients in ONE launch (the chain-rule factor autograd hands
+// total_loss.backward(): a device scalar, so no host read)
+__global__ __launch_bounds__(256) void scale3_kernel(Scale3 a) {
+    const float g = a.g[0];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int64_t j = i; j < a.n[k]; j += (int64_t)gridDim.x * 256) a.dst[k][j] = a.src[k][j] * g;
+}
+int launch_scale3(const Scale3& a, hipStream_t st) {
+    int64_t nmax = a.n[0] > a.n[1] ? a.n[0] : a.n[1];
+    if (a.n[2] > nmax) nmax = a.n[2];
+    int64_t blocks = (nmax + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(scale3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}

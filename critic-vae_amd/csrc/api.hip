@@ -330,8 +330,16 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
                          const float* d_logvar, void* wsv, float* grads, int32_t phase_mask, void* stream) {
     (void)pred;
     RC(check(h, B, wsv));
-    if ((phase_mask & ~7) != 0 || phase_mask == 0) { cvae_set_error("cvae_backward_phases: phase_mask %d (bits 0..2)", phase_mask); return CVAE_EINVAL; }
+    if ((phase_mask & ~15) != 0 || (phase_mask & 7) == 0) { cvae_set_error("cvae_backward_phases: phase_mask %d (bits 0..2 = phases, bit 3 = zero the alignment padding)", phase_mask); return CVAE_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
+    if (phase_mask & 8) {                               // caller handed an uninitialised gradient buffer
+        PadGaps gaps{};
+        for (const ParamEntry& p : h->params) {
+            const int64_t pad = align_up(p.numel, 64) - p.numel;
+            if (pad > 0 && gaps.n < 32) { gaps.off[gaps.n] = p.offset + p.numel; gaps.len[gaps.n] = (int)pad; gaps.n++; }
+        }
+        RC(launch_zero_gaps(grads, gaps, st));
+    }
     float* ws = (float*)wsv;
     const WsLayout w = carve(h, B);
     const int W = h->cfg.width;
@@ -413,6 +421,16 @@ int cvae_adam_step(cvae_handle h, float* params, const float* grads, float* exp_
                    int32_t step, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
     if (!h || step < 1) { cvae_set_error("cvae_adam_step: bad handle/step"); return CVAE_EINVAL; }
     return launch_adam(params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream);
+}
+
+// d_* (out) = d_* (in) * gscale[0]: total_loss.backward()'s incoming factor applied to the three loss
+// gradients cvae_loss wrote, one launch, gscale a device scalar (no host read)
+int cvae_scale_loss_grads(cvae_handle h, int32_t B, const float* gscale, const float* d_recon, const float* d_mu,
+                          const float* d_logvar, float* d_recon_out, float* d_mu_out, float* d_logvar_out, void* stream) {
+    if (!h || B < 1 || !gscale) { cvae_set_error("cvae_scale_loss_grads: bad argument"); return CVAE_EINVAL; }
+    const int W = h->cfg.width;
+    Scale3 a{gscale, {d_recon, d_mu, d_logvar}, {d_recon_out, d_mu_out, d_logvar_out}, {(int64_t)B * 3 * W * W, (int64_t)B * 32, (int64_t)B * 32}};
+    return launch_scale3(a, (hipStream_t)stream);
 }
 
 // ---- critic inference + uint8 frame pre-processing (vae.py:46-50) ----

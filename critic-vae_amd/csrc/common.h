@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -70,6 +71,21 @@ void cvae_set_error(const char* fmt, ...);
             return (int)e_;                                                        \
         }                                                                          \
     } while (0)
+
+// The opt-in to more than 64 KB of dynamic LDS is a PER-DEVICE function attribute: remember, per kernel,
+// the set of devices it has been granted on (idempotent, thread-safe; one handle per device may live in
+// the same process).  `once` is a function-local static of the launcher that owns the kernel.
+struct DeviceOnce { std::atomic<uint64_t> mask{0}; };
+inline int cvae_grant_lds(DeviceOnce& once, const void* kernel, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (e == hipSuccess && (once.mask.load(std::memory_order_acquire) & bit)) return 0;
+    if (e == hipSuccess) e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { cvae_set_error("dynamic LDS opt-in (%d bytes) failed: %s", bytes, hipGetErrorString(e)); return (int)e; }
+    once.mask.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
 
 // ---- launchers implemented across the .hip files (all asynchronous on `st`) ----
 // conv_mfma.hip
@@ -169,3 +185,7 @@ int launch_diff_grey(int width, int B, const float* a, const float* b, float* di
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1,
                 float b2, float eps, float gscale, hipStream_t st);
 int launch_zero(float* p, int64_t n, hipStream_t st);
+struct PadGaps { int64_t off[32]; int len[32]; int n; };
+int launch_zero_gaps(float* grads, const PadGaps& gaps, hipStream_t st);
+struct Scale3 { const float* g; const float* src[3]; float* dst[3]; int64_t n[3]; };
+int launch_scale3(const Scale3& a, hipStream_t st);

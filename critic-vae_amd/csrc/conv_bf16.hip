@@ -347,11 +347,8 @@ static int run_bf16_ns(const ConvBf16Args& a, hipStream_t st) {
     constexpr int EPI_BYTES = (8 * NT > 4 * 32 * 36 ? 8 * NT : 4 * 32 * 36) * 4;
     constexpr int SMEM = STAGE > EPI_BYTES ? STAGE : EPI_BYTES;
     auto kern = conv5x5_bf16_kernel<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, NS, DMAX>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(kern), SMEM); if (rc) return rc; }
     dim3 grid(cdiv(a.B, T::IMGS) * T::TILES_PER_IMG, NCH / NT, KSPLIT);
     cvae_probe_begin(st);
     hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, st, a);
@@ -635,11 +632,8 @@ static int run_wgrad_bf16(int B, const float* in, const float* dout, float* dw, 
     constexpr int STAGE = (T::HP + T::NPX) * 32 * 16, RED = (3 * 16 * 64) * 4 + 256 * 16;
     constexpr int SMEM = STAGE > RED ? STAGE : RED;
     auto kern = conv5x5_wgrad_bf16_kernel<CIN, COUT, H>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(kern), SMEM); if (rc) return rc; }
     cvae_probe_begin(st);
     hipLaunchKernelGGL(kern, dim3(S, CIN / 32, COUT / 32), dim3(256), SMEM, st, a);
     cvae_probe_end(st);

@@ -608,14 +608,10 @@ int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const
     hipLaunchKernelGGL(d4_actbwd_kernel, dim3(B * 3), dim3(256), 0, st, d_recon, recon, dout, plane_sums, width * width);
     CVAE_CHECK_LAUNCH();
     ThinWgradArgs a{dout, o3, w, d_o3, ws, B, tiles, tps};
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(d4_bwd_kernel<64>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, D4_BWD_SMEM);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(d4_bwd_kernel<128>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, D4_BWD_SMEM);
-        attr_set = true;
-    }
+    static DeviceOnce once64, once128;
+    { int rc = width == 64 ? cvae_grant_lds(once64, reinterpret_cast<const void*>(d4_bwd_kernel<64>), D4_BWD_SMEM)
+                           : cvae_grant_lds(once128, reinterpret_cast<const void*>(d4_bwd_kernel<128>), D4_BWD_SMEM);
+      if (rc) return rc; }
     if (width == 64) hipLaunchKernelGGL(d4_bwd_kernel<64>, dim3(S), dim3(256), D4_BWD_SMEM, st, a);
     else hipLaunchKernelGGL(d4_bwd_kernel<128>, dim3(S), dim3(256), D4_BWD_SMEM, st, a);
     CVAE_CHECK_LAUNCH();

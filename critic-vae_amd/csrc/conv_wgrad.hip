@@ -245,11 +245,8 @@ static int run_wgrad(int B, const float* in, const float* dout, float* dw, float
     WgradArgs a{in, dout, ws, B, cdiv(B, T::IMGS) * T::TILES_PER_IMG, tps};
     constexpr int SMEM = (T::HP * 32 + 128 * 32) * 4;
     auto kern = conv5x5_wgrad_kernel<CIN, COUT, H, UP>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(kern), SMEM); if (rc) return rc; }
     cvae_probe_begin(st);
     hipLaunchKernelGGL(kern, dim3(S, CIN / 32, COUT / 32), dim3(256), SMEM, st, a);
     cvae_probe_end(st);

@@ -112,11 +112,8 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(const uint8_t* __res
 int launch_critic_fwd(int width, int B, const float* x, const float* critic_params, float* pred, hipStream_t st) {
     if (width != 64) { cvae_set_error("critic: width %d unsupported (the reference critic is 64x64 only)", width); return -2; }
     constexpr int SMEM = (3 * 66 * 66 + 8 * 34 * 34 + 8 * 18 * 18 + 8 * 10 * 10 + 16 * 4 * 4 + 64) * 4;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(critic_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        attr = true;
-    }
+    static DeviceOnce once;
+    { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(critic_fwd_kernel), SMEM); if (rc) return rc; }
     hipLaunchKernelGGL(critic_fwd_kernel, dim3(B), dim3(256), SMEM, st, x, critic_params, pred);
     CVAE_CHECK_LAUNCH();
     return 0;

@@ -20,18 +20,16 @@
 #include "common.h"
 #include <math.h>
 
-__constant__ float c_win[11];
-static bool g_win_ready = false;
-
-static int ensure_window() {
-    if (g_win_ready) return 0;
-    float e[11], s = 0.f;
-    for (int i = 0; i < 11; ++i) { e[i] = (float)exp((double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); s += e[i]; }
-    for (int i = 0; i < 11; ++i) e[i] = e[i] / s;
-    hipError_t err = hipMemcpyToSymbol(HIP_SYMBOL(c_win), e, sizeof(e));
-    if (err != hipSuccess) { cvae_set_error("msssim window upload failed: %s", hipGetErrorString(err)); return (int)err; }
-    g_win_ready = true;
-    return 0;
+// The 11 normalised taps travel BY VALUE in every kernel's argument struct (scalar registers): no
+// __constant__ symbol, no upload, no process-global device state — handles on different devices are
+// independent and nothing here synchronises.  gaussian_window (vae_nets.py:169-173): fp32 exp, fp32 sum.
+struct MsWin { float w[11]; };
+static MsWin make_window() {
+    MsWin m;
+    float s = 0.f;
+    for (int i = 0; i < 11; ++i) { m.w[i] = (float)exp((double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); s += m.w[i]; }
+    for (int i = 0; i < 11; ++i) m.w[i] = m.w[i] / s;
+    return m;
 }
 
 template <int S>
@@ -86,6 +84,7 @@ struct MsFwdArgs {
     float* part;          // [numBlocks][2]
     int P;
     int last;             // level 4: the contributing map is ssim_map instead of cs_map
+    MsWin win;
 };
 
 template <int S>
@@ -102,7 +101,7 @@ __global__ __launch_bounds__(256) void msssim_fwd_kernel(MsFwdArgs a) {
     __syncthreads();
     float w[11];
 #pragma unroll
-    for (int t = 0; t < 11; ++t) w[t] = c_win[t];
+    for (int t = 0; t < 11; ++t) w[t] = a.win.w[t];
     // horizontal pass.  Large levels (one plane per workgroup): 4 adjacent outputs per work item from
     // a 14-wide register window (3.5 LDS reads per output instead of 22); same fma order per output.
     if constexpr (S >= 32) {
@@ -304,6 +303,7 @@ struct MsBwdArgs {
     const float* coef;    // device scalar for this level
     float* dx;
     int P;
+    MsWin win;
 };
 
 template <int S>
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void msssim_bwd_kernel(MsBwdArgs a) {
     __syncthreads();
     float w[11];
 #pragma unroll
-    for (int t = 0; t < 11; ++t) w[t] = c_win[t];
+    for (int t = 0; t < 11; ++t) w[t] = a.win.w[t];
     if constexpr (S >= 32) {
         constexpr int CG = S / 4;
         for (int it = threadIdx.x; it < G::HR * CG; it += 256) {
@@ -441,8 +441,8 @@ template <int S>
 static int ms_fwd(const MsFwdArgs& a, hipStream_t st) {
     using G = MsGeom<S>;
     constexpr int SMEM = (2 * G::PPB * G::HR * G::HC + 5 * G::PPB * G::HR * S) * 4;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msssim_fwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); attr = true; }
+    static DeviceOnce once;
+    { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(msssim_fwd_kernel<S>), SMEM); if (rc) return rc; }
     hipLaunchKernelGGL(msssim_fwd_kernel<S>, dim3(ms_blocks<S>(a.P)), dim3(256), SMEM, st, a);
     CVAE_CHECK_LAUNCH();
     return 0;
@@ -451,8 +451,8 @@ template <int S>
 static int ms_bwd(const MsBwdArgs& a, hipStream_t st) {
     using G = MsGeom<S>;
     constexpr int SMEM = (3 * G::PPB * G::HR * G::HC + 3 * G::PPB * G::HR * S) * 4;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(msssim_bwd_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); attr = true; }
+    static DeviceOnce once;
+    { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(msssim_bwd_kernel<S>), SMEM); if (rc) return rc; }
     hipLaunchKernelGGL(msssim_bwd_kernel<S>, dim3(ms_blocks<S>(a.P)), dim3(256), SMEM, st, a);
     CVAE_CHECK_LAUNCH();
     return 0;
@@ -485,8 +485,8 @@ static int ms_bwd_size(int S, const MsBwdArgs& a, hipStream_t st) {
 int launch_msssim(int width, int B, const float* img1, const float* img2, const float* mu, const float* logvar,
                   float* ws, float* scalars, float* d_img1, float* d_mu, float* d_logvar, hipStream_t st) {
     if (width != 64 && width != 128) { cvae_set_error("msssim: width %d unsupported", width); return -2; }
-    int rc = ensure_window();
-    if (rc) return rc;
+    int rc = 0;
+    const MsWin win = make_window();
     const MsWs w = ms_carve(width, B);
     const int P = B * 3;
     const bool grad = d_img1 != nullptr;
@@ -496,7 +496,7 @@ int launch_msssim(int width, int B, const float* img1, const float* img2, const 
     for (int l = 0; l < 5; ++l) {
         MsFwdArgs a{lx[l], ly[l], l < 4 ? ws + w.pyrx[l + 1] : nullptr, l < 4 ? ws + w.pyry[l + 1] : nullptr,
                     grad ? ws + w.um[l] : nullptr, grad ? ws + w.u11[l] : nullptr, grad ? ws + w.u12[l] : nullptr,
-                    ws + w.part[l], P, l == 4};
+                    ws + w.part[l], P, l == 4, win};
         rc = ms_fwd_size(width >> l, a, st);
         if (rc) return rc;
     }
@@ -513,7 +513,7 @@ int launch_msssim(int width, int B, const float* img1, const float* img2, const 
     if (!grad) return 0;
     for (int l = 4; l >= 0; --l) {
         MsBwdArgs a{ws + w.um[l], ws + w.u11[l], ws + w.u12[l], lx[l], ly[l], l < 4 ? ws + w.gp[l + 1] : nullptr,
-                    ws + w.coef + l, l == 0 ? d_img1 : ws + w.gp[l], P};
+                    ws + w.coef + l, l == 0 ? d_img1 : ws + w.gp[l], P, win};
         rc = ms_bwd_size(width >> l, a, st);
         if (rc) return rc;
     }

@@ -54,6 +54,7 @@ _SIGS = {
     "cvae_backward": (C.c_int, [_p, _i32] + [_p] * 12),
     "cvae_backward_phases": (C.c_int, [_p, _i32] + [_p] * 11 + [_i32, _p]),
     "cvae_grad_bucket": (C.c_int, [_p, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "cvae_scale_loss_grads": (C.c_int, [_p, _i32] + [_p] * 8),
     "cvae_adam_step": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _f, _f, _f, _f, _f, _p]),
     "cvae_critic_param_count": (_i32, []),
     "cvae_critic_forward": (C.c_int, [_p, _i32, _p, _p, _p, _p]),
@@ -168,10 +169,20 @@ class Handle:
         self._check(self.lib.cvae_loss(self.h, B, _ptr(x), _ptr(mu), _ptr(logvar), _ptr(recon), _ptr(ws),
                                        _ptr(scalars), _ptr(d_recon), _ptr(d_mu), _ptr(d_logvar), _stream()))
 
-    def backward(self, B, x, pred, eps, params, logvar, recon, d_recon, d_mu, d_logvar, ws, grads):
+    def backward(self, B, x, pred, eps, params, logvar, recon, d_recon, d_mu, d_logvar, ws, grads, zero_padding=False):
+        """zero_padding: `grads` is uninitialised memory — also write 0 into the alignment gaps (phase bit 3)."""
+        if zero_padding:
+            self._check(self.lib.cvae_backward_phases(self.h, B, _ptr(x), _ptr(pred), _ptr(eps), _ptr(params),
+                                                      _ptr(logvar), _ptr(recon), _ptr(d_recon), _ptr(d_mu),
+                                                      _ptr(d_logvar), _ptr(ws), _ptr(grads), 15, _stream()))
+            return
         self._check(self.lib.cvae_backward(self.h, B, _ptr(x), _ptr(pred), _ptr(eps), _ptr(params), _ptr(logvar),
                                            _ptr(recon), _ptr(d_recon), _ptr(d_mu), _ptr(d_logvar), _ptr(ws),
                                            _ptr(grads), _stream()))
+
+    def scale_loss_grads(self, B, g, d_recon, d_mu, d_logvar, out_recon, out_mu, out_logvar):
+        self._check(self.lib.cvae_scale_loss_grads(self.h, B, _ptr(g), _ptr(d_recon), _ptr(d_mu), _ptr(d_logvar),
+                                                   _ptr(out_recon), _ptr(out_mu), _ptr(out_logvar), _stream()))
 
     def backward_phase(self, phase, B, x, pred, eps, params, logvar, recon, d_recon, d_mu, d_logvar, ws, grads):
         """Phase 0..2 of the backward (decoder | fc + encoder block 3 | encoder blocks 2..0), in order."""

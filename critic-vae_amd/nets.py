@@ -50,8 +50,11 @@ class _ForwardFn(torch.autograd.Function):
         d_mu = torch.zeros_like(logvar) if d_mu is None else d_mu.contiguous()
         d_logvar = torch.zeros_like(logvar) if d_logvar is None else d_logvar.contiguous()
         d_recon = torch.zeros_like(recon) if d_recon is None else d_recon.contiguous()
-        grads = torch.zeros_like(theta)          # alignment padding between tensors must stay 0
-        vae.handle.backward(B, x, pred, eps, theta, logvar, recon, d_recon, d_mu, d_logvar, vae._workspace(B), grads)
+        # fresh, unshared buffer so AccumulateGrad adopts it as theta.grad without a copy; the library writes
+        # every element (phase bit 3 zeroes the alignment padding) — no 10 MB fill per step
+        grads = torch.empty_like(theta)
+        vae.handle.backward(B, x, pred, eps, theta, logvar, recon, d_recon, d_mu, d_logvar, vae._workspace(B), grads,
+                            zero_padding=True)
         return None, None, None, None, grads
 
 
@@ -66,13 +69,17 @@ class _LossFn(torch.autograd.Function):
         vae.handle.loss(B, x, mu.contiguous(), logvar.contiguous(), recon.contiguous(), vae._workspace(B), scalars,
                         d_recon, d_mu, d_logvar)
         ctx.save_for_backward(d_recon, d_mu, d_logvar)
+        ctx.vae = vae
         vae.last_scalars = scalars
         return scalars[0].clone()
 
     @staticmethod
     def backward(ctx, g):
         d_recon, d_mu, d_logvar = ctx.saved_tensors
-        return None, None, d_mu * g, d_logvar * g, d_recon * g
+        o_recon, o_mu, o_logvar = torch.empty_like(d_recon), torch.empty_like(d_mu), torch.empty_like(d_logvar)
+        ctx.vae.handle.scale_loss_grads(d_mu.shape[0], g.to(torch.float32).contiguous(), d_recon, d_mu, d_logvar,
+                                        o_recon, o_mu, o_logvar)         # one launch, g stays on the device
+        return None, None, o_mu, o_logvar, o_recon
 
 
 class VariationalEncoder(nn.Module):

@@ -80,6 +80,23 @@ class FusedTrainer:
         self.d_logvar = torch.empty_like(self.mu)
         self.scalars = torch.empty(16, device=dev)
         self.ws = vae._workspace(B)
+        self.exposed_ms = []              # measure_exposed: device time the compute stream spent waiting for the all-reduce
+        self.measure_exposed = False
+        self._ev = None
+        if world_size > 1:
+            self.sync_replicas()
+
+    def sync_replicas(self, src=0):
+        """Every rank starts from rank `src`'s replica: parameters, BatchNorm running statistics and the Adam
+        state are broadcast (torch DDP does the same at construction) — ranks built with different seeds,
+        or one rank restored from a checkpoint, would otherwise train different models on the averaged
+        gradient without any error."""
+        dist = torch.distributed
+        for t in (self.vae.theta.data, self.vae.bn_state, self.m, self.v):
+            dist.broadcast(t, src=src, group=self.pg)
+        meta = torch.tensor([self.step_count, self.vae.num_batches_tracked], dtype=torch.int64, device=self.m.device)
+        dist.broadcast(meta, src=src, group=self.pg)
+        self.step_count, self.vae.num_batches_tracked = int(meta[0].item()), int(meta[1].item())
 
     def step(self, x, pred, eps):
         """x (B,3,w,w), pred (B,1), eps (B,32): contiguous fp32 device tensors."""
@@ -96,18 +113,44 @@ class FusedTrainer:
                                  self.d_logvar, self.ws, self.grads)
                 off, n = self.buckets[ph]
                 works.append(torch.distributed.all_reduce(self.grads[off:off + n], group=self.pg, async_op=True))
+            self._exposed_begin()
             for wk in works:
                 wk.wait()                     # nccl: the compute stream waits for the collective's stream
+            self._exposed_end()
         else:
             h.backward(B, x, pred, eps, theta, self.logvar, self.recon, self.d_recon, self.d_mu, self.d_logvar,
                        self.ws, self.grads)
             if self.world_size > 1:
+                self._exposed_begin()
                 torch.distributed.all_reduce(self.grads, group=self.pg)      # one flat RCCL all-reduce (sum)
+                self._exposed_end()
         self.step_count += 1
         v.num_batches_tracked += 1
         h.adam_step(theta, self.grads, self.m, self.v, self.step_count, self.lr, self.betas[0], self.betas[1],
                     self.eps, grad_scale=1.0 / self.world_size)
         return self.scalars
+
+
+    # time between "backward is done" and "the reduced gradient is usable" on the compute stream = the part
+    # of the all-reduce that backward did not hide (bench.py: allreduce_exposed_us)
+    def _exposed_begin(self):
+        if self.measure_exposed:
+            self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._ev[0].record()
+
+    def _exposed_end(self):
+        if self.measure_exposed:
+            self._ev[1].record()
+            self.exposed_ms.append(self._ev)
+
+    def exposed_us(self):
+        """Mean exposed all-reduce time per step (µs) over the steps taken with measure_exposed; syncs."""
+        if not self.exposed_ms:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self.exposed_ms]
+        self.exposed_ms = []
+        return 1e3 * sum(ms) / len(ms)
 
 
 def synthetic_dataset(n_frames, width=P.w, seed=1234):

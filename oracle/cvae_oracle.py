@@ -68,9 +68,14 @@ def _act(x, kind):
     return torch.relu(x) if kind == "relu" else torch.tanh(x)
 
 
-def encoder(params, x, bn_state=None, train=True, taps=None):
+def encoder(params, x, bn_state=None, train=True, taps=None, decisions=None):
     """vae_nets.py:101-111.  Conv -> BatchNorm(batch stats when train) -> MaxPool2 -> act, x4;
-    flatten in (C,H,W) order; fc_mu / fc_var.  `taps` (dict) collects intermediates."""
+    flatten in (C,H,W) order; fc_mu / fc_var.  `taps` (dict) collects intermediates.
+
+    `decisions` (tests only; default None = the reference's own behaviour): impose the discrete choices of
+    another implementation — `pool{l}`: max-pool argmax as flat H*W indices (B,C,H/2,W/2), `relu_enc{l}`: 0/1
+    mask of the units ReLU lets through — so that two runs that agree to fp32 round-off everywhere can be
+    compared beyond the handful of units whose max / sign decision sits inside that round-off."""
     h = x
     for bi_, (ci, bi, act) in enumerate(ENC_BLOCKS):
         y = F.conv2d(h, params[f"encoder.model.{ci}.weight"], params[f"encoder.model.{ci}.bias"],
@@ -86,9 +91,15 @@ def encoder(params, x, bn_state=None, train=True, taps=None):
         n = F.batch_norm(y, rm, rv, params[f"encoder.model.{bi}.weight"],
                          params[f"encoder.model.{bi}.bias"], training=train,
                          momentum=BN_MOMENTUM, eps=BN_EPS)
-        h = _act(F.max_pool2d(n, 2), act)
+        if decisions is None:
+            h = _act(F.max_pool2d(n, 2), act)
+        else:
+            idx = decisions[f"pool{bi_}"]
+            pooled = n.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+            h = pooled * decisions[f"relu_enc{bi_}"].to(pooled.dtype) if act == "relu" else torch.tanh(pooled)
         if taps is not None:
             taps[f"enc_y{bi_}"] = y
+            taps[f"enc_n{bi_}"] = n
             taps[f"enc_a{bi_}"] = h
     flat = torch.flatten(h, start_dim=1)
     mu = F.linear(flat, params["encoder.fc_mu.weight"], params["encoder.fc_mu.bias"])
@@ -101,8 +112,9 @@ def reparametrize(mu, logvar, eps):
     return mu + eps * torch.exp(0.5 * logvar)
 
 
-def decoder(params, z, pred, taps=None):
-    """vae_nets.py:139-147 (training branch): cat -> Linear -> view(-1,256,s,s) -> convs."""
+def decoder(params, z, pred, taps=None, decisions=None):
+    """vae_nets.py:139-147 (training branch): cat -> Linear -> view(-1,256,s,s) -> convs.
+    `decisions["relu_dec{i}"]` (tests only): imposed 0/1 ReLU masks, see encoder()."""
     hcat = torch.cat((z, pred), dim=1)
     h = F.linear(hcat, params["decoder.decoder_input.weight"], params["decoder.decoder_input.bias"])
     side = int(round(math.sqrt(h.shape[1] // 256)))
@@ -110,9 +122,13 @@ def decoder(params, z, pred, taps=None):
     if taps is not None:
         taps["dec_h"] = h
     for i, (ci, act, up) in enumerate(DEC_BLOCKS):
-        h = _act(F.conv2d(h, params[f"decoder.model.{ci}.weight"],
-                          params[f"decoder.model.{ci}.bias"], stride=1, padding=PAD), act)
+        pre = F.conv2d(h, params[f"decoder.model.{ci}.weight"], params[f"decoder.model.{ci}.bias"], stride=1, padding=PAD)
+        if decisions is not None and act == "relu":
+            h = pre * decisions[f"relu_dec{i}"].to(pre.dtype)
+        else:
+            h = _act(pre, act)
         if taps is not None:
+            taps[f"dec_pre{i}"] = pre
             taps[f"dec_o{i}"] = h
         if up:
             h = F.interpolate(h, scale_factor=2, mode="nearest")     # nn.Upsample default mode
@@ -177,14 +193,14 @@ def vae_loss(x, mu, logvar, recon):
             "ssim_levels": sims.detach(), "cs_levels": css.detach()}
 
 
-def train_step(params, x, pred, eps, bn_state=None, taps=None):
+def train_step(params, x, pred, eps, bn_state=None, taps=None, decisions=None):
     """forward + loss + backward of vae.py:53-57 on explicit (x, pred, eps).
 
     `params` must be leaf tensors with requires_grad=True; their .grad is filled (accumulated,
     like autograd does).  Returns dict with mu, logvar, recon and the loss scalars."""
-    mu, logvar = encoder(params, x, bn_state, train=True, taps=taps)
+    mu, logvar = encoder(params, x, bn_state, train=True, taps=taps, decisions=decisions)
     z = reparametrize(mu, logvar, eps)
-    recon = decoder(params, z, pred, taps=taps)
+    recon = decoder(params, z, pred, taps=taps, decisions=decisions)
     losses = vae_loss(x, mu, logvar, recon)
     if taps is not None:
         for t in taps.values():

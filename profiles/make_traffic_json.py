@@ -10,7 +10,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_stamp import kernel_source_sha  # noqa: E402
 
 CONV = {  # probe name -> kernel-name prefix
     "conv_fwd_L1": "void conv5x5_mfma_kernel<32, 64, 32, false, false", "conv_fwd_L2": "void conv5x5_mfma_kernel<64, 128, 16, false, false",
@@ -58,5 +62,6 @@ f, w = pick(fetch, BN_TANH_APPLY), pick(write, BN_TANH_APPLY)
 if f and w:
     out["bn_pool_bwd_apply_L3"] = round(2 * sum(f) / len(f) + sum(w) / len(w))
 json.dump({"workload": "bench.py, fp32, batch 256, one MI355X", "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (see profiles/README.md)",
-           "formula": "2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes, mean over launches", "bytes_per_launch": out}, sys.stdout, indent=1)
+           "formula": "2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes, mean over launches",
+           "kernel_source_sha256": kernel_source_sha(), "bytes_per_launch": out}, sys.stdout, indent=1)
 print()

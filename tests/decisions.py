@@ -1,0 +1,121 @@
+"""Discrete decisions of a training step (max-pool argmax, ReLU masks) — read back from the HIP path's saved
+tensors and from the oracle's taps — and the parity check built on them.
+
+Two correct fp32 implementations agree to round-off everywhere, but a max-pool window whose two largest
+values differ by an ulp, or a ReLU input within an ulp of zero, may be decided differently; the gradient
+then moves by the full local gradient at that unit.  Instead of loosening the relative bound for that,
+the tests (1) count the flipped units and show each one sits inside fp32 round-off of a tie, and
+(2) compare every gradient element against the oracle run with the HIP path's decisions imposed
+(oracle.train_step(decisions=...)), at SURVEY.md A.5's 1e-4 of the tensor's max.
+"""
+import torch
+import torch.nn.functional as F
+
+from critic_vae_amd import synth
+from oracle import cvae_oracle as orc
+
+ENC = [(32, 64), (64, 32), (128, 16), (256, 8)]       # (channels, conv output size at width 64)
+DEC = [(128, 4), (64, 8), (32, 16), (32, 32)]
+TIE_TOL = 1e-5          # |difference to a tie| of a flipped unit, in units of the normalised / pre-activation value (O(1))
+
+
+def hip_decisions(vae, B):
+    ws, h, k = vae._workspace(B), vae.handle, vae.width // 64
+
+    def view(name, c, s):
+        return h.ws_view(ws, B, name, B * s * s * c).view(B, s, s, c).permute(0, 3, 1, 2)
+
+    dec = {}
+    for l, (c, s) in enumerate(ENC):
+        s *= k
+        y = view(f"y{l}", c, s).double()
+        coef = h.ws_view(ws, B, f"coef{l}", c * 4).view(c, 4).double()
+        # the kernels take the first maximum of fmaf(y, scale, shift): the correctly rounded fp32 value
+        n = (y * coef[:, 0].view(1, c, 1, 1) + coef[:, 1].view(1, c, 1, 1)).float()
+        dec[f"pool{l}"] = F.max_pool2d(n, 2, return_indices=True)[1].cpu()
+        dec[f"relu_enc{l}"] = (view(f"a{l}", c, s // 2) > 0).cpu()
+    for i, (c, s) in enumerate(DEC):
+        dec[f"relu_dec{i}"] = (view(f"o{i}", c, s * k) > 0).cpu()
+    return dec
+
+
+def oracle_decisions(taps):
+    dec = {}
+    for l in range(4):
+        dec[f"pool{l}"] = F.max_pool2d(taps[f"enc_n{l}"].detach(), 2, return_indices=True)[1]
+        dec[f"relu_enc{l}"] = taps[f"enc_a{l}"].detach() > 0
+    for i in range(4):
+        dec[f"relu_dec{i}"] = taps[f"dec_o{i}"].detach() > 0
+    return dec
+
+
+def flips(d_hip, d_orc, taps):
+    """[(decision name, number of flipped units, largest distance to a tie among them)]"""
+    out = []
+    for k in d_hip:
+        f = d_hip[k] != d_orc[k]
+        nf = int(f.sum())
+        if not nf:
+            continue
+        idx = int(k[-1])
+        if k.startswith("pool"):
+            n = taps[f"enc_n{idx}"].detach()
+            a = n.flatten(2).gather(2, d_hip[k].flatten(2)).view(f.shape)
+            b = n.flatten(2).gather(2, d_orc[k].flatten(2)).view(f.shape)
+            gap = float((a - b).abs()[f].max())
+        elif k.startswith("relu_enc"):
+            gap = float(F.max_pool2d(taps[f"enc_n{idx}"].detach(), 2).abs()[f].max())
+        else:
+            gap = float(taps[f"dec_pre{idx}"].detach().abs()[f].max())
+        out.append((k, nf, gap))
+    return out
+
+
+def is_pre_bn_bias(name):
+    """Conv biases followed by train-mode BatchNorm: true gradient 0, reference value pure round-off."""
+    return name.startswith("encoder.model.") and name.endswith(".bias") and int(name.split(".")[2]) % 4 == 0
+
+
+def check_step_against_oracle(vae, x, pred, eps, B, wseed=0, tol=1e-4, rel=1e-4, max_flips=64, verbose=False):
+    """After vae's forward+loss+backward on (x, pred, eps): outputs / loss / every gradient element at `tol`
+    absolute vs the plain oracle; flipped decisions counted and shown to be ties; every gradient element at
+    `rel` x the tensor's max vs the oracle with the HIP decisions imposed.  Returns a small report."""
+    W = vae.width
+    params = synth.make_params(wseed, W)
+    p = orc.to_torch(params, requires_grad=True)
+    taps = {}
+    o = orc.train_step(p, x, pred, eps, bn_state=orc.new_bn_state(p), taps=taps)
+    g_hip = {k: v.detach().cpu().double() for k, v in vae.reference_grads().items()}
+    rep = {"abs": 0.0, "rel_plain": 0.0, "rel_forced": 0.0, "flips": []}
+    if not torch.isfinite(o["total_loss"]):
+        return None, o
+    for k, v in p.items():
+        e = float((g_hip[k] - v.grad.double()).abs().max())
+        rep["abs"] = max(rep["abs"], e)
+        assert e <= tol, f"{k}: abs err {e:.3e}"
+        if not is_pre_bn_bias(k):
+            rep["rel_plain"] = max(rep["rel_plain"], e / max(float(v.grad.abs().max()), 1e-30))
+    d_hip, d_orc = hip_decisions(vae, B), oracle_decisions(taps)
+    rep["flips"] = flips(d_hip, d_orc, taps)
+    n_units = sum(v.numel() for v in d_hip.values())
+    n_flips = sum(f[1] for f in rep["flips"])
+    assert n_flips <= max_flips, f"{n_flips} decision flips among {n_units} units: {rep['flips']}"
+    for k, nf, gap in rep["flips"]:
+        assert gap <= TIE_TOL, f"{k}: {nf} flipped unit(s) up to {gap:.3e} away from a tie — not round-off"
+    if n_flips:
+        p2 = orc.to_torch(params, requires_grad=True)
+        orc.train_step(p2, x, pred, eps, bn_state=orc.new_bn_state(p2), decisions=d_hip)
+        want = {k: v.grad.double() for k, v in p2.items()}
+    else:
+        want = {k: v.grad.double() for k, v in p.items()}
+    for k, w in want.items():
+        if is_pre_bn_bias(k):
+            continue
+        scale = max(float(w.abs().max()), 1e-30)
+        e = float((g_hip[k] - w).abs().max())
+        rep["rel_forced"] = max(rep["rel_forced"], e / scale)
+        assert e <= rel * scale, f"{k}: err {e:.3e} vs max|g| {scale:.3e} (decisions imposed; {n_flips} flips)"
+    if verbose:
+        print(f"B={B} W={W}: abs {rep['abs']:.2e}  rel(plain) {rep['rel_plain']:.2e}  flips {rep['flips']}  "
+              f"rel(decisions imposed) {rep['rel_forced']:.2e}")
+    return rep, o

@@ -240,6 +240,73 @@ def critic_case(batch=8):
     print(f"[critic] preds {ref.numpy().reshape(-1)[:4]}")
 
 
+def inference_case(batch=5, wseed=0, dseed=1234, width=64):
+    """The reference's own inference API (vae_nets.py:31-46): three train-mode steps (forward + loss +
+    backward, weights untouched) so that the BatchNorm running statistics are non-trivial, then .eval()
+    and, per frame, encoder(x) / evaluate(x, pred) / evaluate(x, 0) / inject(x) exactly as
+    vae_utility.get_diff_image (vae_utility.py:256-277) and vae.py -inject call them (batch of one)."""
+    params_np = synth.make_params(wseed, width)
+    v = load_reference(params_np, width)
+    for s in range(3):
+        xs, ps, es = map(torch.from_numpy, synth.make_batch(dseed, 20 + s, batch, width))
+        v.zero_grad()
+        run_reference_step(v, xs, ps, es)
+    v.eval()
+    x, pred, _ = map(torch.from_numpy, synth.make_batch(dseed, 9, batch, width))
+    op = orc.to_torch(params_np)
+    bn = orc.new_bn_state(op)
+    for s in range(3):
+        xs, ps, es = map(torch.from_numpy, synth.make_batch(dseed, 20 + s, batch, width))
+        p2 = orc.to_torch(params_np, requires_grad=True)
+        orc.train_step(p2, xs, ps, es, bn_state=bn)
+    fx = {"batch": batch, "wseed": wseed, "dseed": dseed, "step": 9, "train_steps": np.array([20, 21, 22]), "width": width}
+    mus, lvs, ev_pred, ev_zero, inj = [], [], [], [], []
+    with torch.no_grad():
+        for i in range(batch):
+            xi = x[i:i + 1]
+            mu, lv = v.encoder(xi)
+            mus.append(mu.numpy()); lvs.append(lv.numpy())
+            ev_pred.append(v.evaluate(xi, pred[i]).numpy())
+            ev_zero.append(v.evaluate(xi, torch.zeros(1)).numpy())
+            inj.append(np.stack([r.numpy() for r in v.inject(xi)]))
+        mu_o, lv_o = orc.encoder(op, x, bn, train=False)
+        r1_o = orc.decoder(op, mu_o, pred)
+    fx["mu"] = np.concatenate(mus); fx["logvar"] = np.concatenate(lvs)
+    ev_pred, ev_zero = np.concatenate(ev_pred), np.concatenate(ev_zero)
+    fx["evaluate_pred_sample"] = ev_pred.reshape(batch, -1)[:, ::4].copy()       # (B, 3072)
+    fx["evaluate_zero_sample"] = ev_zero.reshape(batch, -1)[:, ::4].copy()
+    fx["inject_first_frame_sample"] = inj[0].reshape(6, -1)[:, ::4].copy()       # 6 rewards x 3072
+    grey = (np.abs(ev_zero - ev_pred) * np.array([0.2989, 0.5870, 0.1140], np.float32).reshape(1, 3, 1, 1)).sum(1)
+    fx["diff_max"] = grey.reshape(batch, -1).max(1)
+    for _, bi, _ in orc.ENC_BLOCKS:
+        fx[f"bn_running_mean/{bi}"] = v.encoder.model[bi].running_mean.numpy().copy()
+        fx[f"bn_running_var/{bi}"] = v.encoder.model[bi].running_var.numpy().copy()
+    d = {"mu": np.abs(fx["mu"] - mu_o.numpy()).max(), "logvar": np.abs(fx["logvar"] - lv_o.numpy()).max(),
+         "evaluate": np.abs(ev_pred - r1_o.numpy()).max()}
+    print(f"[inference] reference eval-mode path; oracle-vs-reference max diffs {d}")
+    assert max(d.values()) < 2e-6, d          # batch-of-one vs batched ATen kernels differ in the last ulp
+    np.savez_compressed(os.path.join(HERE, "inference_b5.npz"), **fx)
+
+
+def critic_real_case(batch=8):
+    """Critic.evaluate with the reference's REAL checkpoint (saved-networks/critic-*.pt: a data file, 11 873
+    floats) on generator frames and on uint8 frames through preprocess: weights + predictions stored."""
+    import critic_net
+    d = "/root/reference/saved-networks"
+    ck = sorted(f for f in os.listdir(d) if f.startswith("critic"))[0]
+    sd = torch.load(os.path.join(d, ck), map_location="cpu")
+    c = critic_net.Critic(); c.load_state_dict(sd); c.eval()
+    x = torch.from_numpy(synth.make_batch(1234, 7, batch)[0])
+    ref = c.evaluate(x)
+    mine = orc.critic_forward(sd, x)
+    assert (ref - mine).abs().max().item() < 1e-7
+    fx = {"checkpoint": ck, "batch": batch, "dseed": 1234, "step": 7, "pred": ref.numpy()}
+    for k, t in sd.items():
+        fx["w/" + k] = t.numpy()
+    np.savez_compressed(os.path.join(HERE, "critic_real_b8.npz"), **fx)
+    print(f"[critic-real] {ck[:30]}... preds {ref.numpy().reshape(-1)[:4]}")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     step_case("b2", 2)
@@ -247,5 +314,7 @@ if __name__ == "__main__":
     step_case("w128_b2", 2, width=128)
     msssim_cases()
     critic_case()
+    critic_real_case()
+    inference_case()
     trajectory_case()
     print("goldens written to", HERE)

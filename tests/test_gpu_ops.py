@@ -266,3 +266,9 @@ def test_critic_forward_and_preprocess(H, golden_dir, scale):
     pre = crit.preprocess(u8.cuda())
     torch.cuda.synchronize()
     assert torch.equal(pre.cpu(), orc.preprocess_frames(u8))
+    if scale == 1.0:        # the reference's REAL checkpoint: weights + predictions of its own Critic.evaluate
+        fr = np.load(os.path.join(golden_dir, "critic_real_b8.npz"))
+        crit.load_state_dict({k[2:]: torch.from_numpy(fr[k]) for k in fr.files if k.startswith("w/")})
+        got = crit.evaluate(x.cuda())
+        torch.cuda.synchronize()
+        check(got, torch.from_numpy(fr["pred"]), "critic pred, real checkpoint vs reference fixture", 2e-6)

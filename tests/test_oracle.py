@@ -106,3 +106,42 @@ def test_critic_matches_reference_fixture(golden_dir):
     assert pred.shape == (int(fx["batch"]), 1) and np.abs(pred.numpy() - fx["pred"]).max() < 1e-6
     pre = orc.preprocess_frames(torch.from_numpy(fx["u8"]))
     assert pre.shape == (4, 3, 64, 64) and np.array_equal(pre.numpy()[:, :, ::8, ::8], fx["u8_pre"])
+
+
+def test_critic_real_checkpoint_fixture(golden_dir):
+    """The reference's real critic checkpoint (saved-networks/critic-*.pt; weights + predictions stored by
+    make_golden.critic_real_case from the reference's own Critic.evaluate)."""
+    fx = np.load(os.path.join(golden_dir, "critic_real_b8.npz"))
+    cp = {k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("w/")}
+    assert sum(v.numel() for v in cp.values()) == 11873
+    x, _, _ = synth.make_batch(int(fx["dseed"]), int(fx["step"]), int(fx["batch"]))
+    pred = orc.critic_forward(cp, torch.from_numpy(x))
+    assert np.abs(pred.numpy() - fx["pred"]).max() < 1e-6
+    assert fx["pred"].std() > 0.01          # a trained network: predictions really depend on the frame
+
+
+def test_inference_path_matches_reference_fixture(golden_dir):
+    """Eval-mode leg (BatchNorm running statistics; decoder(mu, pred)) against the reference's own
+    evaluate / inject (vae_nets.py:31-46) after three train-mode steps."""
+    fx = np.load(os.path.join(golden_dir, "inference_b5.npz"))
+    B, W = int(fx["batch"]), int(fx["width"])
+    params_np = synth.make_params(int(fx["wseed"]), W)
+    bn = orc.new_bn_state(orc.to_torch(params_np))
+    for s in fx["train_steps"]:
+        xs, ps, es = map(torch.from_numpy, synth.make_batch(int(fx["dseed"]), int(s), B, W))
+        orc.train_step(orc.to_torch(params_np, requires_grad=True), xs, ps, es, bn_state=bn)
+    for _, bi, _ in orc.ENC_BLOCKS:
+        assert np.abs(bn[f"encoder.model.{bi}.running_mean"].numpy() - fx[f"bn_running_mean/{bi}"]).max() < TOL
+        assert np.abs(bn[f"encoder.model.{bi}.running_var"].numpy() - fx[f"bn_running_var/{bi}"]).max() < TOL
+    p = orc.to_torch(params_np)
+    x, pred, _ = map(torch.from_numpy, synth.make_batch(int(fx["dseed"]), int(fx["step"]), B, W))
+    with torch.no_grad():
+        mu, lv = orc.encoder(p, x, bn, train=False)
+        r1 = orc.decoder(p, mu, pred)
+        r0 = orc.decoder(p, mu, torch.zeros(B, 1))
+        inj = [orc.decoder(p, mu[:1], torch.full((1, 1), r)) for r in (0, 0.2, 0.4, 0.6, 0.8, 1.0)]
+    assert np.abs(mu.numpy() - fx["mu"]).max() < TOL and np.abs(lv.numpy() - fx["logvar"]).max() < TOL
+    assert np.abs(r1.numpy().reshape(B, -1)[:, ::4] - fx["evaluate_pred_sample"]).max() < TOL
+    assert np.abs(r0.numpy().reshape(B, -1)[:, ::4] - fx["evaluate_zero_sample"]).max() < TOL
+    got = np.stack([r.numpy().reshape(-1)[::4] for r in inj])
+    assert np.abs(got - fx["inject_first_frame_sample"]).max() < TOL

@@ -190,20 +190,27 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ y
 // ReLU blocks: the two backward sums need only the POOLED tensors.  g = da*[a>0]; at the window argmax
 // the normalised value is n = a (ReLU passed it through), and xhat = (n - beta)/gamma, so
 // sum(g) and sum(g*xhat) never touch the full-resolution y (3x less traffic than bn_bwd_kernel<0,0>).
+// Channels whose |gamma| is small (< 1e-2; exactly 0 included) cannot use that shortcut — the division
+// amplifies the rounding of a by 1/|gamma| and is undefined at 0 — and take xhat from y at the recomputed
+// argmax instead (the bn_bwd_kernel<0,0> formula), so dgamma stays correct and such a channel can recover.
 __global__ __launch_bounds__(256) void bn_bwd_stats_relu_kernel(const float* __restrict__ a, const float* __restrict__ da,
                                                                 const float* __restrict__ coef, float* __restrict__ part,
-                                                                int C, int64_t totalPx, int64_t pxPerBlk) {
+                                                                int C, int64_t totalPx, int64_t pxPerBlk,
+                                                                const float* __restrict__ y, int H) {
     __shared__ float red[2][256][4];
-    const int C4 = C / 4, c4 = threadIdx.x % C4, sub = threadIdx.x / C4, NSUB = 256 / C4;
+    const int C4 = C / 4, c4 = threadIdx.x % C4, sub = threadIdx.x / C4, NSUB = 256 / C4, HO = H / 2;
     float gam[4], bet[4];
+    bool tiny[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int c = c4 * 4 + e;
         const float scale = coef[c * 4], shift = coef[c * 4 + 1], mean = coef[c * 4 + 2], invstd = coef[c * 4 + 3];
         const float g = scale / invstd;                       // gamma
-        gam[e] = fabsf(g) > 1e-30f ? 1.0f / g : 0.f;
+        tiny[e] = !(fabsf(g) >= 1e-2f);
+        gam[e] = tiny[e] ? 0.f : 1.0f / g;
         bet[e] = shift + mean * scale;                        // beta
     }
+    const bool any_tiny = tiny[0] || tiny[1] || tiny[2] || tiny[3];
     const int64_t p0 = blockIdx.x * pxPerBlk;
     int64_t p1 = p0 + pxPerBlk; if (p1 > totalPx) p1 = totalPx;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -216,6 +223,19 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_relu_kernel(const float* __r
             const float g = aa[e] > 0.f ? gg[e] : 0.f;
             s1[e] += g;
             s2[e] += g * ((aa[e] - bet[e]) * gam[e]);
+        }
+        if (any_tiny) {
+            const int px = (int)(pp % HO), py = (int)((pp / HO) % HO);
+            const int64_t ib = pp / ((int64_t)HO * HO);
+            const float* base = y + ((ib * H + 2 * py) * H + 2 * px) * C;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (!tiny[e]) continue;
+                const int c = c4 * 4 + e;
+                int pos; float xh; float yv[4];
+                window_argmax(base, H, C, c, coef[c * 4], coef[c * 4 + 1], coef[c * 4 + 2], coef[c * 4 + 3], &pos, &xh, yv);
+                s2[e] += (aa[e] > 0.f ? gg[e] : 0.f) * xh;
+            }
         }
     }
 #pragma unroll
@@ -308,7 +328,7 @@ int launch_bn_pool_act_bwd(int layer, int width, int B, const float* y, const fl
     float* crws = red + 2 * g.C;
     const float invN = 1.0f / (float)((double)B * g.H * g.H);
     if (g.act) hipLaunchKernelGGL((bn_bwd_kernel<1, 0>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, nullptr, nullptr, part, g.C, g.H, totalPx, ppb);
-    else hipLaunchKernelGGL(bn_bwd_stats_relu_kernel, dim3(nblk), dim3(256), 0, st, a, da, coef, part, g.C, totalPx, ppb);
+    else hipLaunchKernelGGL(bn_bwd_stats_relu_kernel, dim3(nblk), dim3(256), 0, st, a, da, coef, part, g.C, totalPx, ppb, y, g.H);
     CVAE_CHECK_LAUNCH();
     const float* rows; int R; int64_t rstride;
     { int rc = launch_col_reduce_partial(part, nblk, 2 * g.C, 2 * g.C, crws, st, &rows, &R, &rstride); if (rc) return rc; }

@@ -35,6 +35,22 @@ def single_rank_grad(r):
     return tr.grads.clone()
 
 
+# replicas built from DIFFERENT seeds (seed=None draws from each process's own RNG in real use) must be
+# identical once a data-parallel trainer exists: FusedTrainer broadcasts rank 0's parameters, BatchNorm
+# statistics and Adam state (torch DDP does the same)
+vae_d = VariationalAutoencoder(max_batch=per, seed=100 + rank).to(dev)
+before = vae_d.theta.data.clone()
+tr_d = FusedTrainer(vae_d, world_size=world)
+r0 = vae_d.theta.data.clone()
+dist.broadcast(r0, src=0)
+assert torch.equal(r0, vae_d.theta.data), "replicas differ after FusedTrainer construction"
+assert rank == 0 or not torch.equal(before, vae_d.theta.data)
+tr_d.step(*batch(rank))
+r0 = vae_d.theta.data.clone()
+dist.broadcast(r0, src=0)
+assert torch.equal(r0, vae_d.theta.data), "replicas diverged after one step"
+del vae_d, tr_d
+
 want_grad = (single_rank_grad(0) + single_rank_grad(1))      # FusedTrainer keeps the SUM; 1/N is folded into Adam
 results = {}
 for overlap in (True, False):

@@ -57,3 +57,49 @@ def test_bucketed_allreduce_path_on_rccl_single_rank():
                        timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "DP_NCCL_OK" in r.stdout
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` from plain python (no torchrun environment) starts the ranks itself; on the
+    one-GPU test box both ranks share device 0 and gloo carries the collectives."""
+    import json
+    env = dict(os.environ, CVAE_DIST_BACKEND="gloo", CVAE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--batch", "16"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    d = res["config"]["distributed"]
+    assert res["n_gpus"] == 2 and d["ranks_counted_by_allreduce"] == 2 and d["world_size"] == 2
+    assert d["backend"] == "gloo" and d["rank_devices"] == [0, 0] and d["allreduce_exposed_us"] is not None
+    assert res["config"]["global_batch"] == 32 and res["value"] > 0 and res["config"]["loss_finite"]
+
+
+def test_two_handles_are_independent():
+    """One handle per configuration, no shared state: two handles of different frame size / precision used
+    alternately give bit-identical results to each one used alone."""
+    import torch
+    from critic_vae_amd import synth
+    from critic_vae_amd.nets import VariationalAutoencoder
+    from critic_vae_amd.train import FusedTrainer
+    dev = torch.device("cuda:0")
+
+    def run(specs, interleave):
+        trs = [FusedTrainer(VariationalAutoencoder(width=w, max_batch=4, seed=0, precision=pr).to(dev)) for w, pr in specs]
+        outs = [[] for _ in specs]
+        order = [(i, s) for s in range(2) for i in range(len(specs))] if interleave else \
+                [(i, s) for i in range(len(specs)) for s in range(2)]
+        for i, s in order:
+            x, pred, eps = (torch.from_numpy(a).to(dev) for a in synth.make_batch(1234, s, 4, specs[i][0]))
+            outs[i].append(trs[i].step(x, pred, eps).clone())
+        torch.cuda.synchronize()
+        return [torch.stack(o) for o in outs], [t.vae.theta.data.clone() for t in trs]
+
+    specs = [(64, "f32"), (128, "f32"), (64, "bf16")]
+    a_s, a_t = run(specs, interleave=True)
+    b_s, b_t = run(specs, interleave=False)
+    for i in range(len(specs)):
+        assert torch.isfinite(a_s[i][:, :3]).all()
+        assert torch.equal(a_s[i], b_s[i]) and torch.equal(a_t[i], b_t[i]), specs[i]

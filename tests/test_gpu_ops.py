@@ -79,8 +79,13 @@ def test_conv_fwd(H, layer, B):
 
 
 @pytest.mark.parametrize("layer", range(4))
-@pytest.mark.parametrize("B,ties", [(3, False), (8, True)])
+@pytest.mark.parametrize("B,ties", [(3, False), (8, True), (5, "tiny_gamma")])
 def test_bn_pool_act_fwd_bwd(H, layer, B, ties):
+    """ties=True: exact max-pool ties + negative gamma.  "tiny_gamma": channels with gamma = 0 / 3e-3 / -5e-3 —
+    the ReLU blocks' pooled-tensor shortcut xhat = (a - beta)/gamma is ill-conditioned there and the kernel
+    must fall back to y (dgamma of a zero-gamma channel is sum(g*xhat), not 0)."""
+    tiny = ties == "tiny_gamma"
+    ties = ties is True
     cin, C, h, _ = LAYERS[layer]
     act = "tanh" if layer == 3 else "relu"
     x = rnd(f"bx{layer}", (B, cin, h, h))
@@ -95,6 +100,9 @@ def test_bn_pool_act_fwd_bwd(H, layer, B, ties):
     beta = rnd(f"be{layer}", (C,), -0.5, 0.5)
     if ties:
         gamma[::3] *= -1            # negative scale flips which element is the maximum
+    if tiny:
+        gamma[0], gamma[5], gamma[9] = 0.0, 3e-3, -5e-3
+        beta[0], beta[5], beta[9] = 0.3, 0.5, 0.2          # ReLU lets these channels through
     # conv on the GPU provides y and the BatchNorm partials
     y = torch.empty(B * h * h * C, device="cuda")
     part = torch.zeros(H.op_bn_partial_floats(layer, B), device="cuda")

@@ -59,6 +59,18 @@ def test_bad_arguments_return_errors_not_crashes():
     assert h.workspace_bytes(4) > 0 and h.workspace_bytes(4) % 4 == 0
 
 
+def test_two_handles_do_not_share_state():
+    """include/cvae.h: one handle per device / configuration, no global state."""
+    a, b = cvlib.Handle(64, 4), cvlib.Handle(128, 2, precision="bf16")
+    assert a.h.value != b.h.value
+    assert a.layout["fc.w"][1] == 4096 * 64 and b.layout["fc.w"][1] == 16384 * 64
+    wa = a.workspace_bytes(4)
+    del b
+    assert a.workspace_bytes(4) == wa and a.lib.cvae_param_count(a.h) == 30
+    # the documented names are the library's native ones (include/cvae.h), not reference state_dict keys
+    assert a.lib.cvae_param_name(a.h, 0) == b"enc0.w" and "decin.b" in a.layout
+
+
 def test_data_parallel_two_ranks_gloo():
     """N-rank all-reduced gradient == mean over ranks of the single-rank (oracle) gradient on that
     rank's shard, through the same flat native buffer the GPU path reduces."""

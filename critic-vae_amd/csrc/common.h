@@ -55,6 +55,30 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// In-launch "last workgroup to arrive" (cdna guide §6 Guideline 16, counter form; placement-independent): every wave
+// drains its stores, the workgroup meets, ONE lane releases at agent scope, drains again and draws a ticket; the
+// workgroup that draws total-1 acquires at agent scope and may then read, with plain loads, everything the other
+// workgroups stored before they arrived.  Returns the same answer in every thread.  *counter must be 0 when the
+// launch starts (zeroed by an EARLIER launch on the stream); the last arriver puts it back to 0.
+__device__ __forceinline__ bool wg_arrive_last(unsigned* counter, unsigned total, unsigned* lds_word) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = t == total - 1;
+        if (last) {
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *lds_word = last ? 1u : 0u;
+    }
+    __syncthreads();
+    return *lds_word != 0u;
+}
+
 // Optional in-step kernel probe (api.hip): the launchers bracket their MAIN kernel with a HIP event
 // pair on the stream it is launched on when the orchestration armed a slot (bench.py roofline).
 void cvae_probe_begin(hipStream_t st);

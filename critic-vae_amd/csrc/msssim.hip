@@ -10,13 +10,17 @@
 // The 2-D window is the outer product of the 1-D one (vae_nets.py:176-177) so the filter is run
 // as 11+11 taps (summation order differs from the 121-tap ATen conv by ~1e-7 relative).
 //
-// Per level one forward kernel: horizontal pass of {x, y, x^2, y^2, xy} into LDS, vertical pass,
-// SSIM/CS maps, per-workgroup partial sums, the 2x2 average for the next level, and — for the
-// backward — the three derivative maps of the level's contributing map w.r.t. (mu1, E[x^2],
-// E[xy]).  One finalize workgroup reduces everything in fp64 in a fixed order, evaluates the
-// loss, the KLD (+ its gradients) and the per-level gradient coefficients; the backward kernels
-// run the same separable filter over the derivative maps, top level first, adding the
-// average-pool backward of the level above.  Only cs_0..3 and ssim_4 carry gradient.
+// Structure (round 2): the loss is L = 1 - prod(mean_l ^ w_l), so dL/dx_l = coef_l * F_l with
+//   F_l = win * u_mu + 2 x (win * u_11) + y (win * u_12),   u_* = d map_l / d (mu1, E[x^2], E[xy])
+// where only the scalar coef_l depends on the global means.  ONE forward kernel per level computes the five
+// filtered maps on the tile EXTENDED by the window radius, the SSIM/CS partial sums on the tile itself, the
+// three derivative maps in LDS (never in HBM), filters them again and stores the single field F_l plus the
+// 2x2 average for the next level.  Levels 16/8/4 run in one launch (one workgroup per plane, everything in
+// LDS).  The finalize runs on 32 workgroups; the last one to arrive (release/acquire ticket) merges their
+// fp64 partials in a fixed order, evaluates the loss, the KLD (+ its gradients) and the five coefficients.
+// The backward is ONE elementwise pass: dx = c0 F0 + 1/4 up(c1 F1 + 1/4 up(c2 F2 + ...)) (avg_pool2d backward).
+// HBM traffic: forward reads x, y once and writes F (+ 1/4-size pyramids); backward reads the F pyramid and
+// writes dx — 1.2x the algorithmic bytes (was 3.2x / 2.5x with the derivative maps stored).
 #include "common.h"
 #include <math.h>
 
@@ -32,90 +36,143 @@ static MsWin make_window() {
     return m;
 }
 
-template <int S>
-struct MsGeom {
-    static constexpr int RS = S < 16 ? S : 16;                    // rows per workgroup
-    static constexpr int PPB = (RS * S >= 256) ? 1 : 256 / (RS * S);   // planes per workgroup
-    static constexpr int HR = RS + 10, HC = S + 10;
-    static constexpr int STRIPS = S / RS;
-};
+static constexpr int MS_NF = 32;            // finalize workgroups
+static constexpr int MS_NT = 512;           // threads of a tile workgroup (two workgroups per CU: 4 waves per SIMD)
 
-// zero-padded load of NMAP planes' strips into LDS: dst[map][plane][HR][HC]
-template <int S, int NMAP>
-__device__ __forceinline__ void ms_load(const float* const (&src)[NMAP], float* dst, int plane0, int P, int r0) {
-    using G = MsGeom<S>;
-    constexpr int PER = G::PPB * G::HR * G::HC;
-    if constexpr (S >= 32) {          // one plane per workgroup: 16-byte row loads of the interior + zeroed 5-column borders
-        constexpr int C4 = S / 4;
-        const bool plane_ok = plane0 < P;
-        for (int q = threadIdx.x; q < G::HR * C4; q += 256) {
-            const int rr = q / C4, c = (q % C4) * 4, r = r0 - 5 + rr;
-            const bool ok = plane_ok && (unsigned)r < (unsigned)S;
-#pragma unroll
-            for (int mI = 0; mI < NMAP; ++mI) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok) v = *reinterpret_cast<const f32x4*>(src[mI] + ((size_t)plane0 * S + r) * S + c);
-                float* d = dst + mI * PER + rr * G::HC + 5 + c;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-        }
-        for (int q = threadIdx.x; q < G::HR * 10; q += 256) {
-            const int rr = q / 10, k = q % 10, col = k < 5 ? k : S + k;       // columns 0..4 and S+5..S+9
-#pragma unroll
-            for (int mI = 0; mI < NMAP; ++mI) dst[mI * PER + rr * G::HC + col] = 0.f;
-        }
-        return;
-    }
-    for (int q = threadIdx.x; q < PER; q += 256) {
-        const int pl = q / (G::HR * G::HC), rem = q % (G::HR * G::HC);
-        const int r = r0 - 5 + rem / G::HC, c = rem % G::HC - 5;
-        const bool ok = (unsigned)r < (unsigned)S && (unsigned)c < (unsigned)S && plane0 + pl < P;
-#pragma unroll
-        for (int mI = 0; mI < NMAP; ++mI)
-            dst[mI * PER + q] = ok ? src[mI][((size_t)(plane0 + pl) * S + r) * S + c] : 0.f;
-    }
+// 1/x to ~0.5 ulp: v_rcp_f32 + one Newton step (3 instructions instead of the ~11 of an IEEE division; the
+// denominators are >= C1 / C2 minus round-off, far from the denormal range)
+__device__ __forceinline__ float ms_rcp(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
 }
+
+// SSIM / CS value of one point and the derivatives of the level's contributing map (cs_map; ssim_map on the
+// last level) w.r.t. (mu1, E[x^2], E[xy]) — vae_nets.py:201-215 and its autograd
+__device__ __forceinline__ void ms_point(float mu1, float mu2, float a11, float a22, float a12, bool last,
+                                         float* ssim, float* cs, float* dm, float* d11, float* d12) {
+    const float C1 = 0.0001f, C2 = 0.0009f;
+    const float mu1sq = mu1 * mu1, mu2sq = mu2 * mu2, mu12 = mu1 * mu2;
+    const float v1 = 2.0f * (a12 - mu12) + C2;
+    const float v2 = (a11 - mu1sq) + (a22 - mu2sq) + C2;
+    const float inv2 = ms_rcp(v2);
+    const float c = v1 * inv2;
+    const float num = 2.0f * mu12 + C1, den = mu1sq + mu2sq + C1;
+    const float invden = ms_rcp(den);
+    const float lum = num * invden;
+    *cs = c;
+    *ssim = lum * c;
+    float m = (2.0f * mu1 * c - 2.0f * mu2) * inv2;
+    float e11 = -c * inv2;
+    float e12 = 2.0f * inv2;
+    if (last) {
+        const float dlum = (2.0f * mu2 - 2.0f * mu1 * lum) * invden;
+        m = dlum * c + lum * m; e11 *= lum; e12 *= lum;
+    }
+    *dm = m; *d11 = e11; *d12 = e12;
+}
+
+// ------------------------------------------------------------------------------------------------
+// large levels (S = 128, 64, 32): one workgroup per (plane, RS x CS tile)
+// ------------------------------------------------------------------------------------------------
+template <int S>
+struct MsT {
+    static constexpr int CS = S < 64 ? S : 64;             // tile columns
+    static constexpr int RS = S == 32 ? 32 : 16;           // tile rows
+    static constexpr int TX = S / CS, TY = S / RS, TILES = TX * TY;
+    static constexpr int ER = RS + 20;                      // input rows staged (tile + 2 window radii)
+    static constexpr int MR = RS + 10, MC = CS + 10;        // map region (tile + 1 window radius)
+    static constexpr int MCP = ((MC + 3) / 4) * 4;          // map row stride (4 outputs per H item)
+    static constexpr int ECP = MCP + 12;                    // input row stride: the last H item reads 14 columns
+    static constexpr int LIN = 2 * ER * ECP;                // floats: x | y halo images; later the 3 derivative maps
+    static constexpr int TMP = 5 * ER * MCP;                // floats: 5 row-filtered maps; later the 3 row-filtered derivative maps
+    static constexpr int SMEM = (LIN + TMP) * 4;
+    static_assert(3 * MR * MCP <= LIN, "derivative maps must fit in the input halo buffer");
+    static_assert(3 * MR * CS <= TMP, "row-filtered derivative maps must fit in the tmp buffer");
+    static_assert(MC % 2 == 0 && MR % 2 == 0, "2x2 blocking of the vertical passes");
+};
 
 struct MsFwdArgs {
     const float* x;       // img1 at this level (carries grad)
     const float* y;       // img2
-    float* nx; float* ny; // next level (2x2 averages) or null
-    float* um; float* u11; float* u12;   // derivative maps or null
-    float* part;          // [numBlocks][2]
+    float* nx; float* ny; // next level (2x2 averages)
+    float* F;             // gradient field of this level (null: forward only)
+    float* part;          // [numBlocks][2] (ssim sum, cs sum)
+    unsigned* ticket;     // finalize arrival counter: zeroed here, a launch boundary ahead of its use
     int P;
-    int last;             // level 4: the contributing map is ssim_map instead of cs_map
     MsWin win;
 };
 
 template <int S>
-__global__ __launch_bounds__(256) void msssim_fwd_kernel(MsFwdArgs a) {
-    using G = MsGeom<S>;
-    constexpr int PER_IN = G::PPB * G::HR * G::HC, PER_T = G::PPB * G::HR * S;
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // 2*PER_IN + 5*PER_T floats
-    __shared__ float red[8];
-    float* lin = smem;
-    float* tmp = smem + 2 * PER_IN;
-    const int plane0 = (blockIdx.x / G::STRIPS) * G::PPB, r0 = (blockIdx.x % G::STRIPS) * G::RS;
-    const float* const srcs[2] = {a.x, a.y};
-    ms_load<S, 2>(srcs, lin, plane0, a.P, r0);
-    __syncthreads();
+__global__ __launch_bounds__(MS_NT) void msssim_fwd_kernel(MsFwdArgs a) {
+    using T = MsT<S>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float red[2 * (MS_NT / 64)];
+    float* lin = smem;                 // [2][ER][ECP]
+    float* tmp = smem + T::LIN;        // [5][ER][MCP]
+    const int blk = xcd_tile(blockIdx.x, gridDim.x);
+    const int plane = blk / T::TILES, tile = blk % T::TILES;
+    const int r0 = (tile / T::TX) * T::RS, c0 = (tile % T::TX) * T::CS;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.ticket) *a.ticket = 0u;
     float w[11];
 #pragma unroll
     for (int t = 0; t < 11; ++t) w[t] = a.win.w[t];
-    // horizontal pass.  Large levels (one plane per workgroup): 4 adjacent outputs per work item from
-    // a 14-wide register window (3.5 LDS reads per output instead of 22); same fma order per output.
-    if constexpr (S >= 32) {
-        constexpr int CG = S / 4;
-        for (int it = threadIdx.x; it < G::HR * CG; it += 256) {
-            const int r = it / CG, c = (it % CG) * 4;
-            const float* px = lin + r * G::HC + c;
-            const float* py = px + PER_IN;
-            float xs[14], ys[14];
+    // ---- stage the zero-padded input halos: image rows r0-10 .. r0+RS+9, columns c0-10 .. (8-byte units).
+    //      All global loads are issued before the first LDS write (one HBM latency per tile, not one per row) ----
+    {
+        constexpr int U = T::ECP / 2, NIT = (T::ER * U + MS_NT - 1) / MS_NT;
+        const float* px = a.x + (size_t)plane * S * S;
+        const float* py = a.y + (size_t)plane * S * S;
+        float2 vx[NIT], vy[NIT];
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                const float2 u = *reinterpret_cast<const float2*>(px + 2 * i);
-                const float2 v = *reinterpret_cast<const float2*>(py + 2 * i);
-                xs[2 * i] = u.x; xs[2 * i + 1] = u.y; ys[2 * i] = v.x; ys[2 * i + 1] = v.y;
+        for (int k = 0; k < NIT; ++k) {
+            const int q = threadIdx.x + k * MS_NT;
+            const int er = q / U, ec = (q % U) * 2;
+            const int gr = r0 - 10 + er, gc = c0 - 10 + ec;
+            // unconditional loads from a clamped address + select (a branch per element would serialise the loads)
+            const bool ok = q < T::ER * U && (unsigned)gr < (unsigned)S && (unsigned)gc < (unsigned)S && ec < T::MC + 10;
+            const int ga = ok ? gr * S + gc : 0;
+            const float2 lx = *reinterpret_cast<const float2*>(px + ga);
+            const float2 ly = *reinterpret_cast<const float2*>(py + ga);
+            vx[k] = ok ? lx : make_float2(0.f, 0.f);
+            vy[k] = ok ? ly : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int q = threadIdx.x + k * MS_NT;
+            if (q < T::ER * U) {
+                const int er = q / U, ec = (q % U) * 2;
+                *reinterpret_cast<float2*>(lin + er * T::ECP + ec) = vx[k];
+                *reinterpret_cast<float2*>(lin + T::ER * T::ECP + er * T::ECP + ec) = vy[k];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 2x2 average for the next level (avg_pool2d, vae_nets.py:232-233) ----
+    {
+        constexpr int SO = S / 2, PR = T::RS / 2, PC = T::CS / 2;
+        for (int q = threadIdx.x; q < PR * PC; q += MS_NT) {
+            const int pr = q / PC, pc = q % PC;
+            const float* p = lin + (10 + 2 * pr) * T::ECP + 10 + 2 * pc;
+            const float* p2 = p + T::ER * T::ECP;
+            const size_t o = ((size_t)plane * SO + r0 / 2 + pr) * SO + c0 / 2 + pc;
+            a.nx[o] = ((p[0] + p[1]) + (p[T::ECP] + p[T::ECP + 1])) * 0.25f;
+            a.ny[o] = ((p2[0] + p2[1]) + (p2[T::ECP] + p2[T::ECP + 1])) * 0.25f;
+        }
+    }
+    // ---- horizontal pass of {x, y, x^2, y^2, xy}: 4 adjacent outputs per item from a 14-wide register window ----
+    {
+        constexpr int J = T::MCP / 4, PT = T::ER * T::MCP;
+        for (int it = threadIdx.x; it < T::ER * J; it += MS_NT) {
+            const int r = it / J, c = (it % J) * 4;
+            const float* px = lin + r * T::ECP + c;
+            const float* py = px + T::ER * T::ECP;
+            float xs[16], ys[16];            // 16-byte LDS reads (the row stride leaves room for the 2 unused columns)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(px + 4 * i);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(py + 4 * i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { xs[4 * i + e] = u[e]; ys[4 * i + e] = v[e]; }
             }
             f32x4 o0, o1, o2, o3, o4;
 #pragma unroll
@@ -129,138 +186,283 @@ __global__ __launch_bounds__(256) void msssim_fwd_kernel(MsFwdArgs a) {
                 }
                 o0[o] = hx; o1[o] = hy; o2[o] = hxx; o3[o] = hyy; o4[o] = hxy;
             }
-            float* d = tmp + r * S + c;
-            *reinterpret_cast<f32x4*>(d) = o0; *reinterpret_cast<f32x4*>(d + PER_T) = o1;
-            *reinterpret_cast<f32x4*>(d + 2 * PER_T) = o2; *reinterpret_cast<f32x4*>(d + 3 * PER_T) = o3;
-            *reinterpret_cast<f32x4*>(d + 4 * PER_T) = o4;
+            float* d = tmp + r * T::MCP + c;
+            *reinterpret_cast<f32x4*>(d) = o0; *reinterpret_cast<f32x4*>(d + PT) = o1;
+            *reinterpret_cast<f32x4*>(d + 2 * PT) = o2; *reinterpret_cast<f32x4*>(d + 3 * PT) = o3;
+            *reinterpret_cast<f32x4*>(d + 4 * PT) = o4;
         }
-    } else {
-    for (int q = threadIdx.x; q < PER_T; q += 256) {
-        const int pl = q / (G::HR * S), rem = q % (G::HR * S), r = rem / S, c = rem % S;
-        const float* px = lin + (pl * G::HR + r) * G::HC + c;
-        const float* py = px + PER_IN;
-        float hx = 0.f, hy = 0.f, hxx = 0.f, hyy = 0.f, hxy = 0.f;
-#pragma unroll
-        for (int t = 0; t < 11; ++t) {
-            const float xv = px[t], yv = py[t];
-            hx = fmaf(w[t], xv, hx); hy = fmaf(w[t], yv, hy);
-            hxx = fmaf(w[t], xv * xv, hxx); hyy = fmaf(w[t], yv * yv, hyy); hxy = fmaf(w[t], xv * yv, hxy);
-        }
-        tmp[q] = hx; tmp[PER_T + q] = hy; tmp[2 * PER_T + q] = hxx; tmp[3 * PER_T + q] = hyy; tmp[4 * PER_T + q] = hxy;
-    }
     }
     __syncthreads();
-    // vertical pass + maps
-    const float C1 = 0.0001f, C2 = 0.0009f;
+    // ---- vertical pass on the map region + SSIM/CS maps + derivative maps (into the input buffer) ----
     float s_ssim = 0.f, s_cs = 0.f;
-    auto pixel = [&](int pl, int r, int c, float mu1, float mu2, float a11, float a22, float a12) {
-        const float mu1sq = mu1 * mu1, mu2sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float v1 = 2.0f * (a12 - mu12) + C2;
-        const float v2 = (a11 - mu1sq) + (a22 - mu2sq) + C2;
-        const float cs = v1 / v2;
-        const float num = 2.0f * mu12 + C1, den = mu1sq + mu2sq + C1;
-        const float lum = num / den;
-        s_cs += cs;
-        s_ssim += (num * v1) / (den * v2);
-        if (a.um) {
-            // d cs / d(mu1, A11, A12);  level 4: d (lum*cs) / d(...)
-            const float inv2 = 1.0f / v2;
-            float dm = (2.0f * mu1 * cs - 2.0f * mu2) * inv2;
-            float d11 = -cs * inv2;
-            float d12 = 2.0f * inv2;
-            if (a.last) {
-                const float dlum = (2.0f * mu2 - 2.0f * mu1 * lum) / den;
-                dm = dlum * cs + lum * dm; d11 *= lum; d12 *= lum;
-            }
-            const size_t o = ((size_t)(plane0 + pl) * S + r0 + r) * S + c;
-            a.um[o] = dm; a.u11[o] = d11; a.u12[o] = d12;
-        }
-    };
-    if constexpr (S >= 32) {       // 4 vertically adjacent outputs per work item from a 14-deep register window
-        if (plane0 < a.P) {
-            for (int it = threadIdx.x; it < (G::RS / 4) * S; it += 256) {
-                const int c = it % S, rb = (it / S) * 4;
-                float res[5][4];
+    {
+        constexpr int PT = T::ER * T::MCP, DM = T::MR * T::MCP;
+        float* dmap = lin;
+        for (int it = threadIdx.x; it < (T::MR / 2) * (T::MC / 2); it += MS_NT) {
+            const int mr = (it / (T::MC / 2)) * 2, mc = (it % (T::MC / 2)) * 2;
+            float res[5][2][2];
 #pragma unroll
-                for (int mI = 0; mI < 5; ++mI) {
-                    const float* t0 = tmp + mI * PER_T + rb * S + c;
-                    float v[14];
+            for (int mI = 0; mI < 5; ++mI) {
+                const float* t0 = tmp + mI * PT + mr * T::MCP + mc;
+                float2 v[12];
 #pragma unroll
-                    for (int i = 0; i < 14; ++i) v[i] = t0[i * S];
+                for (int i = 0; i < 12; ++i) v[i] = *reinterpret_cast<const float2*>(t0 + i * T::MCP);
 #pragma unroll
-                    for (int o = 0; o < 4; ++o) {
-                        float acc = 0.f;
+                for (int o = 0; o < 2; ++o) {
+                    float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-                        for (int t = 0; t < 11; ++t) acc = fmaf(w[t], v[o + t], acc);
-                        res[mI][o] = acc;
-                    }
+                    for (int t = 0; t < 11; ++t) { a0 = fmaf(w[t], v[o + t].x, a0); a1 = fmaf(w[t], v[o + t].y, a1); }
+                    res[mI][o][0] = a0; res[mI][o][1] = a1;
                 }
+            }
 #pragma unroll
-                for (int o = 0; o < 4; ++o) pixel(0, rb + o, c, res[0][o], res[1][o], res[2][o], res[3][o], res[4][o]);
+            for (int o = 0; o < 2; ++o) {
+                float dmv[2], d11v[2], d12v[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float ss, cs;
+                    ms_point(res[0][o][e], res[1][o][e], res[2][o][e], res[3][o][e], res[4][o][e], false, &ss, &cs,
+                             &dmv[e], &d11v[e], &d12v[e]);
+                    const int r = mr + o, c = mc + e;
+                    const bool interior = r >= 5 && r < 5 + T::RS && c >= 5 && c < 5 + T::CS;
+                    if (interior) { s_ssim += ss; s_cs += cs; }
+                    const bool inside = (unsigned)(r0 - 5 + r) < (unsigned)S && (unsigned)(c0 - 5 + c) < (unsigned)S;
+                    if (!inside) { dmv[e] = 0.f; d11v[e] = 0.f; d12v[e] = 0.f; }      // conv2d zero-pads the maps it filters
+                }
+                float* d = dmap + (mr + o) * T::MCP + mc;
+                *reinterpret_cast<float2*>(d) = make_float2(dmv[0], dmv[1]);
+                *reinterpret_cast<float2*>(d + DM) = make_float2(d11v[0], d11v[1]);
+                *reinterpret_cast<float2*>(d + 2 * DM) = make_float2(d12v[0], d12v[1]);
             }
         }
-    } else {
-    for (int q = threadIdx.x; q < G::PPB * G::RS * S; q += 256) {
-        const int pl = q / (G::RS * S), rem = q % (G::RS * S), r = rem / S, c = rem % S;
-        if (plane0 + pl >= a.P) continue;
-        const float* t0 = tmp + (pl * G::HR + r) * S + c;
-        float mu1 = 0.f, mu2 = 0.f, a11 = 0.f, a22 = 0.f, a12 = 0.f;
-#pragma unroll
-        for (int t = 0; t < 11; ++t) {
-            mu1 = fmaf(w[t], t0[t * S], mu1); mu2 = fmaf(w[t], t0[PER_T + t * S], mu2);
-            a11 = fmaf(w[t], t0[2 * PER_T + t * S], a11); a22 = fmaf(w[t], t0[3 * PER_T + t * S], a22);
-            a12 = fmaf(w[t], t0[4 * PER_T + t * S], a12);
-        }
-        pixel(pl, r, c, mu1, mu2, a11, a22, a12);
-    }
     }
     s_ssim = wave_sum(s_ssim); s_cs = wave_sum(s_cs);
     if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = s_ssim; red[(threadIdx.x >> 6) * 2 + 1] = s_cs; }
-    // 2x2 average for the next level (avg_pool2d, vae_nets.py:232-233)
-    if (a.nx) {
-        constexpr int SO = S / 2;
-        for (int q = threadIdx.x; q < G::PPB * (G::RS / 2) * SO; q += 256) {
-            const int pl = q / ((G::RS / 2) * SO), rem = q % ((G::RS / 2) * SO), pr = rem / SO, pc = rem % SO;
-            if (plane0 + pl >= a.P) continue;
-            const float* px = lin + (pl * G::HR + 2 * pr + 5) * G::HC + 2 * pc + 5;
-            const float* py = px + PER_IN;
-            const size_t o = ((size_t)(plane0 + pl) * SO + r0 / 2 + pr) * SO + pc;
-            a.nx[o] = ((px[0] + px[1]) + (px[G::HC] + px[G::HC + 1])) * 0.25f;
-            a.ny[o] = ((py[0] + py[1]) + (py[G::HC] + py[G::HC + 1])) * 0.25f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < MS_NT / 64; ++k) { t0 += red[2 * k]; t1 += red[2 * k + 1]; }
+        a.part[(size_t)blk * 2] = t0;
+        a.part[(size_t)blk * 2 + 1] = t1;
+    }
+    if (!a.F) return;
+    // ---- the same separable filter over the three derivative maps: horizontal ... ----
+    {
+        constexpr int J = T::CS / 4, DM = T::MR * T::MCP, PT = T::MR * T::CS;
+        const float* dmap = lin;
+        for (int it = threadIdx.x; it < T::MR * J; it += MS_NT) {
+            const int r = it / J, c = (it % J) * 4;
+#pragma unroll
+            for (int mI = 0; mI < 3; ++mI) {
+                const float* p0 = dmap + mI * DM + r * T::MCP + c;
+                float xs[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(p0 + 4 * i);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xs[4 * i + e] = u[e];
+                }
+                f32x4 o4v;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float h = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 11; ++t) h = fmaf(w[t], xs[o + t], h);
+                    o4v[o] = h;
+                }
+                *reinterpret_cast<f32x4*>(tmp + mI * PT + r * T::CS + c) = o4v;
+            }
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        a.part[blockIdx.x * 2] = (red[0] + red[2]) + (red[4] + red[6]);
-        a.part[blockIdx.x * 2 + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+    // ---- ... vertical (2 rows x 1 column per item), then F = f0 + 2 x f1 + y f2 ----
+    {
+        constexpr int PT = T::MR * T::CS;
+        const float* px = a.x + (size_t)plane * S * S;
+        const float* py = a.y + (size_t)plane * S * S;
+        float* pf = a.F + (size_t)plane * S * S;
+        for (int it = threadIdx.x; it < (T::RS / 2) * T::CS; it += MS_NT) {
+            const int r = (it / T::CS) * 2, c = it % T::CS;
+            const size_t g = (size_t)(r0 + r) * S + c0 + c;
+            const float x0 = px[g], x1 = px[g + S], y0 = py[g], y1 = py[g + S];     // L2 hits, issued ahead of the filter
+            float f[3][2];
+#pragma unroll
+            for (int mI = 0; mI < 3; ++mI) {
+                const float* t0 = tmp + mI * PT + r * T::CS + c;
+                float v[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) v[i] = t0[i * T::CS];
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    float a0 = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 11; ++t) a0 = fmaf(w[t], v[o + t], a0);
+                    f[mI][o] = a0;
+                }
+            }
+            pf[g] = f[0][0] + 2.0f * x0 * f[1][0] + y0 * f[2][0];
+            pf[g + S] = f[0][1] + 2.0f * x1 * f[1][1] + y1 * f[2][1];
+        }
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// small levels (16 -> 8 [-> 4]): one workgroup per plane, the pyramid never leaves LDS
+// ------------------------------------------------------------------------------------------------
+struct MsSmallArgs {
+    const float* x; const float* y;     // 16x16 planes
+    float* F[3];                         // gradient fields of the NLEV levels (null: forward only)
+    float* part[3];                      // [P][2] per level
+    int P;
+    MsWin win;
+};
+static constexpr int MS_SMALL_SMEM = (2 * 36 * 36 + 2 * 28 * 28 + 5 * 36 * 26 + 3 * 26 * 26 + 3 * 26 * 16) * 4;
+
+template <int NLEV>
+__global__ __launch_bounds__(256) void msssim_small_kernel(MsSmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float red[8];
+    float* linA = smem;                          // [2][36*36]
+    float* linB = linA + 2 * 36 * 36;            // [2][28*28]
+    float* tmp5 = linB + 2 * 28 * 28;            // [5][36*26]
+    float* dmap = tmp5 + 5 * 36 * 26;            // [3][26*26]
+    float* tmp3 = dmap + 3 * 26 * 26;            // [3][26*16]
+    const int plane = blockIdx.x;
+    float w[11];
+#pragma unroll
+    for (int t = 0; t < 11; ++t) w[t] = a.win.w[t];
+    {
+        const float* px = a.x + (size_t)plane * 256;
+        const float* py = a.y + (size_t)plane * 256;
+        for (int q = threadIdx.x; q < 36 * 36; q += 256) {
+            const int r = q / 36 - 10, c = q % 36 - 10;
+            const bool ok = (unsigned)r < 16u && (unsigned)c < 16u;
+            linA[q] = ok ? px[r * 16 + c] : 0.f;
+            linA[36 * 36 + q] = ok ? py[r * 16 + c] : 0.f;
+        }
+    }
+    __syncthreads();
+    float* lin = linA;
+    float* nxt = linB;
+#pragma unroll
+    for (int lev = 0; lev < NLEV; ++lev) {
+        const int S = 16 >> lev, ER = S + 20, MR = S + 10, LP = ER * ER;
+        const bool last = lev == NLEV - 1;
+        // horizontal pass of the five products
+        for (int q = threadIdx.x; q < ER * MR; q += 256) {
+            const int r = q / MR, m = q % MR;
+            const float* px = lin + r * ER + m;
+            const float* py = px + LP;
+            float hx = 0.f, hy = 0.f, hxx = 0.f, hyy = 0.f, hxy = 0.f;
+#pragma unroll
+            for (int t = 0; t < 11; ++t) {
+                const float xv = px[t], yv = py[t];
+                hx = fmaf(w[t], xv, hx); hy = fmaf(w[t], yv, hy);
+                hxx = fmaf(w[t], xv * xv, hxx); hyy = fmaf(w[t], yv * yv, hyy); hxy = fmaf(w[t], xv * yv, hxy);
+            }
+            const int PT = ER * MR;
+            tmp5[q] = hx; tmp5[PT + q] = hy; tmp5[2 * PT + q] = hxx; tmp5[3 * PT + q] = hyy; tmp5[4 * PT + q] = hxy;
+        }
+        __syncthreads();
+        float s_ssim = 0.f, s_cs = 0.f;
+        for (int q = threadIdx.x; q < MR * MR; q += 256) {
+            const int r = q / MR, m = q % MR, PT = ER * MR;
+            const float* t0 = tmp5 + r * MR + m;
+            float mu1 = 0.f, mu2 = 0.f, a11 = 0.f, a22 = 0.f, a12 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 11; ++t) {
+                mu1 = fmaf(w[t], t0[t * MR], mu1); mu2 = fmaf(w[t], t0[PT + t * MR], mu2);
+                a11 = fmaf(w[t], t0[2 * PT + t * MR], a11); a22 = fmaf(w[t], t0[3 * PT + t * MR], a22);
+                a12 = fmaf(w[t], t0[4 * PT + t * MR], a12);
+            }
+            float ss, cs, dm, d11, d12;
+            ms_point(mu1, mu2, a11, a22, a12, last, &ss, &cs, &dm, &d11, &d12);
+            const bool inside = r >= 5 && r < 5 + S && m >= 5 && m < 5 + S;     // the whole plane is the tile
+            if (inside) { s_ssim += ss; s_cs += cs; } else { dm = 0.f; d11 = 0.f; d12 = 0.f; }
+            dmap[q] = dm; dmap[MR * MR + q] = d11; dmap[2 * MR * MR + q] = d12;
+        }
+        s_ssim = wave_sum(s_ssim); s_cs = wave_sum(s_cs);
+        if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = s_ssim; red[(threadIdx.x >> 6) * 2 + 1] = s_cs; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a.part[lev][(size_t)plane * 2] = (red[0] + red[2]) + (red[4] + red[6]);
+            a.part[lev][(size_t)plane * 2 + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+        }
+        if (a.F[lev]) {
+            for (int q = threadIdx.x; q < MR * S; q += 256) {
+                const int r = q / S, c = q % S;
+                const float* p0 = dmap + r * MR + c;
+                float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+#pragma unroll
+                for (int t = 0; t < 11; ++t) {
+                    h0 = fmaf(w[t], p0[t], h0); h1 = fmaf(w[t], p0[MR * MR + t], h1); h2 = fmaf(w[t], p0[2 * MR * MR + t], h2);
+                }
+                tmp3[q] = h0; tmp3[MR * S + q] = h1; tmp3[2 * MR * S + q] = h2;
+            }
+            __syncthreads();
+            for (int q = threadIdx.x; q < S * S; q += 256) {
+                const int r = q / S, c = q % S;
+                const float* t0 = tmp3 + r * S + c;
+                float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+#pragma unroll
+                for (int t = 0; t < 11; ++t) {
+                    f0 = fmaf(w[t], t0[t * S], f0); f1 = fmaf(w[t], t0[MR * S + t * S], f1); f2 = fmaf(w[t], t0[2 * MR * S + t * S], f2);
+                }
+                const float xv = lin[(10 + r) * ER + 10 + c], yv = lin[LP + (10 + r) * ER + 10 + c];
+                a.F[lev][(size_t)plane * S * S + q] = f0 + 2.0f * xv * f1 + yv * f2;
+            }
+        }
+        if (!last) {            // next level's zero-padded halo images from this level's interior
+            const int SN = S / 2, EN = SN + 20;
+            for (int q = threadIdx.x; q < EN * EN; q += 256) {
+                const int r = q / EN - 10, c = q % EN - 10;
+                float vx = 0.f, vy = 0.f;
+                if ((unsigned)r < (unsigned)SN && (unsigned)c < (unsigned)SN) {
+                    const float* p = lin + (10 + 2 * r) * ER + 10 + 2 * c;
+                    vx = ((p[0] + p[1]) + (p[ER] + p[ER + 1])) * 0.25f;
+                    vy = ((p[LP] + p[LP + 1]) + (p[LP + ER] + p[LP + ER + 1])) * 0.25f;
+                }
+                nxt[q] = vx; nxt[EN * EN + q] = vy;
+            }
+            float* sw = lin; lin = nxt; nxt = sw;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: MS_NF workgroups reduce the partials / the KLD in fp64, the last arriver finishes
+// ------------------------------------------------------------------------------------------------
 struct MsFinArgs {
-    const float* part;       // all levels' partials, level l at partOff[l], nblk[l] pairs
-    int partOff[5], nblk[5];
+    const float* part[5];    // level l: nblk[l] (ssim, cs) pairs
+    int nblk[5];
     double count[5];         // B*3*S_l*S_l
     const float* mu; const float* logvar; int B;
+    double* slab;            // [MS_NF][11]
+    unsigned* ticket;
     float* scalars;          // CVAE_N_SCALARS
     float* coef;             // [5] per-pixel gradient coefficient of each level's map
     float* d_mu; float* d_logvar;
 };
 
-__global__ __launch_bounds__(1024) void msssim_finalize_kernel(MsFinArgs a) {
-    __shared__ double red[11][16];
-    // every thread accumulates all 11 sums (5 x ssim, 5 x cs, KLD) over its strided share, then ONE
-    // block reduction (wave shuffles + 16 wave partials), all in a fixed order
+__global__ __launch_bounds__(256) void msssim_finalize_kernel(MsFinArgs a) {
+    __shared__ double red[11][4];
+    __shared__ unsigned last_flag;
+    // every thread accumulates all 11 sums (5 x ssim, 5 x cs, KLD) over its strided share, one block
+    // reduction, one fp64 row per workgroup — all in a fixed order
     double acc[11];
 #pragma unroll
     for (int q = 0; q < 11; ++q) acc[q] = 0.0;
+    const int gtid = blockIdx.x * 256 + threadIdx.x, gstride = MS_NF * 256;
 #pragma unroll
     for (int l = 0; l < 5; ++l)
-        for (int i = threadIdx.x; i < a.nblk[l]; i += 1024) {
-            acc[l] += (double)a.part[a.partOff[l] + i * 2];
-            acc[5 + l] += (double)a.part[a.partOff[l] + i * 2 + 1];
+        for (int i = gtid; i < a.nblk[l]; i += gstride) {
+            acc[l] += (double)a.part[l][(size_t)i * 2];
+            acc[5 + l] += (double)a.part[l][(size_t)i * 2 + 1];
         }
     const float kw = 0.001f, invB = a.B > 0 ? 1.0f / (float)a.B : 0.f;
-    for (int i = threadIdx.x; i < a.B * 32; i += 1024) {
+    for (int i = gtid; i < a.B * 32; i += gstride) {
         const float m = a.mu[i], lv = a.logvar[i], e = expf(lv);
         acc[10] += (double)(1.0f + lv - m * m - e);
         if (a.d_mu) { a.d_mu[i] = kw * m * invB; a.d_logvar[i] = kw * 0.5f * (e - 1.0f) * invB; }
@@ -271,13 +473,15 @@ __global__ __launch_bounds__(1024) void msssim_finalize_kernel(MsFinArgs a) {
         if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = v;
     }
     __syncthreads();
+    if (threadIdx.x < 11) a.slab[blockIdx.x * 11 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    if (!wg_arrive_last(a.ticket, MS_NF, &last_flag)) return;
     if (threadIdx.x < 64) {
         // lanes 0-4: ssim_l, lanes 5-9: cs_l, lane 10: KLD sum — every lane finishes its own scalar
         // (same operations and order as a serial evaluation), shuffles bring them together
         const int lane = threadIdx.x, l = lane % 5;
         const float wts[5] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
         double t = 0.0;
-        if (lane < 11) for (int wv = 0; wv < 16; ++wv) t += red[lane][wv];
+        if (lane < 11) for (int g = 0; g < MS_NF; ++g) t += a.slab[g * 11 + lane];
         const double cnt = a.count[l];
         const float meanf = (float)(t / cnt);
         const float pw = powf(meanf, wts[l]);
@@ -296,142 +500,64 @@ __global__ __launch_bounds__(1024) void msssim_finalize_kernel(MsFinArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward: dx = c0 F0 + 1/4 up(c1 F1 + 1/4 up(c2 F2 + 1/4 up(c3 F3 + 1/4 up(c4 F4))))
+// ------------------------------------------------------------------------------------------------
 struct MsBwdArgs {
-    const float* um; const float* u11; const float* u12;
-    const float* x; const float* y;
-    const float* gup;     // gradient of the level above (S/2) or null
-    const float* coef;    // device scalar for this level
+    const float* F[5];
+    const float* coef;
     float* dx;
-    int P;
-    MsWin win;
+    int64_t total4;       // P * W * W / 4
 };
 
-template <int S>
+template <int W>
 __global__ __launch_bounds__(256) void msssim_bwd_kernel(MsBwdArgs a) {
-    using G = MsGeom<S>;
-    constexpr int PER_IN = G::PPB * G::HR * G::HC, PER_T = G::PPB * G::HR * S;
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // 3*PER_IN + 3*PER_T floats
-    float* lin = smem;
-    float* tmp = smem + 3 * PER_IN;
-    const int plane0 = (blockIdx.x / G::STRIPS) * G::PPB, r0 = (blockIdx.x % G::STRIPS) * G::RS;
-    const float* const srcs[3] = {a.um, a.u11, a.u12};
-    ms_load<S, 3>(srcs, lin, plane0, a.P, r0);
-    __syncthreads();
-    float w[11];
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.total4) return;
+    constexpr int W4 = W / 4;
+    const int c = (int)(idx % W4) * 4, r = (int)((idx / W4) % W);
+    const int64_t plane = idx / ((int64_t)W4 * W);
+    float cf[5];
 #pragma unroll
-    for (int t = 0; t < 11; ++t) w[t] = a.win.w[t];
-    if constexpr (S >= 32) {
-        constexpr int CG = S / 4;
-        for (int it = threadIdx.x; it < G::HR * CG; it += 256) {
-            const int r = it / CG, c = (it % CG) * 4;
-#pragma unroll
-            for (int mI = 0; mI < 3; ++mI) {
-                const float* p0 = lin + mI * PER_IN + r * G::HC + c;
-                float xs[14];
-#pragma unroll
-                for (int i = 0; i < 7; ++i) {
-                    const float2 u = *reinterpret_cast<const float2*>(p0 + 2 * i);
-                    xs[2 * i] = u.x; xs[2 * i + 1] = u.y;
-                }
-                f32x4 o4v;
-#pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    float h = 0.f;
-#pragma unroll
-                    for (int t = 0; t < 11; ++t) h = fmaf(w[t], xs[o + t], h);
-                    o4v[o] = h;
-                }
-                *reinterpret_cast<f32x4*>(tmp + mI * PER_T + r * S + c) = o4v;
-            }
-        }
-    } else {
-    for (int q = threadIdx.x; q < PER_T; q += 256) {
-        const int pl = q / (G::HR * S), rem = q % (G::HR * S), r = rem / S, c = rem % S;
-        const float* p0 = lin + (pl * G::HR + r) * G::HC + c;
-        float h0 = 0.f, h1 = 0.f, h2 = 0.f;
-#pragma unroll
-        for (int t = 0; t < 11; ++t) {
-            h0 = fmaf(w[t], p0[t], h0); h1 = fmaf(w[t], p0[PER_IN + t], h1); h2 = fmaf(w[t], p0[2 * PER_IN + t], h2);
-        }
-        tmp[q] = h0; tmp[PER_T + q] = h1; tmp[2 * PER_T + q] = h2;
-    }
-    }
-    __syncthreads();
-    const float coef = a.coef[0];
-    auto emit = [&](int pl, int r, int c, float f0, float f1, float f2) {
-        const size_t o = ((size_t)(plane0 + pl) * S + r0 + r) * S + c;
-        float g = coef * (f0 + 2.0f * a.x[o] * f1 + a.y[o] * f2);
-        if (a.gup) g += 0.25f * a.gup[((size_t)(plane0 + pl) * (S / 2) + (r0 + r) / 2) * (S / 2) + c / 2];
-        a.dx[o] = g;
-    };
-    if constexpr (S >= 32) {
-        if (plane0 < a.P) {
-            for (int it = threadIdx.x; it < (G::RS / 4) * S; it += 256) {
-                const int c = it % S, rb = (it / S) * 4;
-                float res[3][4];
-#pragma unroll
-                for (int mI = 0; mI < 3; ++mI) {
-                    const float* t0 = tmp + mI * PER_T + rb * S + c;
-                    float v[14];
-#pragma unroll
-                    for (int i = 0; i < 14; ++i) v[i] = t0[i * S];
-#pragma unroll
-                    for (int o = 0; o < 4; ++o) {
-                        float acc = 0.f;
-#pragma unroll
-                        for (int t = 0; t < 11; ++t) acc = fmaf(w[t], v[o + t], acc);
-                        res[mI][o] = acc;
-                    }
-                }
-#pragma unroll
-                for (int o = 0; o < 4; ++o) emit(0, rb + o, c, res[0][o], res[1][o], res[2][o]);
-            }
-        }
-    } else {
-    for (int q = threadIdx.x; q < G::PPB * G::RS * S; q += 256) {
-        const int pl = q / (G::RS * S), rem = q % (G::RS * S), r = rem / S, c = rem % S;
-        if (plane0 + pl >= a.P) continue;
-        const float* t0 = tmp + (pl * G::HR + r) * S + c;
-        float f0 = 0.f, f1 = 0.f, f2 = 0.f;
-#pragma unroll
-        for (int t = 0; t < 11; ++t) {
-            f0 = fmaf(w[t], t0[t * S], f0); f1 = fmaf(w[t], t0[PER_T + t * S], f1); f2 = fmaf(w[t], t0[2 * PER_T + t * S], f2);
-        }
-        emit(pl, r, c, f0, f1, f2);
-    }
-    }
+    for (int l = 0; l < 5; ++l) cf[l] = a.coef[l];
+    // top level first, exactly the nesting of the avg_pool2d backward chain
+    const float g4 = cf[4] * a.F[4][(plane * (W / 16) + (r >> 4)) * (W / 16) + (c >> 4)];
+    const float g3 = cf[3] * a.F[3][(plane * (W / 8) + (r >> 3)) * (W / 8) + (c >> 3)] + 0.25f * g4;
+    const float g2 = cf[2] * a.F[2][(plane * (W / 4) + (r >> 2)) * (W / 4) + (c >> 2)] + 0.25f * g3;
+    const float2 f1 = *reinterpret_cast<const float2*>(a.F[1] + (plane * (W / 2) + (r >> 1)) * (W / 2) + (c >> 1));
+    const float g1a = cf[1] * f1.x + 0.25f * g2, g1b = cf[1] * f1.y + 0.25f * g2;
+    const f32x4 f0 = *reinterpret_cast<const f32x4*>(a.F[0] + (plane * W + r) * W + c);
+    f32x4 o;
+    o[0] = cf[0] * f0[0] + 0.25f * g1a; o[1] = cf[0] * f0[1] + 0.25f * g1a;
+    o[2] = cf[0] * f0[2] + 0.25f * g1b; o[3] = cf[0] * f0[3] + 0.25f * g1b;
+    *reinterpret_cast<f32x4*>(a.dx + (plane * W + r) * W + c) = o;
 }
 
-template <int S> static int ms_blocks(int P) { using G = MsGeom<S>; return cdiv(P, G::PPB) * G::STRIPS; }
-
-// workspace carve (floats).  sizes for width W: level sizes W, W/2, .., W/16.
+// ------------------------------------------------------------------------------------------------
+// workspace carve (floats) and the launcher
+// ------------------------------------------------------------------------------------------------
 struct MsWs {
-    int64_t pyrx[5], pyry[5], um[5], u11[5], u12[5], gp[5], part[5], coef, total;
-    int nblk[5];
+    int64_t pyrx[5], pyry[5], F[5], part[5], slab, coef, ticket, total;
+    int nblk[5], nbig;        // nbig: levels run by the tile kernel (size >= 32)
 };
+static int ms_tiles(int S) { return S == 128 ? MsT<128>::TILES : (S == 64 ? MsT<64>::TILES : MsT<32>::TILES); }
 static MsWs ms_carve(int width, int B) {
     MsWs w{};
     const int P = B * 3;
     int64_t off = 0;
     auto take = [&](int64_t n) { int64_t o = off; off += align_up(n, 64); return o; };
+    w.nbig = width == 128 ? 3 : 2;
     for (int l = 0; l < 5; ++l) {
         const int S = width >> l;
         const int64_t n = (int64_t)P * S * S;
-        if (l > 0) { w.pyrx[l] = take(n); w.pyry[l] = take(n); w.gp[l] = take(n); }
-        w.um[l] = take(n); w.u11[l] = take(n); w.u12[l] = take(n);
-    }
-    for (int l = 0; l < 5; ++l) {
-        switch (width >> l) {
-            case 128: w.nblk[l] = ms_blocks<128>(P); break;
-            case 64: w.nblk[l] = ms_blocks<64>(P); break;
-            case 32: w.nblk[l] = ms_blocks<32>(P); break;
-            case 16: w.nblk[l] = ms_blocks<16>(P); break;
-            case 8: w.nblk[l] = ms_blocks<8>(P); break;
-            default: w.nblk[l] = ms_blocks<4>(P); break;
-        }
+        if (l > 0 && l <= w.nbig) { w.pyrx[l] = take(n); w.pyry[l] = take(n); }     // levels below 16 stay in LDS
+        w.F[l] = take(n);
+        w.nblk[l] = l < w.nbig ? P * ms_tiles(S) : P;
     }
     for (int l = 0; l < 5; ++l) w.part[l] = take((int64_t)w.nblk[l] * 2);
+    w.slab = take(MS_NF * 11 * 2);
     w.coef = take(8);
+    w.ticket = take(4);
     w.total = off;
     return w;
 }
@@ -439,47 +565,12 @@ int64_t msssim_ws_floats(int width, int B) { return ms_carve(width, B).total; }
 
 template <int S>
 static int ms_fwd(const MsFwdArgs& a, hipStream_t st) {
-    using G = MsGeom<S>;
-    constexpr int SMEM = (2 * G::PPB * G::HR * G::HC + 5 * G::PPB * G::HR * S) * 4;
+    using T = MsT<S>;
     static DeviceOnce once;
-    { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(msssim_fwd_kernel<S>), SMEM); if (rc) return rc; }
-    hipLaunchKernelGGL(msssim_fwd_kernel<S>, dim3(ms_blocks<S>(a.P)), dim3(256), SMEM, st, a);
+    { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(msssim_fwd_kernel<S>), T::SMEM); if (rc) return rc; }
+    hipLaunchKernelGGL(msssim_fwd_kernel<S>, dim3(a.P * T::TILES), dim3(MS_NT), T::SMEM, st, a);
     CVAE_CHECK_LAUNCH();
     return 0;
-}
-template <int S>
-static int ms_bwd(const MsBwdArgs& a, hipStream_t st) {
-    using G = MsGeom<S>;
-    constexpr int SMEM = (3 * G::PPB * G::HR * G::HC + 3 * G::PPB * G::HR * S) * 4;
-    static DeviceOnce once;
-    { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(msssim_bwd_kernel<S>), SMEM); if (rc) return rc; }
-    hipLaunchKernelGGL(msssim_bwd_kernel<S>, dim3(ms_blocks<S>(a.P)), dim3(256), SMEM, st, a);
-    CVAE_CHECK_LAUNCH();
-    return 0;
-}
-static int ms_fwd_size(int S, const MsFwdArgs& a, hipStream_t st) {
-    switch (S) {
-        case 128: return ms_fwd<128>(a, st);
-        case 64: return ms_fwd<64>(a, st);
-        case 32: return ms_fwd<32>(a, st);
-        case 16: return ms_fwd<16>(a, st);
-        case 8: return ms_fwd<8>(a, st);
-        case 4: return ms_fwd<4>(a, st);
-    }
-    cvae_set_error("msssim: level size %d unsupported", S);
-    return -2;
-}
-static int ms_bwd_size(int S, const MsBwdArgs& a, hipStream_t st) {
-    switch (S) {
-        case 128: return ms_bwd<128>(a, st);
-        case 64: return ms_bwd<64>(a, st);
-        case 32: return ms_bwd<32>(a, st);
-        case 16: return ms_bwd<16>(a, st);
-        case 8: return ms_bwd<8>(a, st);
-        case 4: return ms_bwd<4>(a, st);
-    }
-    cvae_set_error("msssim: level size %d unsupported", S);
-    return -2;
 }
 
 int launch_msssim(int width, int B, const float* img1, const float* img2, const float* mu, const float* logvar,
@@ -490,32 +581,46 @@ int launch_msssim(int width, int B, const float* img1, const float* img2, const 
     const MsWs w = ms_carve(width, B);
     const int P = B * 3;
     const bool grad = d_img1 != nullptr;
+    unsigned* ticket = reinterpret_cast<unsigned*>(ws + w.ticket);
     const float* lx[5]; const float* ly[5];
     lx[0] = img1; ly[0] = img2;
-    for (int l = 1; l < 5; ++l) { lx[l] = ws + w.pyrx[l]; ly[l] = ws + w.pyry[l]; }
-    for (int l = 0; l < 5; ++l) {
-        MsFwdArgs a{lx[l], ly[l], l < 4 ? ws + w.pyrx[l + 1] : nullptr, l < 4 ? ws + w.pyry[l + 1] : nullptr,
-                    grad ? ws + w.um[l] : nullptr, grad ? ws + w.u11[l] : nullptr, grad ? ws + w.u12[l] : nullptr,
-                    ws + w.part[l], P, l == 4, win};
-        rc = ms_fwd_size(width >> l, a, st);
+    for (int l = 1; l <= w.nbig; ++l) { lx[l] = ws + w.pyrx[l]; ly[l] = ws + w.pyry[l]; }
+    for (int l = 0; l < w.nbig; ++l) {
+        MsFwdArgs a{lx[l], ly[l], ws + w.pyrx[l + 1], ws + w.pyry[l + 1], grad ? ws + w.F[l] : nullptr, ws + w.part[l],
+                    l == 0 ? ticket : nullptr, P, win};
+        switch (width >> l) {
+            case 128: rc = ms_fwd<128>(a, st); break;
+            case 64: rc = ms_fwd<64>(a, st); break;
+            default: rc = ms_fwd<32>(a, st); break;
+        }
         if (rc) return rc;
     }
+    {
+        MsSmallArgs s{};
+        s.x = lx[w.nbig]; s.y = ly[w.nbig]; s.P = P; s.win = win;
+        const int nsmall = 5 - w.nbig;
+        for (int k = 0; k < nsmall; ++k) { s.F[k] = grad ? ws + w.F[w.nbig + k] : nullptr; s.part[k] = ws + w.part[w.nbig + k]; }
+        if (nsmall == 3) hipLaunchKernelGGL(msssim_small_kernel<3>, dim3(P), dim3(256), MS_SMALL_SMEM, st, s);
+        else hipLaunchKernelGGL(msssim_small_kernel<2>, dim3(P), dim3(256), MS_SMALL_SMEM, st, s);
+        CVAE_CHECK_LAUNCH();
+    }
     MsFinArgs f{};
-    f.part = ws;
     for (int l = 0; l < 5; ++l) {
-        f.partOff[l] = (int)w.part[l]; f.nblk[l] = w.nblk[l];
+        f.part[l] = ws + w.part[l]; f.nblk[l] = w.nblk[l];
         f.count[l] = (double)P * (width >> l) * (width >> l);
     }
     f.mu = mu; f.logvar = logvar; f.B = mu ? B : 0; f.scalars = scalars; f.coef = ws + w.coef;
+    f.slab = reinterpret_cast<double*>(ws + w.slab); f.ticket = ticket;
     f.d_mu = d_mu; f.d_logvar = d_logvar;
-    hipLaunchKernelGGL(msssim_finalize_kernel, dim3(1), dim3(1024), 0, st, f);
+    hipLaunchKernelGGL(msssim_finalize_kernel, dim3(MS_NF), dim3(256), 0, st, f);
     CVAE_CHECK_LAUNCH();
     if (!grad) return 0;
-    for (int l = 4; l >= 0; --l) {
-        MsBwdArgs a{ws + w.um[l], ws + w.u11[l], ws + w.u12[l], lx[l], ly[l], l < 4 ? ws + w.gp[l + 1] : nullptr,
-                    ws + w.coef + l, l == 0 ? d_img1 : ws + w.gp[l], P, win};
-        rc = ms_bwd_size(width >> l, a, st);
-        if (rc) return rc;
-    }
+    MsBwdArgs b{};
+    for (int l = 0; l < 5; ++l) b.F[l] = ws + w.F[l];
+    b.coef = ws + w.coef; b.dx = d_img1; b.total4 = (int64_t)P * width * width / 4;
+    const unsigned grid = (unsigned)((b.total4 + 255) / 256);
+    if (width == 64) hipLaunchKernelGGL(msssim_bwd_kernel<64>, dim3(grid), dim3(256), 0, st, b);
+    else hipLaunchKernelGGL(msssim_bwd_kernel<128>, dim3(grid), dim3(256), 0, st, b);
+    CVAE_CHECK_LAUNCH();
     return 0;
 }

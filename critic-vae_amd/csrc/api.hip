@@ -218,6 +218,8 @@ static bool use_bf16(cvae_handle h, int layer) {
     if (h->cfg.precision >= 2 && layer > 4) return false;     // D1..D3: the fp32 phase-collapsed kernels beat nine bf16 MFMAs per block
     return h->cfg.precision != 0 && conv_bf16_supported(layer, h->cfg.width);
 }
+// precision 1: activations and activation gradients are bf16 IN HBM (every kernel that touches them is told so)
+static bool io_bf16(cvae_handle h) { return h->cfg.precision == 1; }
 static bool use_bf16_wgrad(cvae_handle h, int layer) { return h->cfg.precision == 1 && conv_bf16_supported(layer, h->cfg.width); }
 static int bf16_splits(cvae_handle h) { return h->cfg.precision >= 2 ? 3 : 1; }          // packed weight copies
 static int bf16_mode(cvae_handle h) { return h->cfg.precision == 2 ? 3 : (h->cfg.precision == 3 ? 6 : 1); }   // launcher code: 1 bf16, 3 x9, 6 x6
@@ -249,9 +251,9 @@ int cvae_forward(cvae_handle h, int32_t B, const float* x, const float* pred, co
         else { ProbeArm pa(h, 0, l); RC(launch_conv_fwd(l, W, B, ws + w.a[l - 1], P_(h->enc_w[l]), P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st)); }
         RC(launch_bn_fwd_finalize(l, W, B, ws + w.bnpart[l], P_(h->enc_g[l]), P_(h->enc_be[l]), bn_state + kBnOff[l],
                                   bn_state + 480 + kBnOff[l], ws + w.coef[l], ws + w.scratch, train, st));
-        RC(launch_bn_pool_act_fwd(l, W, B, ws + w.y[l], ws + w.coef[l], ws + w.a[l], st));
+        RC(launch_bn_pool_act_fwd(l, W, B, ws + w.y[l], ws + w.coef[l], ws + w.a[l], st, io_bf16(h)));
     }
-    RC(launch_fc_fwd(W, B, ws + w.a[3], P_(h->fc_w), P_(h->fc_b), eps, pred, mu, logvar, ws + w.zcat, ws + w.scratch, st));
+    RC(launch_fc_fwd(W, B, ws + w.a[3], P_(h->fc_w), P_(h->fc_b), eps, pred, mu, logvar, ws + w.zcat, ws + w.scratch, st, io_bf16(h)));
     if (!recon) return 0;                       // encode only (VariationalEncoder.forward)
     return cvae_decode(h, B, nullptr, params, recon, wsv, stream);
 }
@@ -269,7 +271,7 @@ int cvae_decode(cvae_handle h, int32_t B, const float* zcat, const float* params
         if (e != hipSuccess) { cvae_set_error("cvae_decode: copy failed: %s", hipGetErrorString(e)); return (int)e; }
         RC(pack_bf16_weights(h, params, ws, w, st));          // stand-alone decode: cvae_forward did not run
     }
-    RC(launch_decin_fwd(W, B, ws + w.zcat, P_(h->di_w), P_(h->di_b), ws + w.h, st));
+    RC(launch_decin_fwd(W, B, ws + w.zcat, P_(h->di_w), P_(h->di_b), ws + w.h, st, io_bf16(h)));
     // Upsample -> Conv of D1..D3 runs at the low resolution with phase-collapsed weights (conv_up.hip)
     {
         const float* wsrc[3] = {P_(h->dec_w[1]), P_(h->dec_w[2]), P_(h->dec_w[3])};
@@ -291,7 +293,7 @@ int cvae_decode(cvae_handle h, int32_t B, const float* zcat, const float* params
             RC(launch_conv_up_fwd(4 + i, W, B, ws + w.o[i - 1], ws + w.wc[i - 1], P_(h->dec_b[i]), ws + w.o[i], ws + w.scratch, st));
         }
     }
-    RC(launch_d4_fwd(W, B, ws + w.o[3], P_(h->dec_w[4]), P_(h->dec_b[4]), recon, st));
+    RC(launch_d4_fwd(W, B, ws + w.o[3], P_(h->dec_w[4]), P_(h->dec_b[4]), recon, st, io_bf16(h)));
     return 0;
 }
 
@@ -368,7 +370,7 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
     if (phase_mask & 1) {
     // decoder, last layer first
     RC(launch_d4_bwd(W, B, ws + w.o[3], d_recon, recon, P_(h->dec_w[4]), ws + w.dout4, ws + w.d_o[3],
-                     G_(h->dec_w[4]), G_(h->dec_b[4]), sc, st));
+                     G_(h->dec_w[4]), G_(h->dec_b[4]), sc, st, io_bf16(h)));
     for (int i = 3; i >= 0; --i) {
         const int l = 4 + i;
         const float* in = i == 0 ? ws + w.h : ws + w.o[i - 1];
@@ -388,18 +390,18 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
         }
     }
     // latent
-    RC(launch_decin_bwd(W, B, ws + w.zcat, ws + w.d_h, P_(h->di_w), G_(h->di_w), G_(h->di_b), ws + w.d_zcat, sc, st));
+    RC(launch_decin_bwd(W, B, ws + w.zcat, ws + w.d_h, P_(h->di_w), G_(h->di_w), G_(h->di_b), ws + w.d_zcat, sc, st, io_bf16(h)));
     RC(join());
     }
     if (phase_mask & 2)
         RC(launch_fc_bwd(W, B, ws + w.a[3], P_(h->fc_w), ws + w.d_zcat, eps, logvar, d_mu, d_logvar, G_(h->fc_w),
-                         G_(h->fc_b), ws + w.d_a[3], sc, st));
+                         G_(h->fc_b), ws + w.d_a[3], sc, st, io_bf16(h)));
     // encoder
     for (int l = 3; l >= 0; --l) {
         if (!(phase_mask & (l == 3 ? 2 : 4))) continue;
         { ProbeArm pa(h, 3, l);
           RC(launch_bn_pool_act_bwd(l, W, B, ws + w.y[l], ws + w.a[l], ws + w.d_a[l], ws + w.coef[l], P_(h->enc_g[l]),
-                                    ws + w.d_y[l], G_(h->enc_g[l]), G_(h->enc_be[l]), nullptr, sc, st)); }
+                                    ws + w.d_y[l], G_(h->enc_g[l]), G_(h->enc_be[l]), nullptr, sc, st, io_bf16(h))); }
         RC(fork(7 - l));
         if (l == 0) {
             RC(launch_e1_wgrad(W, B, x, ws + w.d_y[0], G_(h->enc_w[0]), G_(h->enc_b[0]), scw, sd, h->cfg.precision == 1));

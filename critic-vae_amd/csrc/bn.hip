@@ -267,6 +267,185 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     if (c < C && q == 0) { dgamma[c] = s2; dbeta[c] = s1; bcoef[c * 2] = s1 * invN; bcoef[c * 2 + 1] = s2 * invN; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// precision mode 1: y, a, da, dy are bf16 in HBM (statistics, coefficients and partial sums stay fp32).
+// One thread = 8 consecutive channels of one pooled pixel: every access is one 16-byte unit.
+// ------------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_pool_act_fwd_bf16_kernel(const float* __restrict__ y, const float* __restrict__ coef,
+                                                                   float* __restrict__ a, int C, int H, int64_t total) {
+    using A = Act<__bf16>;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int C8 = C / 8, HO = H / 2;
+    const int c8 = (int)(idx % C8);
+    const int64_t pp = idx / C8;
+    const int px = (int)(pp % HO), py = (int)((pp / HO) % HO);
+    const int64_t ib = pp / ((int64_t)HO * HO);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = coef[(c8 * 8 + e) * 4]; sh[e] = coef[(c8 * 8 + e) * 4 + 1]; }
+    const size_t base = (size_t)((ib * H + 2 * py) * H + 2 * px) * C + c8 * 8;
+    float m[8];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const bf16x8 v = A::ld8(y, base + (size_t)((p >> 1) * H + (p & 1)) * C);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float n = fmaf((float)v[e], sc[e], sh[e]);
+            m[e] = (p == 0 || n > m[e]) ? n : m[e];
+        }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)act_fwd(m[e], ACT);
+    A::st8(a, (size_t)pp * C + c8 * 8, o);
+}
+
+// MODE 0: partial sums (sum g, sum g*xhat) per channel.  MODE 1: write dy, partial sums of dy.
+template <int ACT, int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_bf16_kernel(const float* __restrict__ y, const float* __restrict__ a,
+                                                          const float* __restrict__ da, const float* __restrict__ coef,
+                                                          const float* __restrict__ bcoef, float* __restrict__ dy,
+                                                          float* __restrict__ part, int C, int H, int64_t totalPx, int64_t pxPerBlk) {
+    using A = Act<__bf16>;
+    __shared__ float red[2][256][8];
+    const int HO = H / 2, C8 = C / 8;
+    const int c8 = threadIdx.x % C8, sub = threadIdx.x / C8, NSUB = 256 / C8;
+    float sc[8], sh[8], mean[8], invstd[8], k1[8], k2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c8 * 8 + e;
+        sc[e] = coef[c * 4]; sh[e] = coef[c * 4 + 1]; mean[e] = coef[c * 4 + 2]; invstd[e] = coef[c * 4 + 3];
+        k1[e] = MODE == 1 ? bcoef[c * 2] : 0.f; k2[e] = MODE == 1 ? bcoef[c * 2 + 1] : 0.f;
+    }
+    const int64_t p0 = blockIdx.x * pxPerBlk;
+    int64_t p1 = p0 + pxPerBlk; if (p1 > totalPx) p1 = totalPx;
+    float acc0[8], acc1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    for (int64_t pp = p0 + sub; pp < p1; pp += NSUB) {
+        const int px = (int)(pp % HO), py = (int)((pp / HO) % HO);
+        const int64_t ib = pp / ((int64_t)HO * HO);
+        const size_t base = (size_t)((ib * H + 2 * py) * H + 2 * px) * C + c8 * 8;
+        bf16x8 yv[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) yv[p] = A::ld8(y, base + (size_t)((p >> 1) * H + (p & 1)) * C);
+        const bf16x8 av = A::ld8(a, (size_t)pp * C + c8 * 8), gv = A::ld8(da, (size_t)pp * C + c8 * 8);
+        bf16x8 out[4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float mx = 0.f, ym = 0.f; int pos = 0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float yy = (float)yv[p][e], n = fmaf(yy, sc[e], sh[e]);
+                if (p == 0 || n > mx) { mx = n; pos = p; ym = yy; }
+            }
+            const float g = (float)gv[e] * act_bwd_from_out((float)av[e], ACT);
+            if (MODE == 0) {
+                acc0[e] += g; acc1[e] += g * ((ym - mean[e]) * invstd[e]);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float xhat = ((float)yv[p][e] - mean[e]) * invstd[e];
+                    const float d = sc[e] * ((p == pos ? g : 0.f) - k1[e] - xhat * k2[e]);
+                    out[p][e] = (__bf16)d;
+                    acc0[e] += d;
+                }
+            }
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) A::st8(dy, base + (size_t)((p >> 1) * H + (p & 1)) * C, out[p]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][threadIdx.x][e] = acc0[e]; red[1][threadIdx.x][e] = acc1[e]; }
+    __syncthreads();
+    if (sub == 0) {
+        for (int k = 1; k < NSUB; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { acc0[e] += red[0][k * C8 + c8][e]; acc1[e] += red[1][k * C8 + c8][e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c8 * 8 + e;
+            if (MODE == 0) {
+                part[((size_t)blockIdx.x * 2) * C + c] = acc0[e];
+                part[((size_t)blockIdx.x * 2 + 1) * C + c] = acc1[e];
+            } else {
+                part[(size_t)blockIdx.x * C + c] = acc0[e];
+            }
+        }
+    }
+}
+
+// ReLU blocks, bf16 storage: the two backward sums from the pooled tensors alone (see bn_bwd_stats_relu_kernel)
+__global__ __launch_bounds__(256) void bn_bwd_stats_relu_bf16_kernel(const float* __restrict__ a, const float* __restrict__ da,
+                                                                     const float* __restrict__ coef, float* __restrict__ part,
+                                                                     int C, int64_t totalPx, int64_t pxPerBlk,
+                                                                     const float* __restrict__ y, int H) {
+    using A = Act<__bf16>;
+    __shared__ float red[2][256][8];
+    const int C8 = C / 8, c8 = threadIdx.x % C8, sub = threadIdx.x / C8, NSUB = 256 / C8, HO = H / 2;
+    float gam[8], bet[8];
+    bool tiny[8], any_tiny = false;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c8 * 8 + e;
+        const float scale = coef[c * 4], shift = coef[c * 4 + 1], mean = coef[c * 4 + 2], invstd = coef[c * 4 + 3];
+        const float g = scale / invstd;
+        tiny[e] = !(fabsf(g) >= 1e-2f);
+        any_tiny = any_tiny || tiny[e];
+        gam[e] = tiny[e] ? 0.f : 1.0f / g;
+        bet[e] = shift + mean * scale;
+    }
+    const int64_t p0 = blockIdx.x * pxPerBlk;
+    int64_t p1 = p0 + pxPerBlk; if (p1 > totalPx) p1 = totalPx;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    for (int64_t pp = p0 + sub; pp < p1; pp += NSUB) {
+        const bf16x8 av = A::ld8(a, (size_t)pp * C + c8 * 8), gv = A::ld8(da, (size_t)pp * C + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float aa = (float)av[e];
+            const float g = aa > 0.f ? (float)gv[e] : 0.f;
+            s1[e] += g;
+            s2[e] += g * ((aa - bet[e]) * gam[e]);
+        }
+        if (any_tiny) {
+            const int px = (int)(pp % HO), py = (int)((pp / HO) % HO);
+            const int64_t ib = pp / ((int64_t)HO * HO);
+            const size_t base = (size_t)((ib * H + 2 * py) * H + 2 * px) * C;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (!tiny[e]) continue;
+                const int c = c8 * 8 + e;
+                float mx = 0.f, ym = 0.f;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float yy = A::ld(y, base + (size_t)((p >> 1) * H + (p & 1)) * C + c), n = fmaf(yy, coef[c * 4], coef[c * 4 + 1]);
+                    if (p == 0 || n > mx) { mx = n; ym = yy; }
+                }
+                s2[e] += ((float)av[e] > 0.f ? (float)gv[e] : 0.f) * ((ym - coef[c * 4 + 2]) * coef[c * 4 + 3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
+    __syncthreads();
+    if (sub == 0) {
+        for (int k = 1; k < NSUB; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] += red[0][k * C8 + c8][e]; s2[e] += red[1][k * C8 + c8][e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            part[((size_t)blockIdx.x * 2) * C + c8 * 8 + e] = s1[e];
+            part[((size_t)blockIdx.x * 2 + 1) * C + c8 * 8 + e] = s2[e];
+        }
+    }
+}
+
 static constexpr int BN_RA = 32;
 int64_t bn_fwd_ws_floats(int layer, int width) { (void)width; return (int64_t)2 * BN_RA * 3 * kLayers[layer].cout; }
 
@@ -291,8 +470,16 @@ int launch_bn_fwd_finalize(int layer, int width, int B, const float* bnpart, con
     return 0;
 }
 
-int launch_bn_pool_act_fwd(int layer, int width, int B, const float* y, const float* coef, float* a, hipStream_t st) {
+int launch_bn_pool_act_fwd(int layer, int width, int B, const float* y, const float* coef, float* a, hipStream_t st, bool bf16io) {
     const BnGeom g = bn_geom(layer, width);
+    if (bf16io) {
+        const int64_t total8 = (int64_t)B * (g.H / 2) * (g.H / 2) * (g.C / 8);
+        const unsigned grid8 = (unsigned)((total8 + 255) / 256);
+        if (g.act) hipLaunchKernelGGL(bn_pool_act_fwd_bf16_kernel<1>, dim3(grid8), dim3(256), 0, st, y, coef, a, g.C, g.H, total8);
+        else hipLaunchKernelGGL(bn_pool_act_fwd_bf16_kernel<0>, dim3(grid8), dim3(256), 0, st, y, coef, a, g.C, g.H, total8);
+        CVAE_CHECK_LAUNCH();
+        return 0;
+    }
     const int64_t total = (int64_t)B * (g.H / 2) * (g.H / 2) * (g.C / 4);
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (g.act) hipLaunchKernelGGL(bn_pool_act_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, y, coef, a, g.C, g.H, total);
@@ -316,7 +503,7 @@ int64_t bn_bwd_ws_floats(int layer, int width, int B) {
 
 int launch_bn_pool_act_bwd(int layer, int width, int B, const float* y, const float* a, const float* da,
                            const float* coef, const float* gamma, float* dy, float* dgamma, float* dbeta,
-                           float* dbias, float* ws, hipStream_t st) {
+                           float* dbias, float* ws, hipStream_t st, bool bf16io) {
     (void)gamma;
     const BnGeom g = bn_geom(layer, width);
     const int64_t totalPx = (int64_t)B * (g.H / 2) * (g.H / 2);
@@ -327,7 +514,9 @@ int launch_bn_pool_act_bwd(int layer, int width, int B, const float* y, const fl
     float* red = bcoef + 2 * g.C;
     float* crws = red + 2 * g.C;
     const float invN = 1.0f / (float)((double)B * g.H * g.H);
-    if (g.act) hipLaunchKernelGGL((bn_bwd_kernel<1, 0>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, nullptr, nullptr, part, g.C, g.H, totalPx, ppb);
+    if (bf16io && g.act) hipLaunchKernelGGL((bn_bwd_bf16_kernel<1, 0>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, nullptr, nullptr, part, g.C, g.H, totalPx, ppb);
+    else if (bf16io) hipLaunchKernelGGL(bn_bwd_stats_relu_bf16_kernel, dim3(nblk), dim3(256), 0, st, a, da, coef, part, g.C, totalPx, ppb, y, g.H);
+    else if (g.act) hipLaunchKernelGGL((bn_bwd_kernel<1, 0>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, nullptr, nullptr, part, g.C, g.H, totalPx, ppb);
     else hipLaunchKernelGGL(bn_bwd_stats_relu_kernel, dim3(nblk), dim3(256), 0, st, a, da, coef, part, g.C, totalPx, ppb, y, g.H);
     CVAE_CHECK_LAUNCH();
     const float* rows; int R; int64_t rstride;
@@ -335,7 +524,9 @@ int launch_bn_pool_act_bwd(int layer, int width, int B, const float* y, const fl
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(g.C, 16)), dim3(256), 0, st, rows, R, rstride, g.C, invN, dgamma, dbeta, bcoef);
     CVAE_CHECK_LAUNCH();
     cvae_probe_begin(st);                       // the apply pass: reads y, a, da, writes dy — the step's largest HBM-bound kernel
-    if (g.act) hipLaunchKernelGGL((bn_bwd_kernel<1, 1>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, bcoef, dy, part, g.C, g.H, totalPx, ppb);
+    if (bf16io && g.act) hipLaunchKernelGGL((bn_bwd_bf16_kernel<1, 1>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, bcoef, dy, part, g.C, g.H, totalPx, ppb);
+    else if (bf16io) hipLaunchKernelGGL((bn_bwd_bf16_kernel<0, 1>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, bcoef, dy, part, g.C, g.H, totalPx, ppb);
+    else if (g.act) hipLaunchKernelGGL((bn_bwd_kernel<1, 1>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, bcoef, dy, part, g.C, g.H, totalPx, ppb);
     else hipLaunchKernelGGL((bn_bwd_kernel<0, 1>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, bcoef, dy, part, g.C, g.H, totalPx, ppb);
     cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();

@@ -9,6 +9,37 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));     // one v_mfma_f32_32x32x16_bf16 operand fragment
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// Activation storage type of a run: fp32 (precision modes 0, 2, 3) or bf16 (precision mode 1: y_l, a_l, h, o_i and
+// their gradients live in HBM as bf16; BatchNorm statistics, loss scalars, master weights and the flat gradient
+// stay fp32).  Tensor pointers cross the launchers as opaque float*; kernels index them in ELEMENTS through Act<AT>.
+template <typename AT> struct Act;
+template <> struct Act<float> {
+    static constexpr bool BF16 = false;
+    static __device__ __forceinline__ float ld(const float* p, size_t i) { return p[i]; }
+    static __device__ __forceinline__ void st(float* p, size_t i, float v) { p[i] = v; }
+    static __device__ __forceinline__ f32x4 ld4(const float* p, size_t i) { return *reinterpret_cast<const f32x4*>(p + i); }
+    static __device__ __forceinline__ void st4(float* p, size_t i, f32x4 v) { *reinterpret_cast<f32x4*>(p + i) = v; }
+};
+template <> struct Act<__bf16> {
+    static constexpr bool BF16 = true;
+    static __device__ __forceinline__ float ld(const float* p, size_t i) { return (float)reinterpret_cast<const __bf16*>(p)[i]; }
+    static __device__ __forceinline__ void st(float* p, size_t i, float v) { reinterpret_cast<__bf16*>(p)[i] = (__bf16)v; }
+    static __device__ __forceinline__ f32x4 ld4(const float* p, size_t i) {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p) + i);
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+    static __device__ __forceinline__ void st4(float* p, size_t i, f32x4 v) {
+        bf16x4 o;
+        o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p) + i) = o;
+    }
+    // 8 consecutive elements = one 16-byte unit
+    static __device__ __forceinline__ bf16x8 ld8(const float* p, size_t i) { return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p) + i); }
+    static __device__ __forceinline__ void st8(float* p, size_t i, bf16x8 v) { *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p) + i) = v; }
+};
+
 #define CVAE_LATENT 32
 #define CVAE_ZCAT 33
 
@@ -131,13 +162,13 @@ int launch_conv_up_fwd_bf16(int layer, int width, int ns, int B, const float* in
 int launch_conv_up_dgrad_bf16(int layer, int width, int ns, int B, const float* dout, const float* packed, const float* aux, float* din, hipStream_t st);
 int64_t wgrad_bf16_ws_floats(int layer, int width, int B);
 int launch_conv_wgrad_bf16(int layer, int width, int B, const float* in, const float* dout, float* dw, float* dbias, float* ws, hipStream_t st);
-int launch_splitk_bias_relu(const float* slab, const float* bias, float* out, int64_t slice, int KS, int C, hipStream_t st);
+int launch_splitk_bias_relu(const float* slab, const float* bias, float* out, int64_t slice, int KS, int C, hipStream_t st, bool out_bf16 = false);
 // conv_wgrad.hip
 int64_t wgrad_ws_floats(int layer, int width, int B);
 int launch_conv_wgrad(int layer, int width, int B, const float* in, const float* dout, float* dw,
                       float* dbias, float* ws, hipStream_t st);
 int launch_reduce_slabs(const float* slab, float* dst, int64_t n, int S, int64_t stride, hipStream_t st,
-                        float* mid = nullptr);
+                        float* mid = nullptr, bool out_bf16 = false);
 int launch_colsum(const float* src, int64_t rows, int C, float* dst, float* ws, hipStream_t st);
 int64_t colsum_ws_floats(int64_t rows, int C);
 // reduce.hip
@@ -152,11 +183,11 @@ int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw
                     hipStream_t st, bool bf16 = false);
 int64_t e1_wgrad_ws_floats(int width, int B);
 int launch_d4_fwd(int width, int B, const float* in, const float* w, const float* bias, float* recon,
-                  hipStream_t st);
+                  hipStream_t st, bool bf16io = false);
 int64_t d4_bwd_ws_floats(int width, int B);
 int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const float* recon,
                   const float* w, float* dout, float* d_o3, float* dw, float* db, float* ws,
-                  hipStream_t st);
+                  hipStream_t st, bool bf16io = false);
 // conv_up.hip (phase-collapsed Upsample->Conv blocks D1..D3, layers 5..7)
 int64_t conv_up_wc_floats(int layer);
 int launch_collapse_w(int layer, const float* w, float* wc, hipStream_t st);
@@ -177,24 +208,24 @@ int launch_bn_fwd_finalize(int layer, int width, int B, const float* bnpart, con
                            float* ws, int train, hipStream_t st);
 int64_t bn_fwd_ws_floats(int layer, int width);
 int launch_bn_pool_act_fwd(int layer, int width, int B, const float* y, const float* coef, float* a,
-                           hipStream_t st);
+                           hipStream_t st, bool bf16io = false);
 int64_t bn_bwd_ws_floats(int layer, int width, int B);
 int launch_bn_pool_act_bwd(int layer, int width, int B, const float* y, const float* a,
                            const float* da, const float* coef, const float* gamma, float* dy,
-                           float* dgamma, float* dbeta, float* dbias, float* ws, hipStream_t st);
+                           float* dgamma, float* dbeta, float* dbias, float* ws, hipStream_t st, bool bf16io = false);
 // fc.hip
 int64_t fc_ws_floats(int width, int B);
 int launch_fc_fwd(int width, int B, const float* flat, const float* wfc, const float* bfc,
                   const float* eps, const float* pred, float* mu, float* logvar, float* zcat,
-                  float* ws, hipStream_t st);
+                  float* ws, hipStream_t st, bool bf16io = false);
 int launch_decin_fwd(int width, int B, const float* zcat, const float* wd, const float* bd, float* h,
-                     hipStream_t st);
+                     hipStream_t st, bool bf16io = false);
 int launch_decin_bwd(int width, int B, const float* zcat, const float* dh, const float* wd, float* dwd,
-                     float* dbd, float* dzcat, float* ws, hipStream_t st);
+                     float* dbd, float* dzcat, float* ws, hipStream_t st, bool bf16io = false);
 int launch_fc_bwd(int width, int B, const float* flat, const float* wfc, const float* dzcat,
                   const float* eps, const float* logvar, const float* dmu_loss,
                   const float* dlv_loss, float* dwfc, float* dbfc, float* dflat, float* ws,
-                  hipStream_t st);
+                  hipStream_t st, bool bf16io = false);
 // msssim.hip
 int64_t msssim_ws_floats(int width, int B);
 int launch_msssim(int width, int B, const float* img1, const float* img2, const float* mu,

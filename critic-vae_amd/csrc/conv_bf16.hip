@@ -4,8 +4,10 @@
 // Same call sites as conv_mfma.hip (nn.Conv2d E2..E4 and D0, vae_nets.py:74,79,84,117, and their
 // input gradients in loss.backward(), vae.py:57), same tiling (Tile<H>: 128 output pixels x NT
 // channels per workgroup, wave = 32 pixels), same fp32 epilogues (conv_epilogue.h).  What changes:
-//   * operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) when they are staged into LDS;
-//     activations, gradients, BatchNorm statistics and the master weights stay fp32 in HBM;
+//   * precision mode 1 (NS == 1): activations and activation gradients ARE bf16 in HBM (written by the producing
+//     kernel's epilogue, RNE), so a 16-byte global load is already one LDS unit of 8 channels — no conversion
+//     while staging; BatchNorm statistics (taken from the fp32 accumulators), loss scalars, master weights and the
+//     flat gradient stay fp32.  The fp32-emulation modes (NS == 3) keep fp32 tensors and split them while staging;
 //   * the contraction runs on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): one instruction covers
 //     a 16-channel block of one tap — 8x fewer instructions at half the cycles each;
 //   * a K stage = one kernel row x up to 64 channels; LDS holds 16-byte units of 8 channels,
@@ -23,7 +25,7 @@
 
 
 struct ConvBf16Args {
-    const float* in;        // fp32 NHWC, KCH channels
+    const float* in;        // NHWC, KCH channels: bf16 when NS == 1 (opaque pointer), fp32 when NS == 3
     const bf16x8* wp;       // packed weights [25][KCH/16][2][NCH] units of 8 bf16
     const float* bias;
     float* out;
@@ -129,7 +131,8 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     // input halo chunk: fp32 NHWC -> registers (one chunk ahead, in flight during the MFMAs of the
     // current chunk) -> bf16 units [octet][halo pixel] (split into hi/mid/lo planes when NS == 3)
     constexpr int NQ = T::HP * OCT, IPT = (NQ + 255) / 256;
-    f32x4 ireg[2 * IPT];
+    f32x4 ireg[NS == 1 ? 1 : 2 * IPT];
+    bf16x8 breg[NS == 1 ? IPT : 1];
     auto load_input = [&](int cc) {
 #pragma unroll
         for (int i = 0; i < IPT; ++i) {
@@ -137,19 +140,26 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
             const int oct = q % OCT, hp = q / OCT;
             const int img = hp / T::HPI, rem = hp - img * T::HPI;
             const int gy = ty0 + rem / T::HTW - 2, gx = tx0 + rem % T::HTW - 2, ib = img0 + img;
-            f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-            if ((NQ % 256 == 0 || q < NQ) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B) {
-                const float* src;
+            const bool ok = (NQ % 256 == 0 || q < NQ) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B;
+            size_t e = 0;                           // element index of the unit's first channel
+            if (ok) {
                 if (MODE == MODE_UP_DGRAD) {        // channel k = p*COUT + co of the low-res view = dout[2y+py][2x+px][co]
                     const int k0 = cc * KCB + oct * 8, p = k0 / COUT_UP, co = k0 % COUT_UP;
-                    src = a.in + ((size_t)(ib * 2 * H + 2 * gy + (p >> 1)) * (2 * H) + 2 * gx + (p & 1)) * COUT_UP + co;
+                    e = ((size_t)(ib * 2 * H + 2 * gy + (p >> 1)) * (2 * H) + 2 * gx + (p & 1)) * COUT_UP + co;
                 } else {
-                    src = a.in + ((size_t)(ib * H + gy) * H + gx) * KCH + cc * KCB + oct * 8;
+                    e = ((size_t)(ib * H + gy) * H + gx) * KCH + cc * KCB + oct * 8;
                 }
-                lo = *reinterpret_cast<const f32x4*>(src);
-                hi = *reinterpret_cast<const f32x4*>(src + 4);
             }
-            ireg[2 * i] = lo; ireg[2 * i + 1] = hi;
+            if constexpr (NS == 1) {
+                bf16x8 z;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) z[k] = (__bf16)0.f;
+                breg[i] = ok ? Act<__bf16>::ld8(a.in, e) : z;
+            } else {
+                f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+                if (ok) { lo = *reinterpret_cast<const f32x4*>(a.in + e); hi = *reinterpret_cast<const f32x4*>(a.in + e + 4); }
+                ireg[2 * i] = lo; ireg[2 * i + 1] = hi;
+            }
         }
     };
     auto store_input = [&]() {
@@ -158,10 +168,10 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
             const int q = tid + i * 256;
             if (!(NQ % 256 == 0 || q < NQ)) continue;
             const int oct = q % OCT, hp = q / OCT;
-            const f32x4 lo = ireg[2 * i], hi = ireg[2 * i + 1];
-            if (NS == 1) {
-                lds_a[oct * PSP + hp] = to_bf16x8(lo, hi);
+            if constexpr (NS == 1) {
+                lds_a[oct * PSP + hp] = breg[i];
             } else {
+                const f32x4 lo = ireg[2 * i], hi = ireg[2 * i + 1];
                 bf16x8 u0, u1, u2;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -238,6 +248,32 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
                 if (MODE == MODE_UP_FWD) x = fmaxf(x, 0.f);
                 patch[((v & 3) + 8 * (v >> 2) + 4 * lh) * 36 + li] = x;
             }
+            if constexpr (NS == 1) {          // bf16 tensors: 8 channels = one 16-byte unit per lane
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int idx = it * 64 + lane, px = idx >> 2, c8 = idx & 3;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(patch + px * 36 + c8 * 8);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(patch + px * 36 + c8 * 8 + 4);
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = (__bf16)lo[e]; o[4 + e] = (__bf16)hi[e]; }
+                    const int mm = wave * 32 + px;
+                    const int im = mm / (T::TH * T::TW), rem = mm % (T::TH * T::TW);
+                    const int gy = ty0 + rem / T::TW, gx = tx0 + rem % T::TW, ib = img0 + im;
+                    if (ib >= a.B) continue;
+                    if (MODE == MODE_UP_FWD) {
+                        const size_t oo = ((size_t)(ib * 2 * H + 2 * gy + (p >> 1)) * (2 * H) + 2 * gx + (p & 1)) * COUT_UP + c0 + c8 * 8;
+                        Act<__bf16>::st8(a.out, oo, o);
+                    } else {
+                        const size_t oo = ((size_t)(ib * H + gy) * H + gx) * NCH + c0 + c8 * 8;
+                        const bf16x8 mk = Act<__bf16>::ld8(a.aux, oo);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (float)mk[e] > 0.f ? o[e] : (__bf16)0.f;
+                        Act<__bf16>::st8(a.out, oo, o);
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int idx = it * 64 + lane, px = idx >> 3, c4 = idx & 7;
@@ -262,7 +298,8 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
         epilogue_store<H, NT, NCH, EPI_PLAIN>(acc, nullptr, a.out + (size_t)blockIdx.z * a.sliceFloats, nullptr, smem, a.B,
                                               mt, n0, img0, ty0, tx0);
     } else {
-        epilogue_store<H, NT, NCH, EPI>(acc, a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0);
+        if constexpr (NS == 1) epilogue_store<H, NT, NCH, EPI, __bf16>(acc, a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0);
+        else epilogue_store<H, NT, NCH, EPI>(acc, a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0);
     }
 }
 
@@ -380,7 +417,7 @@ int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, c
                 a.out = ws; a.sliceFloats = slice;
                 int rc = run_bf16<256, 128, 4, 64, EPI_PLAIN, 4>(a, st);
                 if (rc) return rc;
-                return launch_splitk_bias_relu(ws, bias, out, slice, 4, 128, st);
+                return launch_splitk_bias_relu(ws, bias, out, slice, 4, 128, st, ns == 1);
             }
         }
     } else if (width == 128) {
@@ -407,7 +444,7 @@ int launch_conv_dgrad_bf16(int layer, int width, int ns, int B, const float* dou
                 a.out = ws; a.sliceFloats = slice;
                 int rc = run_bf16<128, 256, 4, 64, EPI_PLAIN, 2>(a, st);
                 if (rc) return rc;
-                return launch_reduce_slabs(ws, din, slice, 2, slice, st, nullptr);
+                return launch_reduce_slabs(ws, din, slice, 2, slice, st, nullptr, ns == 1);
             }
         }
     } else if (width == 128) {
@@ -470,8 +507,8 @@ int launch_conv_up_dgrad_bf16(int layer, int width, int ns, int B, const float* 
 // channel), lanes 0-31 take pixel p and lanes 32-63 pixel p+1 — one instruction contracts 2 pixels
 // x 8 images.  Workgroup = 8 images x (4 x TW) pixels x 32 ci x 32 co, all 25 taps; wave w owns
 // taps w, w+4, .., w+20 and row w of tap 24 (as conv_wgrad.hip).  Staging transposes on the fly:
-// a thread loads the same 4 channels of the 8 images (8 coalesced 16-byte loads), rounds to bf16
-// and writes 4 units.  The bias gradient is summed from the fp32 values while they pass through
+// a thread loads the same 8 channels (one 16-byte unit of the bf16 tensor) of the 8 images and writes the
+// 8 image-major units.  The bias gradient is summed (fp32) from the values while they pass through
 // the registers.  Split-K slabs + fixed-order reduce_slabs as in the fp32 kernel.
 // ---------------------------------------------------------------------------------------------
 template <int H> struct WgTile {
@@ -481,8 +518,8 @@ template <int H> struct WgTile {
 };
 
 struct WgradBf16Args {
-    const float* in;     // (B,H,H,CIN) fp32
-    const float* dout;   // (B,H,H,COUT) fp32
+    const float* in;     // (B,H,H,CIN) bf16 (opaque pointer)
+    const float* dout;   // (B,H,H,COUT) bf16
     float* slab;         // [S][25*CIN*COUT + COUT]
     int B, numTiles, tilesPerSplit;
 };
@@ -512,14 +549,19 @@ __global__ __launch_bounds__(256, 2) void conv5x5_wgrad_bf16_kernel(WgradBf16Arg
     bf16x8* lds_d = lds_in + T::HP * 32;                        // [pixel][32 co]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int split = blockIdx.x, ci0 = blockIdx.y * 32, n0 = blockIdx.z * 32;
-    const int quad = tid & 7;                                   // the 4 channels this thread stages (fixed)
+    const int oct = tid & 3;                                    // the 8 channels this thread stages (fixed)
 
     f32x16 acc[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
-    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    float bsum[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) bsum[c] = 0.f;
+    bf16x8 zero8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) zero8[c] = (__bf16)0.f;
 
     const int t0 = split * a.tilesPerSplit;
     int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
@@ -527,42 +569,45 @@ __global__ __launch_bounds__(256, 2) void conv5x5_wgrad_bf16_kernel(WgradBf16Arg
         const int grp = mt / T::TILES_PER_GRP, t = mt % T::TILES_PER_GRP;
         const int img0 = grp * 8, ty0 = (t / T::TILES_X) * T::TH, tx0 = (t % T::TILES_X) * T::TW;
         __syncthreads();
-        for (int q = tid; q < T::HP * 8; q += 256) {
-            const int hp = q >> 3;
+        for (int q = tid; q < T::HP * 4; q += 256) {
+            const int hp = q >> 2;
             const int gy = ty0 + hp / T::HTW - 2, gx = tx0 + hp % T::HTW - 2;
             const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H;
-            f32x4 v[8];
+            bf16x8 v[8];
 #pragma unroll
             for (int im = 0; im < 8; ++im) {
-                v[im] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (inb && img0 + im < a.B)
-                    v[im] = *reinterpret_cast<const f32x4*>(a.in + ((size_t)((img0 + im) * H + gy) * H + gx) * CIN + ci0 + quad * 4);
+                const bool ok = inb && img0 + im < a.B;
+                const size_t e = ok ? ((size_t)((img0 + im) * H + gy) * H + gx) * CIN + ci0 + oct * 8 : 0;
+                const bf16x8 l = Act<__bf16>::ld8(a.in, e);
+                v[im] = ok ? l : zero8;
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 8; ++c) {
                 bf16x8 u;
 #pragma unroll
-                for (int im = 0; im < 8; ++im) u[im] = (__bf16)v[im][c];
-                lds_in[hp * 32 + quad * 4 + c] = u;
+                for (int im = 0; im < 8; ++im) u[im] = v[im][c];
+                lds_in[hp * 32 + oct * 8 + c] = u;
             }
         }
-        for (int q = tid; q < T::NPX * 8; q += 256) {
-            const int px = q >> 3;
+        for (int q = tid; q < T::NPX * 4; q += 256) {
+            const int px = q >> 2;
             const int gy = ty0 + px / T::TW, gx = tx0 + px % T::TW;
-            f32x4 v[8];
+            bf16x8 v[8];
 #pragma unroll
             for (int im = 0; im < 8; ++im) {
-                v[im] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (img0 + im < a.B)
-                    v[im] = *reinterpret_cast<const f32x4*>(a.dout + ((size_t)((img0 + im) * H + gy) * H + gx) * COUT + n0 + quad * 4);
-                bsum += v[im];
+                const bool ok = img0 + im < a.B;
+                const size_t e = ok ? ((size_t)((img0 + im) * H + gy) * H + gx) * COUT + n0 + oct * 8 : 0;
+                const bf16x8 l = Act<__bf16>::ld8(a.dout, e);
+                v[im] = ok ? l : zero8;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) bsum[c] += (float)v[im][c];
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 8; ++c) {
                 bf16x8 u;
 #pragma unroll
-                for (int im = 0; im < 8; ++im) u[im] = (__bf16)v[im][c];
-                lds_d[px * 32 + quad * 4 + c] = u;
+                for (int im = 0; im < 8; ++im) u[im] = v[im][c];
+                lds_d[px * 32 + oct * 8 + c] = u;
             }
         }
         __syncthreads();
@@ -589,8 +634,9 @@ __global__ __launch_bounds__(256, 2) void conv5x5_wgrad_bf16_kernel(WgradBf16Arg
 #pragma unroll
         for (int v = 0; v < 16; ++v) red[((wave - 1) * 16 + v) * 64 + lane] = acc[6][v];
     }
-    f32x4* bred = reinterpret_cast<f32x4*>(red + 3 * 16 * 64);
-    bred[tid] = bsum;
+    f32x4* bred = reinterpret_cast<f32x4*>(red + 3 * 16 * 64);      // [256 threads][2 halves of the thread's 8 channels]
+    bred[tid * 2] = f32x4{bsum[0], bsum[1], bsum[2], bsum[3]};
+    bred[tid * 2 + 1] = f32x4{bsum[4], bsum[5], bsum[6], bsum[7]};
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
@@ -600,9 +646,9 @@ __global__ __launch_bounds__(256, 2) void conv5x5_wgrad_bf16_kernel(WgradBf16Arg
             out[((size_t)24 * CIN + ci) * COUT + n0 + li] = x;
         }
     }
-    if (blockIdx.y == 0 && tid < 8) {
+    if (blockIdx.y == 0 && tid < 8) {          // channel quad tid = half (tid & 1) of octet (tid >> 1): 64 threads staged it
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < 32; ++k) s += bred[k * 8 + tid];
+        for (int k = 0; k < 64; ++k) s += bred[(k * 4 + (tid >> 1)) * 2 + (tid & 1)];
         *reinterpret_cast<f32x4*>(out + (size_t)25 * CIN * COUT + n0 + tid * 4) = s;
     }
 }
@@ -629,7 +675,7 @@ static int run_wgrad_bf16(int B, const float* in, const float* dout, float* dw, 
     const int64_t n = (int64_t)25 * CIN * COUT, row = n + COUT;
     if (need) { *need = (int64_t)(S + 16) * row; return 0; }
     WgradBf16Args a{in, dout, ws, B, numTiles, tps};
-    constexpr int STAGE = (T::HP + T::NPX) * 32 * 16, RED = (3 * 16 * 64) * 4 + 256 * 16;
+    constexpr int STAGE = (T::HP + T::NPX) * 32 * 16, RED = (3 * 16 * 64) * 4 + 256 * 32;
     constexpr int SMEM = STAGE > RED ? STAGE : RED;
     auto kern = conv5x5_wgrad_bf16_kernel<CIN, COUT, H>;
     static DeviceOnce once;
@@ -697,55 +743,63 @@ __global__ __launch_bounds__(256, 2) void conv_up_wgrad_bf16_kernel(WgradBf16Arg
     bf16x8* lds_d = lds_in + T::HP * 32;                        // [phase][pixel][32 co]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int split = blockIdx.x, ci0 = blockIdx.y * 32, n0 = blockIdx.z * 32;
-    const int quad = tid & 7;
+    const int oct = tid & 3;
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    float bsum[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) bsum[c] = 0.f;
+    bf16x8 zero8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) zero8[c] = (__bf16)0.f;
     const int t0 = split * a.tilesPerSplit;
     int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
     for (int mt = t0; mt < t1; ++mt) {
         const int grp = mt / T::TILES_PER_GRP, t = mt % T::TILES_PER_GRP;
         const int img0 = grp * 8, ty0 = (t / T::TILES_X) * T::TH, tx0 = (t % T::TILES_X) * T::TW;
         __syncthreads();
-        for (int q = tid; q < T::HP * 8; q += 256) {
-            const int hp = q >> 3;
+        for (int q = tid; q < T::HP * 4; q += 256) {
+            const int hp = q >> 2;
             const int gy = ty0 + hp / T::HTW - 1, gx = tx0 + hp % T::HTW - 1;
             const bool inb = (unsigned)gy < (unsigned)HS && (unsigned)gx < (unsigned)HS;
-            f32x4 v[8];
+            bf16x8 v[8];
 #pragma unroll
             for (int im = 0; im < 8; ++im) {
-                v[im] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (inb && img0 + im < a.B)
-                    v[im] = *reinterpret_cast<const f32x4*>(a.in + ((size_t)((img0 + im) * HS + gy) * HS + gx) * CIN + ci0 + quad * 4);
+                const bool ok = inb && img0 + im < a.B;
+                const size_t e = ok ? ((size_t)((img0 + im) * HS + gy) * HS + gx) * CIN + ci0 + oct * 8 : 0;
+                const bf16x8 l = Act<__bf16>::ld8(a.in, e);
+                v[im] = ok ? l : zero8;
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 8; ++c) {
                 bf16x8 u;
 #pragma unroll
-                for (int im = 0; im < 8; ++im) u[im] = (__bf16)v[im][c];
-                lds_in[hp * 32 + quad * 4 + c] = u;
+                for (int im = 0; im < 8; ++im) u[im] = v[im][c];
+                lds_in[hp * 32 + oct * 8 + c] = u;
             }
         }
-        for (int q = tid; q < 4 * T::NPX * 8; q += 256) {
-            const int px = (q >> 3) % T::NPX, p = q / (8 * T::NPX);
+        for (int q = tid; q < 4 * T::NPX * 4; q += 256) {
+            const int px = (q >> 2) % T::NPX, p = q / (4 * T::NPX);
             const int oy = 2 * (ty0 + px / T::TW) + (p >> 1), ox = 2 * (tx0 + px % T::TW) + (p & 1);
-            f32x4 v[8];
+            bf16x8 v[8];
 #pragma unroll
             for (int im = 0; im < 8; ++im) {
-                v[im] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (img0 + im < a.B)
-                    v[im] = *reinterpret_cast<const f32x4*>(a.dout + ((size_t)((img0 + im) * H + oy) * H + ox) * COUT + n0 + quad * 4);
-                bsum += v[im];
+                const bool ok = img0 + im < a.B;
+                const size_t e = ok ? ((size_t)((img0 + im) * H + oy) * H + ox) * COUT + n0 + oct * 8 : 0;
+                const bf16x8 l = Act<__bf16>::ld8(a.dout, e);
+                v[im] = ok ? l : zero8;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) bsum[c] += (float)v[im][c];
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 8; ++c) {
                 bf16x8 u;
 #pragma unroll
-                for (int im = 0; im < 8; ++im) u[im] = (__bf16)v[im][c];
-                lds_d[(p * T::NPX + px) * 32 + quad * 4 + c] = u;
+                for (int im = 0; im < 8; ++im) u[im] = v[im][c];
+                lds_d[(p * T::NPX + px) * 32 + oct * 8 + c] = u;
             }
         }
         __syncthreads();
@@ -770,11 +824,12 @@ __global__ __launch_bounds__(256, 2) void conv_up_wgrad_bf16_kernel(WgradBf16Arg
         }
     __syncthreads();
     f32x4* bred = reinterpret_cast<f32x4*>(smem_raw);
-    bred[tid] = bsum;
+    bred[tid * 2] = f32x4{bsum[0], bsum[1], bsum[2], bsum[3]};
+    bred[tid * 2 + 1] = f32x4{bsum[4], bsum[5], bsum[6], bsum[7]};
     __syncthreads();
     if (blockIdx.y == 0 && tid < 8) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < 32; ++k) s += bred[k * 8 + tid];
+        for (int k = 0; k < 64; ++k) s += bred[(k * 4 + (tid >> 1)) * 2 + (tid & 1)];
         *reinterpret_cast<f32x4*>(out + (size_t)36 * CIN * COUT + n0 + tid * 4) = s;
     }
 }

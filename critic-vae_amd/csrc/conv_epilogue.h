@@ -10,7 +10,7 @@ enum { EPI_BIAS_BNSTAT = 0, EPI_BIAS_RELU = 1, EPI_PLAIN = 2, EPI_POOLSUM_MASK =
 // per-channel BatchNorm partials (sum, M2 about the tile mean) that bn_fwd_finalize merges
 // (train-mode batch statistics of nn.BatchNorm2d, vae_nets.py:70,75,80,85).
 // `smem` is reused (a barrier precedes the first write) and must hold >= max(8*NT, 4*32*36) floats.
-template <int H, int NT, int NCH, int EPI>
+template <int H, int NT, int NCH, int EPI, typename AT = float>      // AT: storage type of `out` (bf16 in precision mode 1)
 __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[NT / 32], const float* bias, float* out,
                                                float* bnpart, float* smem, int B, int mt, int n0,
                                                int img0, int ty0, int tx0) {
@@ -35,6 +35,21 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[NT / 32], const flo
             acc[nb][v] = x;
             patch[((v & 3) + 8 * (v >> 2) + 4 * lh) * 36 + li] = x;
         }
+        if constexpr (Act<AT>::BF16) {        // 8 channels = one 16-byte unit per lane: 2 store instructions per tile
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int idx = it * 64 + lane, px = idx >> 2, c8 = idx & 3;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(patch + px * 36 + c8 * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(patch + px * 36 + c8 * 8 + 4);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = (__bf16)lo[e]; o[4 + e] = (__bf16)hi[e]; }
+                const int mm = wave * 32 + px;
+                const int im = mm / (T::TH * T::TW), rem = mm % (T::TH * T::TW);
+                const int gy = ty0 + rem / T::TW, gx = tx0 + rem % T::TW, ib = img0 + im;
+                if (ib < B) Act<AT>::st8(out, ((size_t)(ib * H + gy) * H + gx) * NCH + n0 + nb * 32 + c8 * 8, o);
+            }
+        } else {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int idx = it * 64 + lane, px = idx >> 3, c4 = idx & 7;
@@ -44,6 +59,7 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[NT / 32], const flo
             const int gy = ty0 + rem / T::TW, gx = tx0 + rem % T::TW, ib = img0 + im;
             if (ib < B)
                 *reinterpret_cast<float4*>(out + ((size_t)(ib * H + gy) * H + gx) * NCH + n0 + nb * 32 + c4 * 4) = val;
+        }
         }
     }
     if (EPI == EPI_BIAS_BNSTAT) {

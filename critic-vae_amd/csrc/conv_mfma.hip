@@ -215,6 +215,7 @@ static int run(const ConvArgs& a, hipStream_t st) {
 }
 
 // out[i] = relu(bias[i % C] + sum_z slab[z][i])   (split-K finish of the decoder head)
+template <typename AT>
 __global__ __launch_bounds__(256) void splitk_bias_relu_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
                                                                float* __restrict__ out, int64_t n4, int64_t slice, int KS, int C) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -225,11 +226,13 @@ __global__ __launch_bounds__(256) void splitk_bias_relu_kernel(const float* __re
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
-    *reinterpret_cast<float4*>(out + i * 4) = acc;
+    Act<AT>::st4(out, (size_t)i * 4, f32x4{acc.x, acc.y, acc.z, acc.w});
 }
 
-int launch_splitk_bias_relu(const float* slab, const float* bias, float* out, int64_t slice, int KS, int C, hipStream_t st) {
-    hipLaunchKernelGGL(splitk_bias_relu_kernel, dim3((unsigned)((slice / 4 + 255) / 256)), dim3(256), 0, st, slab, bias, out,
+int launch_splitk_bias_relu(const float* slab, const float* bias, float* out, int64_t slice, int KS, int C, hipStream_t st, bool out_bf16) {
+    if (out_bf16) hipLaunchKernelGGL(splitk_bias_relu_kernel<__bf16>, dim3((unsigned)((slice / 4 + 255) / 256)), dim3(256), 0, st, slab, bias, out,
+                                     slice / 4, slice, KS, C);
+    else hipLaunchKernelGGL(splitk_bias_relu_kernel<float>, dim3((unsigned)((slice / 4 + 255) / 256)), dim3(256), 0, st, slab, bias, out,
                        slice / 4, slice, KS, C);
     CVAE_CHECK_LAUNCH();
     return 0;
@@ -255,7 +258,7 @@ int launch_conv_fwd(int layer, int width, int B, const float* in, const float* w
                 a.out = ws; a.sliceFloats = slice;
                 int rc = run<256, 128, 4, false, false, 64, EPI_PLAIN, D0_KSPLIT>(a, st);
                 if (rc) return rc;
-                hipLaunchKernelGGL(splitk_bias_relu_kernel, dim3((unsigned)((slice / 4 + 255) / 256)), dim3(256), 0, st,
+                hipLaunchKernelGGL(splitk_bias_relu_kernel<float>, dim3((unsigned)((slice / 4 + 255) / 256)), dim3(256), 0, st,
                                    ws, bias, out, slice / 4, slice, D0_KSPLIT, 128);
                 CVAE_CHECK_LAUNCH();
                 return 0;

@@ -103,11 +103,24 @@ __global__ __launch_bounds__(256) void e1_fwd_kernel(const float* __restrict__ x
             patch[((v & 3) + 8 * (v >> 2) + 4 * lh) * 36 + li] = val;
         }
         const int gy = ty0 + wave * 4 + r;
+        if (BF16) {             // precision mode 1: y1 is stored as bf16, 8 channels = one 16-byte unit per lane
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int idx = it * 64 + lane, px = idx >> 2, c8 = idx & 3;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(patch + px * 36 + c8 * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(patch + px * 36 + c8 * 8 + 4);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = (__bf16)lo[e]; o[4 + e] = (__bf16)hi[e]; }
+                Act<__bf16>::st8(y, ((size_t)(ib * H + gy) * H + tx0 + px) * 32 + c8 * 8, o);
+            }
+        } else {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int idx = it * 64 + lane, px = idx >> 3, c4 = idx & 7;
             const float4 val = *reinterpret_cast<const float4*>(patch + px * 36 + c4 * 4);
             *reinterpret_cast<float4*>(y + ((size_t)(ib * H + gy) * H + tx0 + px) * 32 + c4 * 4) = val;
+        }
         }
     }
     s += __shfl_xor(s, 32, 64);
@@ -173,7 +186,7 @@ __device__ __forceinline__ void thin_slab_out(f32x16 (&acc)[3], float* red, floa
 }
 
 // tile mt of E1 wgrad into registers: x halo (3 planes, zero padded) and the 128x32 dy tile
-template <int H>
+template <int H, bool BF16>
 __device__ __forceinline__ void e1_wgrad_fetch(const ThinWgradArgs& a, int mt, float (&rx)[(3 * Tile<H>::HPI + 255) / 256],
                                                f32x4 (&rd)[4]) {
     using T = Tile<H>;
@@ -189,6 +202,17 @@ __device__ __forceinline__ void e1_wgrad_fetch(const ThinWgradArgs& a, int mt, f
         if (q < 3 * T::HPI && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H)
             v = a.a0[((size_t)(ib * 3 + c) * H + gy) * H + gx];
         rx[i] = v;
+    }
+    if (BF16) {          // dy is bf16 (precision mode 1): two 16-byte units per thread, widened to the same 4 x f32x4
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + i * 256, c8 = q & 3, mm = q >> 2;
+            const int gy = ty0 + mm / T::TW, gx = tx0 + mm % T::TW;
+            const bf16x8 v = Act<__bf16>::ld8(a.a1, ((size_t)(ib * H + gy) * H + gx) * 32 + c8 * 8);
+            rd[2 * i] = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+            rd[2 * i + 1] = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+        }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -230,7 +254,7 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
     constexpr int XQ = (3 * T::HPI + 255) / 256;
     float rx[XQ];
     f32x4 rd[4];
-    if (t0 < t1) e1_wgrad_fetch<H>(a, t0, rx, rd);
+    if (t0 < t1) e1_wgrad_fetch<H, BF16>(a, t0, rx, rd);
     for (int mt = t0; mt < t1; ++mt) {
         __syncthreads();
 #pragma unroll
@@ -240,11 +264,13 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int q = tid + i * 256;
-            *reinterpret_cast<f32x4*>(lds_d + (q >> 3) * 32 + (q & 7) * 4) = rd[i];
+            // BF16: rd[2i], rd[2i+1] = the two halves of 16-byte unit q = tid + i*256 (pixel q>>2, octet q&3)
+            const int q = BF16 ? tid + (i >> 1) * 256 : tid + i * 256;
+            float* d = BF16 ? lds_d + (q >> 2) * 32 + (q & 3) * 8 + (i & 1) * 4 : lds_d + (q >> 3) * 32 + (q & 7) * 4;
+            *reinterpret_cast<f32x4*>(d) = rd[i];
         }
         __syncthreads();
-        if (mt + 1 < t1) e1_wgrad_fetch<H>(a, mt + 1, rx, rd);
+        if (mt + 1 < t1) e1_wgrad_fetch<H, BF16>(a, mt + 1, rx, rd);
         if (BF16) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -358,7 +384,7 @@ __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f / (__ex
 // weights B[ci][tap*3+co] live in 48 registers per lane, the next tile's window is fetched into
 // registers while the MFMAs of the current one run, and the tap gather + Tanh + NCHW store of one
 // workgroup overlaps the MFMAs of the other workgroup on the CU.
-template <int H>   // H = output size (64); source o3 is (H/2)^2 x 32 NHWC
+template <int H, typename AT>   // H = output size (64); source o3 is (H/2)^2 x 32 NHWC, stored as AT
 __global__ __launch_bounds__(256) void d4_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ recon, int B) {
     constexpr int HS = H / 2, TX = H / 16, TPI = TX * TX;
@@ -384,8 +410,10 @@ __global__ __launch_bounds__(256) void d4_fwd_kernel(const float* __restrict__ i
             const int q = tid + i * 256, c4 = q & 7, sp = q >> 3;
             const int sy = sy0 + sp / 10, sx = sx0 + sp % 10;
             ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (sp < 100 && (unsigned)sy < (unsigned)HS && (unsigned)sx < (unsigned)HS)
-                ra[i] = *reinterpret_cast<const float4*>(in + ((size_t)(ib * HS + sy) * HS + sx) * 32 + c4 * 4);
+            if (sp < 100 && (unsigned)sy < (unsigned)HS && (unsigned)sx < (unsigned)HS) {
+                const f32x4 v = Act<AT>::ld4(in, ((size_t)(ib * HS + sy) * HS + sx) * 32 + c4 * 4);
+                ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+            }
         }
     };
     if ((int)blockIdx.x < numTiles) fetch(blockIdx.x);
@@ -459,7 +487,7 @@ __global__ __launch_bounds__(256) void d4_actbwd_kernel(const float* __restrict_
 }
 
 // tile mt of the D4 backward into registers: dOut halo planes [3][20][36] (zero padded) and the o3 tile
-template <int H>
+template <int H, typename AT>
 __device__ __forceinline__ void d4_bwd_fetch(const ThinWgradArgs& a, int mt, float (&rg)[(3 * 720 + 255) / 256], f32x4 (&ro)[4]) {
     constexpr int HS = H / 2, TPI = (HS / 8) * (HS / 16), G0 = 3 * 720;
     const int tid = threadIdx.x;
@@ -477,12 +505,11 @@ __device__ __forceinline__ void d4_bwd_fetch(const ThinWgradArgs& a, int mt, flo
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int q = tid + i * 256, c4 = q & 7, sp = q >> 3;
-        ro[i] = *reinterpret_cast<const f32x4*>(
-            a.a1 + ((size_t)(ib * HS + sy0 + sp / 16) * HS + sx0 + sp % 16) * 32 + c4 * 4);
+        ro[i] = Act<AT>::ld4(a.a1, ((size_t)(ib * HS + sy0 + sp / 16) * HS + sx0 + sp % 16) * 32 + c4 * 4);
     }
 }
 
-template <int H>   // H = output size (64); src tiles of 8 rows x 16 cols at HS = H/2
+template <int H, typename AT>   // H = output size (64); src tiles of 8 rows x 16 cols at HS = H/2; o3 / d_o3 stored as AT
 __global__ __launch_bounds__(256) void d4_bwd_kernel(ThinWgradArgs a) {
     constexpr int HS = H / 2, TPI = (HS / 8) * (HS / 16);
     constexpr int G0 = 3 * 720, O = 128 * 32, G = 128 * 77 + 32, WR = 76 * 32;
@@ -510,7 +537,7 @@ __global__ __launch_bounds__(256) void d4_bwd_kernel(ThinWgradArgs a) {
     constexpr int GQ = (G0 + 255) / 256;
     float rg[GQ];
     f32x4 ro[4];
-    if (t0 < t1) d4_bwd_fetch<H>(a, t0, rg, ro);
+    if (t0 < t1) d4_bwd_fetch<H, AT>(a, t0, rg, ro);
     const int gsp = tid & 127, ghalf = tid >> 7, gsy = gsp >> 4, gsx = gsp & 15;
     for (int mt = t0; mt < t1; ++mt) {
         const int ib = mt / TPI, t = mt % TPI;
@@ -527,7 +554,7 @@ __global__ __launch_bounds__(256) void d4_bwd_kernel(ThinWgradArgs a) {
             *reinterpret_cast<f32x4*>(lds_o + (q >> 3) * 32 + (q & 7) * 4) = ro[i];
         }
         __syncthreads();
-        if (mt + 1 < t1) d4_bwd_fetch<H>(a, mt + 1, rg, ro);
+        if (mt + 1 < t1) d4_bwd_fetch<H, AT>(a, mt + 1, rg, ro);
         // G[src][(r*5+s)*3+co] = sum of dOut over the 2x2 block of src shifted by the tap: thread =
         // (src pixel, half of the 15 (co, r) pairs); the five s taps of a pair share six column sums
 #pragma unroll
@@ -561,7 +588,7 @@ __global__ __launch_bounds__(256) void d4_bwd_kernel(ThinWgradArgs a) {
         for (int v = 0; v < 16; ++v) {
             const int sp = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
             const float x = lds_o[sp * 32 + li] > 0.f ? accd[v] : 0.f;
-            a.din[((size_t)(ib * HS + sy0 + sp / 16) * HS + sx0 + sp % 16) * 32 + li] = x;
+            Act<AT>::st(a.din, ((size_t)(ib * HS + sy0 + sp / 16) * HS + sx0 + sp % 16) * 32 + li, x);
         }
         // wgrad: dW[k][ci] += sum_src G[src][k] * o3[src][ci]
 #pragma unroll
@@ -587,11 +614,13 @@ int64_t d4_bwd_ws_floats(int width, int B) {
     return (int64_t)d4_splits(width, B, &tps) * 3072 + align_up((int64_t)B * 3, 64) + 3072 + col_reduce_ws_floats(3072);
 }
 
-int launch_d4_fwd(int width, int B, const float* in, const float* w, const float* bias, float* recon, hipStream_t st) {
+int launch_d4_fwd(int width, int B, const float* in, const float* w, const float* bias, float* recon, hipStream_t st, bool bf16io) {
     // 66 KB of LDS -> two workgroups per CU, each looping over its share of the 16x16 tiles
     const int tiles = B * (width / 16) * (width / 16), grid = tiles < 512 ? tiles : 512;
-    if (width == 64) hipLaunchKernelGGL(d4_fwd_kernel<64>, dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
-    else if (width == 128) hipLaunchKernelGGL(d4_fwd_kernel<128>, dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
+    if (width == 64 && bf16io) hipLaunchKernelGGL((d4_fwd_kernel<64, __bf16>), dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
+    else if (width == 128 && bf16io) hipLaunchKernelGGL((d4_fwd_kernel<128, __bf16>), dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
+    else if (width == 64) hipLaunchKernelGGL((d4_fwd_kernel<64, float>), dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
+    else if (width == 128) hipLaunchKernelGGL((d4_fwd_kernel<128, float>), dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
     else { cvae_set_error("d4_fwd: width %d unsupported", width); return -2; }
     CVAE_CHECK_LAUNCH();
     return 0;
@@ -599,7 +628,7 @@ int launch_d4_fwd(int width, int B, const float* in, const float* w, const float
 
 // Fused D4 backward: Tanh backward -> dout planes (B,3,W,W), then d_o3 (ReLU-masked), dW4, db4.
 int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const float* recon, const float* w,
-                  float* dout, float* d_o3, float* dw, float* db, float* ws, hipStream_t st) {
+                  float* dout, float* d_o3, float* dw, float* db, float* ws, hipStream_t st, bool bf16io) {
     if (width != 64 && width != 128) { cvae_set_error("d4_bwd: width %d unsupported", width); return -2; }
     int tps;
     const int tiles = B * (width / 16) * (width / 32);
@@ -608,12 +637,11 @@ int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const
     hipLaunchKernelGGL(d4_actbwd_kernel, dim3(B * 3), dim3(256), 0, st, d_recon, recon, dout, plane_sums, width * width);
     CVAE_CHECK_LAUNCH();
     ThinWgradArgs a{dout, o3, w, d_o3, ws, B, tiles, tps};
-    static DeviceOnce once64, once128;
-    { int rc = width == 64 ? cvae_grant_lds(once64, reinterpret_cast<const void*>(d4_bwd_kernel<64>), D4_BWD_SMEM)
-                           : cvae_grant_lds(once128, reinterpret_cast<const void*>(d4_bwd_kernel<128>), D4_BWD_SMEM);
-      if (rc) return rc; }
-    if (width == 64) hipLaunchKernelGGL(d4_bwd_kernel<64>, dim3(S), dim3(256), D4_BWD_SMEM, st, a);
-    else hipLaunchKernelGGL(d4_bwd_kernel<128>, dim3(S), dim3(256), D4_BWD_SMEM, st, a);
+    static DeviceOnce once[4];
+    void (*kern)(ThinWgradArgs) = width == 64 ? (bf16io ? d4_bwd_kernel<64, __bf16> : d4_bwd_kernel<64, float>)
+                                              : (bf16io ? d4_bwd_kernel<128, __bf16> : d4_bwd_kernel<128, float>);
+    { int rc = cvae_grant_lds(once[(width == 128) * 2 + bf16io], reinterpret_cast<const void*>(kern), D4_BWD_SMEM); if (rc) return rc; }
+    hipLaunchKernelGGL(kern, dim3(S), dim3(256), D4_BWD_SMEM, st, a);
     CVAE_CHECK_LAUNCH();
     float* red = plane_sums + align_up((int64_t)B * 3, 64);
     { int rc = launch_col_reduce(ws, S, 3072, 3072, red, red + 3072, st); if (rc) return rc; }

@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5_wgrad_kernel(WgradArgs a) {
 // dst[i] = sum_s slab[s*stride + i] over s in [s0, s0+cnt), fixed order.  grid (n/4/256, RA): each
 // row-chunk y writes its partial to dst + y*n (two passes when S is large and n small, so that
 // enough loads are in flight to run at HBM speed).
+template <typename AT>
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ dst,
                                                            int64_t n, int S, int64_t stride, int perChunk) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
         const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)s * stride + i);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-    *reinterpret_cast<float4*>(dst + (size_t)blockIdx.y * n + i) = acc;
+    Act<AT>::st4(dst, (size_t)blockIdx.y * n + i, f32x4{acc.x, acc.y, acc.z, acc.w});
 }
 
 // One launch for many slabs: a workgroup owns 16 consecutive float4 outputs; its 16 thread groups add
@@ -206,8 +207,14 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __r
 // `slab`, `stride` and n must keep 16-byte alignment (n % 4 == 0).  S <= 32: one thread per output adds
 // all rows; larger S: the wide kernel above (`mid` is kept in the signature for callers that size it,
 // it is no longer written).
-int launch_reduce_slabs(const float* slab, float* dst, int64_t n, int S, int64_t stride, hipStream_t st, float* mid) {
+int launch_reduce_slabs(const float* slab, float* dst, int64_t n, int S, int64_t stride, hipStream_t st, float* mid, bool out_bf16) {
     (void)mid;
+    if (out_bf16) {          // activation-gradient slabs (split-K dgrad) in precision mode 1: few slabs, bf16 result
+        const unsigned gx = (unsigned)((n / 4 + 255) / 256);
+        hipLaunchKernelGGL(reduce_slabs_kernel<__bf16>, dim3(gx, 1), dim3(256), 0, st, slab, dst, n, S, stride, S);
+        CVAE_CHECK_LAUNCH();
+        return 0;
+    }
     if (S > 32) {
         const int64_t n4 = n / 4;
         hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, slab, dst, n4, S, stride);
@@ -215,7 +222,7 @@ int launch_reduce_slabs(const float* slab, float* dst, int64_t n, int S, int64_t
         return 0;
     }
     const unsigned gx = (unsigned)((n / 4 + 255) / 256);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, 1), dim3(256), 0, st, slab, dst, n, S, stride, S);
+    hipLaunchKernelGGL(reduce_slabs_kernel<float>, dim3(gx, 1), dim3(256), 0, st, slab, dst, n, S, stride, S);
     CVAE_CHECK_LAUNCH();
     return 0;
 }

@@ -14,7 +14,7 @@ static constexpr int FC_IMGS = 16;       // images per workgroup
 // A is [M][K] row-major.  B_KMAJOR == false: Bm(k,n) = Bp[k*64 + n] (fc_mu|fc_var weights, N = 64);
 // B_KMAJOR == true : Bm(k,n) = Bp[n*K + k] for n < NV, 0 otherwise (decoder_input transposed, NV = 33).
 // WG = 128 rows x 64 columns x one K-slice; wave w owns rows 32w..32w+31 and both 32-column tiles.
-template <bool B_KMAJOR>
+template <bool B_KMAJOR, typename AT>       // AT = storage type of A (an activation / activation gradient)
 __global__ __launch_bounds__(256) void latent_gemm_kernel(const float* __restrict__ A, const float* __restrict__ Bp,
                                                           float* __restrict__ slab, int M, int K, int kslice, int NV) {
     __shared__ float lds_a[128 * 33];
@@ -30,10 +30,10 @@ __global__ __launch_bounds__(256) void latent_gemm_kernel(const float* __restric
         __syncthreads();
         for (int q = tid; q < 128 * 8; q += 256) {
             const int c4 = q & 7, r = q >> 3;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + r < M) v = *reinterpret_cast<const float4*>(A + (size_t)(m0 + r) * K + kc + c4 * 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m0 + r < M) v = Act<AT>::ld4(A, (size_t)(m0 + r) * K + kc + c4 * 4);
             float* d = lds_a + r * 33 + c4 * 4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         }
         if (!B_KMAJOR) {
             for (int q = tid; q < 32 * 16; q += 256) {
@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void fc_finish_kernel(const float* __restrict_
 }
 
 // h[b][j] = bd[j] + sum_i zcat[b][i] * Wd[i][j]
+template <typename AT>
 __global__ __launch_bounds__(256) void decin_fwd_kernel(const float* __restrict__ zcat, const float* __restrict__ wd,
                                                         const float* __restrict__ bd, float* __restrict__ h, int K) {
     __shared__ float z[33];
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void decin_fwd_kernel(const float* __restrict_
         acc.x = fmaf(z[i], w.x, acc.x); acc.y = fmaf(z[i], w.y, acc.y);
         acc.z = fmaf(z[i], w.z, acc.z); acc.w = fmaf(z[i], w.w, acc.w);
     }
-    *reinterpret_cast<float4*>(h + (size_t)b * K + j) = acc;
+    Act<AT>::st4(h, (size_t)b * K + j, f32x4{acc.x, acc.y, acc.z, acc.w});
 }
 
 // dzcat[b][i] = sum_j dh[b][j] * Wd[i][j].  One wave = 2 images x all 33 rows of Wd: lanes split K,
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(256) void decin_bwd_dz_kernel(const float* __restri
 }
 
 // slab[bs][i][j] (i<33: dWd, i==33: dbd) = sum over the batch slice bs
+template <typename AT>
 __global__ __launch_bounds__(256) void decin_bwd_dw_kernel(const float* __restrict__ zcat, const float* __restrict__ dh,
                                                            float* __restrict__ slab, int B, int K, int bPerSplit) {
     constexpr int ZB = 16;                          // batch rows staged per barrier pair
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256) void decin_bwd_dw_kernel(const float* __restri
         for (int q = threadIdx.x; q < nb * 33; q += 256) z[q] = zcat[bb * 33 + q];
         __syncthreads();
         for (int r = 0; r < nb; ++r) {
-            const float g = dh[(size_t)(bb + r) * K + j];
+            const float g = Act<AT>::ld(dh, (size_t)(bb + r) * K + j);
 #pragma unroll
             for (int i = 0; i < 33; ++i) acc[i] = fmaf(z[r * 33 + i], g, acc[i]);
             acc[33] += g;
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(256) void fc_bwd_prep_kernel(const float* __restric
 }
 
 // dflat[b][k] = sum_n dml[b][n] * Wfc[k][n]
+template <typename AT>
 __global__ __launch_bounds__(256) void fc_bwd_dflat_kernel(const float* __restrict__ dml, const float* __restrict__ wfc,
                                                            float* __restrict__ dflat, int B, int K) {
     __shared__ float g[8][64];
@@ -236,19 +239,20 @@ __global__ __launch_bounds__(256) void fc_bwd_dflat_kernel(const float* __restri
         float acc = 0.f;
 #pragma unroll
         for (int n = 0; n < 64; ++n) acc = fmaf(g[i][n], w[n], acc);
-        dflat[(size_t)(b0 + i) * K + k] = acc;
+        Act<AT>::st(dflat, (size_t)(b0 + i) * K + k, acc);
     }
 }
 
 // dWfc[k][n] = sum_b flat[b][k] * dml[b][n]    (16 k-rows per workgroup: each wave 4 rows x 64 columns, all of
 // the batch; the four flat values of a row group are one 16-byte wave-uniform load per image)
+template <typename AT>
 __global__ __launch_bounds__(256) void fc_bwd_dw_kernel(const float* __restrict__ flat, const float* __restrict__ dml,
                                                         float* __restrict__ dwfc, int B, int K) {
     const int n = threadIdx.x & 63, k = blockIdx.x * 16 + (threadIdx.x >> 6) * 4;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll 8
     for (int b = 0; b < B; ++b) {
-        const f32x4 f = *reinterpret_cast<const f32x4*>(flat + (size_t)b * K + k);
+        const f32x4 f = Act<AT>::ld4(flat, (size_t)b * K + k);
         const float d = dml[(size_t)b * 64 + n];
         a0 = fmaf(f.x, d, a0); a1 = fmaf(f.y, d, a1); a2 = fmaf(f.z, d, a2); a3 = fmaf(f.w, d, a3);
     }
@@ -268,31 +272,35 @@ int64_t fc_ws_floats(int width, int B) {
 }
 
 int launch_fc_fwd(int width, int B, const float* flat, const float* wfc, const float* bfc, const float* eps,
-                  const float* pred, float* mu, float* logvar, float* zcat, float* ws, hipStream_t st) {
+                  const float* pred, float* mu, float* logvar, float* zcat, float* ws, hipStream_t st, bool bf16io) {
     const int K = bott(width);
-    hipLaunchKernelGGL(latent_gemm_kernel<false>, dim3(cdiv(B, 128), FC_KS), dim3(256), 0, st, flat, wfc, ws, B, K, K / FC_KS, 64);
+    if (bf16io) hipLaunchKernelGGL((latent_gemm_kernel<false, __bf16>), dim3(cdiv(B, 128), FC_KS), dim3(256), 0, st, flat, wfc, ws, B, K, K / FC_KS, 64);
+    else hipLaunchKernelGGL((latent_gemm_kernel<false, float>), dim3(cdiv(B, 128), FC_KS), dim3(256), 0, st, flat, wfc, ws, B, K, K / FC_KS, 64);
     CVAE_CHECK_LAUNCH();
     hipLaunchKernelGGL(fc_finish_kernel, dim3(cdiv(B * 32, 256)), dim3(256), 0, st, ws, bfc, eps, pred, mu, logvar, zcat, B);
     CVAE_CHECK_LAUNCH();
     return 0;
 }
 
-int launch_decin_fwd(int width, int B, const float* zcat, const float* wd, const float* bd, float* h, hipStream_t st) {
+int launch_decin_fwd(int width, int B, const float* zcat, const float* wd, const float* bd, float* h, hipStream_t st, bool bf16io) {
     const int K = bott(width);
-    hipLaunchKernelGGL(decin_fwd_kernel, dim3(B, K / 1024), dim3(256), 0, st, zcat, wd, bd, h, K);
+    if (bf16io) hipLaunchKernelGGL(decin_fwd_kernel<__bf16>, dim3(B, K / 1024), dim3(256), 0, st, zcat, wd, bd, h, K);
+    else hipLaunchKernelGGL(decin_fwd_kernel<float>, dim3(B, K / 1024), dim3(256), 0, st, zcat, wd, bd, h, K);
     CVAE_CHECK_LAUNCH();
     return 0;
 }
 
 int launch_decin_bwd(int width, int B, const float* zcat, const float* dh, const float* wd, float* dwd, float* dbd,
-                     float* dzcat, float* ws, hipStream_t st) {
+                     float* dzcat, float* ws, hipStream_t st, bool bf16io) {
     const int K = bott(width);
-    hipLaunchKernelGGL(latent_gemm_kernel<true>, dim3(cdiv(B, 128), FC_KS), dim3(256), 0, st, dh, wd, ws, B, K, K / FC_KS, 33);
+    if (bf16io) hipLaunchKernelGGL((latent_gemm_kernel<true, __bf16>), dim3(cdiv(B, 128), FC_KS), dim3(256), 0, st, dh, wd, ws, B, K, K / FC_KS, 33);
+    else hipLaunchKernelGGL((latent_gemm_kernel<true, float>), dim3(cdiv(B, 128), FC_KS), dim3(256), 0, st, dh, wd, ws, B, K, K / FC_KS, 33);
     CVAE_CHECK_LAUNCH();
     hipLaunchKernelGGL(decin_dz_finish_kernel, dim3(cdiv(B * 33, 256)), dim3(256), 0, st, ws, dzcat, B, FC_KS);
     CVAE_CHECK_LAUNCH();
     const int S = decin_splits(B), bps = cdiv(B, S);
-    hipLaunchKernelGGL(decin_bwd_dw_kernel, dim3(K / 256, S), dim3(256), 0, st, zcat, dh, ws, B, K, bps);
+    if (bf16io) hipLaunchKernelGGL(decin_bwd_dw_kernel<__bf16>, dim3(K / 256, S), dim3(256), 0, st, zcat, dh, ws, B, K, bps);
+    else hipLaunchKernelGGL(decin_bwd_dw_kernel<float>, dim3(K / 256, S), dim3(256), 0, st, zcat, dh, ws, B, K, bps);
     CVAE_CHECK_LAUNCH();
     int rc = launch_reduce_slabs(ws, dwd, (int64_t)33 * K, S, (int64_t)34 * K, st);
     if (rc) return rc;
@@ -301,7 +309,7 @@ int launch_decin_bwd(int width, int B, const float* zcat, const float* dh, const
 
 int launch_fc_bwd(int width, int B, const float* flat, const float* wfc, const float* dzcat, const float* eps,
                   const float* logvar, const float* dmu_loss, const float* dlv_loss, float* dwfc, float* dbfc,
-                  float* dflat, float* ws, hipStream_t st) {
+                  float* dflat, float* ws, hipStream_t st, bool bf16io) {
     const int K = bott(width);
     const int64_t a = (int64_t)FC_KS * B * 64, b = (int64_t)decin_splits(B) * 34 * K;
     float* dml = ws + (a > b ? a : b);
@@ -310,9 +318,11 @@ int launch_fc_bwd(int width, int B, const float* flat, const float* wfc, const f
     CVAE_CHECK_LAUNCH();
     int rc = launch_colsum(dml, B, 64, dbfc, csws, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(fc_bwd_dflat_kernel, dim3(cdiv(B, 8), K / 256), dim3(256), 0, st, dml, wfc, dflat, B, K);
+    if (bf16io) hipLaunchKernelGGL(fc_bwd_dflat_kernel<__bf16>, dim3(cdiv(B, 8), K / 256), dim3(256), 0, st, dml, wfc, dflat, B, K);
+    else hipLaunchKernelGGL(fc_bwd_dflat_kernel<float>, dim3(cdiv(B, 8), K / 256), dim3(256), 0, st, dml, wfc, dflat, B, K);
     CVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(fc_bwd_dw_kernel, dim3(K / 16), dim3(256), 0, st, flat, dml, dwfc, B, K);
+    if (bf16io) hipLaunchKernelGGL(fc_bwd_dw_kernel<__bf16>, dim3(K / 16), dim3(256), 0, st, flat, dml, dwfc, B, K);
+    else hipLaunchKernelGGL(fc_bwd_dw_kernel<float>, dim3(K / 16), dim3(256), 0, st, flat, dml, dwfc, B, K);
     CVAE_CHECK_LAUNCH();
     return 0;
 }

@@ -57,12 +57,12 @@ def probe_name(pid):
     return f"{KINDS[pid // 9]}_L{pid % 9}"
 
 
-def bn_apply_bytes(layer, B, width=64):
+def bn_apply_bytes(layer, B, width=64, elem_bytes=4.0):
     """Algorithmic HBM bytes of one BatchNorm+pool backward apply launch: read y and the pooled a, da;
-    write dy (fp32): (2 + 2/4) * B*H*H*C * 4."""
+    write dy: (2 + 2/4) * B*H*H*C elements of 4 bytes (fp32 storage) or 2 (precision mode bf16)."""
     c, h = BN_CH_H[layer]
     h = h * width // 64
-    return 2.5 * B * h * h * c * 4.0
+    return 2.5 * B * h * h * c * elem_bytes
 
 
 def measured_traffic(name):
@@ -237,7 +237,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": {"f32": "f32", "bf16": "bf16 MFMA operands (fwd+dgrad+wgrad of E2-E4, D0-D3), f32 elsewhere",
+        "dtype": {"f32": "f32", "bf16": "bf16 (MFMA operands of every conv pass incl. E1/D4; activations and activation gradients stored as bf16; fp32 accumulate, BatchNorm statistics, loss, master weights, gradients, Adam)",
                   "bf16x9": "f32 emulated: 3-way exact bf16 operand splits, 9 bf16 MFMAs per product block (fwd+dgrad of "
                             "E2-E4, D0), f32 MFMA wgrad, f32 elsewhere",
                   "bf16x6": "f32 emulated: 3-way exact bf16 operand splits, the 6 leading partial products (fwd+dgrad of "
@@ -277,7 +277,7 @@ def main():
                                                     for k, v in sorted(survey.items()) if k < 27}}
             if ms_hbm:          # second roofline: the largest HBM-bound kernel of the step
                 sh = sum(ms_hbm) / len(ms_hbm) * 1e-3
-                by = bn_apply_bytes(dominant_hbm - 27, B, Wd)
+                by = bn_apply_bytes(dominant_hbm - 27, B, Wd, 2.0 if args.precision == 'bf16' else 4.0)
                 res["roofline_hbm"] = {
                     "bound": "hbm", "kernel": probe_name(dominant_hbm), "achieved": round(by / sh / 1e9, 1),
                     "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(by / sh / 1e9 / PEAK_HBM_GBPS, 4),

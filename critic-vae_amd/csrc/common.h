@@ -40,6 +40,19 @@ template <> struct Act<__bf16> {
     static __device__ __forceinline__ void st8(float* p, size_t i, bf16x8 v) { *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p) + i) = v; }
 };
 
+// 8 k-values of this lane for one bf16 MFMA operand out of a row-major [k rows][channel columns] LDS image: two
+// transposed 4x16 reads (ds_read_b64_tr_b16; within each group of 16 lanes, lane 4q+p supplies the address of row q,
+// columns 4p..4p+3 of a 4 x 16 block and lane i receives column i of the 4 rows — profiles/experiments/tr16_probe.hip).
+// EXEC must be all ones; addresses 8-byte aligned.
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef short short8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* p0, const __bf16* p1) {
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p0);
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p1);
+    const short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 #define CVAE_LATENT 32
 #define CVAE_ZCAT 33
 

@@ -59,6 +59,9 @@ __device__ __forceinline__ Split3 split3(float x) {
 // MODE_UP_DGRAD: its input gradient: K = 4 phases x COUT channels gathered from dout by phase
 //   (space-to-depth view), taps flipped in the packed weights, ReLU mask of the producer in the epilogue.
 enum { MODE_STD = 0, MODE_UP_FWD = 1, MODE_UP_DGRAD = 2 };
+#ifndef BF16_MT
+#define BF16_MT 2          // 128-pixel tiles per workgroup of the plain bf16 kernels (1 = round-1 structure)
+#endif
 
 __device__ __forceinline__ bf16x8 to_bf16x8(f32x4 lo, f32x4 hi) {
     bf16x8 r;
@@ -67,6 +70,13 @@ __device__ __forceinline__ bf16x8 to_bf16x8(f32x4 lo, f32x4 hi) {
     return r;
 }
 
+// channels per K chunk: 16 for the 3-way-split emulation (3x the LDS per channel), 64 for single-tile bf16 workgroups,
+// 32 when a workgroup holds two tiles
+template <int KCH, int NS, int MT> struct Bf16Chunk {
+    static constexpr int CAP = NS == 3 ? 16 : (MT > 1 ? 32 : 64);
+    static constexpr int KCB = KCH < CAP ? KCH : CAP;
+};
+
 template <int H, int OCT> struct Bf16Geom {
     // halo plane stride in 16-byte units: >= HP and == 16/OCT (mod 16) so that the 16 lanes of one b128
     // write phase (OCT octets x 16/OCT pixels) land in 16 different 16-byte bank groups
@@ -74,33 +84,44 @@ template <int H, int OCT> struct Bf16Geom {
     static constexpr int PSP = ((Tile<H>::HP + 15 - PAD) / 16) * 16 + PAD;
 };
 
-template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT, int KS = 5, int MODE = MODE_STD, int NS = 1, int DMAX = 4>
+// MT = 128-pixel tiles per workgroup (bf16 mode: 2): one weight slab staged into LDS — and one weight fragment read
+// from LDS — serves MT times as many MFMAs; the K chunk shrinks to 32 channels so that the LDS footprint (and with
+// it the number of resident workgroups) stays where it was.
+template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT, int KS = 5, int MODE = MODE_STD, int NS = 1, int DMAX = 4, int MT = 1>
 __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     using T = Tile<H>;
     static_assert(NS == 1 || NS == 3, "operand splits: 1 (bf16) or 3 (fp32 emulation, 9 MFMAs per product block)");
+    static_assert(MT == 1 || NS == 1, "multi-tile workgroups are a bf16-mode feature");
     constexpr int OFF = 2 - KS / 2;                   // a 3x3 window sits one pixel inside the 5x5 halo
     constexpr int COUT_UP = (MODE == MODE_UP_FWD) ? NCH / 4 : KCH / 4;   // conv channels of the upsampled layer
-    constexpr int KCB = NS == 3 ? 16 : (KCH < 64 ? KCH : 64);          // channels per K chunk
+    constexpr int KCB = Bf16Chunk<KCH, NS, MT>::KCB;                    // channels per K chunk
     constexpr int KB = KCB / 16, OCT = KCB / 8, NB = NT / 32;
     constexpr int PSP = Bf16Geom<H, OCT>::PSP;
     constexpr int A_UNITS = OCT * PSP, W_UNITS = KS * KB * 2 * NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);      // [split][octet][halo pixel]
-    bf16x8* lds_w = lds_a + NS * A_UNITS;                      // [split][tap][kb][half][n]
+    bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);      // [tile][split][octet][halo pixel]
+    bf16x8* lds_w = lds_a + MT * NS * A_UNITS;                 // [split][tap][kb][half][n]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int mt = xcd_tile(blockIdx.x, gridDim.x), n0 = blockIdx.y * NT;
-    const int tileInImg = mt % T::TILES_PER_IMG, img0 = (mt / T::TILES_PER_IMG) * T::IMGS;
-    const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;
+    const int mt0 = xcd_tile(blockIdx.x, gridDim.x) * MT, n0 = blockIdx.y * NT;
+    int img0v[MT], ty0v[MT], tx0v[MT];
+#pragma unroll
+    for (int tl = 0; tl < MT; ++tl) {          // a tile index past the end maps to images >= B: loads give 0, stores are skipped
+        const int tileInImg = (mt0 + tl) % T::TILES_PER_IMG;
+        img0v[tl] = ((mt0 + tl) / T::TILES_PER_IMG) * T::IMGS;
+        ty0v[tl] = (tileInImg / T::TILES_X) * T::TH; tx0v[tl] = (tileInImg % T::TILES_X) * T::TW;
+    }
     const int m = wave * 32 + li;
     const int pimg = m / (T::TH * T::TW), prem = m % (T::TH * T::TW);
     const int aPix = pimg * T::HPI + (prem / T::TW) * T::HTW + (prem % T::TW);
 
-    f32x16 acc[NB];
+    f32x16 acc[MT][NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int tl = 0; tl < MT; ++tl)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[nb][v] = 0.f;
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[tl][nb][v] = 0.f;
 
     // weight slab of stage (cc, r): units [s][kb][half][n] <- wp[(r*5+s)][cc*KB + kb][half][n0 + n]
     constexpr int WPT = (W_UNITS + 255) / 256;
@@ -132,14 +153,16 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     // current chunk) -> bf16 units [octet][halo pixel] (split into hi/mid/lo planes when NS == 3)
     constexpr int NQ = T::HP * OCT, IPT = (NQ + 255) / 256;
     f32x4 ireg[NS == 1 ? 1 : 2 * IPT];
-    bf16x8 breg[NS == 1 ? IPT : 1];
+    bf16x8 breg[NS == 1 ? MT * IPT : 1];
     auto load_input = [&](int cc) {
+#pragma unroll
+      for (int tl = 0; tl < MT; ++tl)
 #pragma unroll
         for (int i = 0; i < IPT; ++i) {
             const int q = tid + i * 256;
             const int oct = q % OCT, hp = q / OCT;
             const int img = hp / T::HPI, rem = hp - img * T::HPI;
-            const int gy = ty0 + rem / T::HTW - 2, gx = tx0 + rem % T::HTW - 2, ib = img0 + img;
+            const int gy = ty0v[tl] + rem / T::HTW - 2, gx = tx0v[tl] + rem % T::HTW - 2, ib = img0v[tl] + img;
             const bool ok = (NQ % 256 == 0 || q < NQ) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B;
             size_t e = 0;                           // element index of the unit's first channel
             if (ok) {
@@ -154,7 +177,7 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
                 bf16x8 z;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) z[k] = (__bf16)0.f;
-                breg[i] = ok ? Act<__bf16>::ld8(a.in, e) : z;
+                breg[tl * IPT + i] = ok ? Act<__bf16>::ld8(a.in, e) : z;
             } else {
                 f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
                 if (ok) { lo = *reinterpret_cast<const f32x4*>(a.in + e); hi = *reinterpret_cast<const f32x4*>(a.in + e + 4); }
@@ -164,12 +187,14 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     };
     auto store_input = [&]() {
 #pragma unroll
+      for (int tl = 0; tl < MT; ++tl)
+#pragma unroll
         for (int i = 0; i < IPT; ++i) {
             const int q = tid + i * 256;
             if (!(NQ % 256 == 0 || q < NQ)) continue;
             const int oct = q % OCT, hp = q / OCT;
             if constexpr (NS == 1) {
-                lds_a[oct * PSP + hp] = breg[i];
+                lds_a[tl * A_UNITS + oct * PSP + hp] = breg[tl * IPT + i];
             } else {
                 const f32x4 lo = ireg[2 * i], hi = ireg[2 * i + 1];
                 bf16x8 u0, u1, u2;
@@ -206,10 +231,16 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 if (NS == 1) {
-                    const bf16x8 av = ap[(kb * 2) * PSP + s];
+                    bf16x8 bv[NB];
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bp[((s * KB + kb) * 2) * NT + nb * 32], acc[nb], 0, 0, 0);
+                    for (int nb = 0; nb < NB; ++nb) bv[nb] = bp[((s * KB + kb) * 2) * NT + nb * 32];
+#pragma unroll
+                    for (int tl = 0; tl < MT; ++tl) {
+                        const bf16x8 av = ap[tl * A_UNITS + (kb * 2) * PSP + s];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[tl][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[nb], acc[tl][nb], 0, 0, 0);
+                    }
                 } else {
                     bf16x8 av[3];
 #pragma unroll
@@ -226,13 +257,17 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
 #pragma unroll
                             for (int ia = 0; ia < 3; ++ia) {
                                 const int ib = d - ia;
-                                if (ib >= 0 && ib < 3) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ia], bv[ib], acc[nb], 0, 0, 0);
+                                if (ib >= 0 && ib < 3) acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ia], bv[ib], acc[0][nb], 0, 0, 0);
                             }
                     }
                 }
             }
     }
     float* smem = reinterpret_cast<float*>(smem_raw);
+    const int numTiles = cdiv(a.B, T::IMGS) * T::TILES_PER_IMG;
+#pragma unroll
+    for (int tl = 0; tl < MT; ++tl) {
+    const int mt = mt0 + tl, img0 = img0v[tl], ty0 = ty0v[tl], tx0 = tx0v[tl];
     if (MODE != MODE_STD) {
         // per-wave transpose through LDS, then 16-byte stores (as epilogue_store)
         __syncthreads();
@@ -244,7 +279,7 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
             const float bv = MODE == MODE_UP_FWD ? a.bias[c0 + li] : 0.f;
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                float x = acc[nb][v] + bv;
+                float x = acc[tl][nb][v] + bv;
                 if (MODE == MODE_UP_FWD) x = fmaxf(x, 0.f);
                 patch[((v & 3) + 8 * (v >> 2) + 4 * lh) * 36 + li] = x;
             }
@@ -295,11 +330,12 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
             }
         }
     } else if (KSPLIT > 1) {
-        epilogue_store<H, NT, NCH, EPI_PLAIN>(acc, nullptr, a.out + (size_t)blockIdx.z * a.sliceFloats, nullptr, smem, a.B,
-                                              mt, n0, img0, ty0, tx0);
+        epilogue_store<H, NT, NCH, EPI_PLAIN>(acc[tl], nullptr, a.out + (size_t)blockIdx.z * a.sliceFloats, nullptr, smem, a.B,
+                                              mt, n0, img0, ty0, tx0, numTiles);
     } else {
-        if constexpr (NS == 1) epilogue_store<H, NT, NCH, EPI, __bf16>(acc, a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0);
-        else epilogue_store<H, NT, NCH, EPI>(acc, a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0);
+        if constexpr (NS == 1) epilogue_store<H, NT, NCH, EPI, __bf16>(acc[tl], a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0, numTiles);
+        else epilogue_store<H, NT, NCH, EPI>(acc[tl], a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0, numTiles);
+    }
     }
 }
 
@@ -376,17 +412,17 @@ int launch_pack_up_bf16(const float* const wc[3], float* packed, int ns, hipStre
     return 0;
 }
 
-template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT = 1, int KS = 5, int MODE = MODE_STD, int NS = 1, int DMAX = 4>
+template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT = 1, int KS = 5, int MODE = MODE_STD, int NS = 1, int DMAX = 4, int MT = 1>
 static int run_bf16_ns(const ConvBf16Args& a, hipStream_t st) {
     using T = Tile<H>;
-    constexpr int KCB = NS == 3 ? 16 : (KCH < 64 ? KCH : 64);
-    constexpr int STAGE = NS * ((KCB / 8) * Bf16Geom<H, KCB / 8>::PSP + KS * (KCB / 16) * 2 * NT) * 16;
+    constexpr int KCB = Bf16Chunk<KCH, NS, MT>::KCB;
+    constexpr int STAGE = (MT * NS * (KCB / 8) * Bf16Geom<H, KCB / 8>::PSP + NS * KS * (KCB / 16) * 2 * NT) * 16;
     constexpr int EPI_BYTES = (8 * NT > 4 * 32 * 36 ? 8 * NT : 4 * 32 * 36) * 4;
     constexpr int SMEM = STAGE > EPI_BYTES ? STAGE : EPI_BYTES;
-    auto kern = conv5x5_bf16_kernel<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, NS, DMAX>;
+    auto kern = conv5x5_bf16_kernel<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, NS, DMAX, MT>;
     static DeviceOnce once;
     { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(kern), SMEM); if (rc) return rc; }
-    dim3 grid(cdiv(a.B, T::IMGS) * T::TILES_PER_IMG, NCH / NT, KSPLIT);
+    dim3 grid(cdiv(cdiv(a.B, T::IMGS) * T::TILES_PER_IMG, MT), NCH / NT, KSPLIT);
     cvae_probe_begin(st);
     hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, st, a);
     cvae_probe_end(st);
@@ -394,12 +430,12 @@ static int run_bf16_ns(const ConvBf16Args& a, hipStream_t st) {
     return 0;
 }
 
-// a.splitStride != 0 selects the 3-split fp32-emulation instantiation
+// a.splitStride != 0 selects the 3-split fp32-emulation instantiation; plain bf16 runs two tiles per workgroup
 template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT = 1, int KS = 5, int MODE = MODE_STD>
 static int run_bf16(const ConvBf16Args& a, hipStream_t st) {
     if (a.splitStride && a.products == 6) return run_bf16_ns<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, 3, 2>(a, st);
     if (a.splitStride) return run_bf16_ns<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, 3, 4>(a, st);
-    return run_bf16_ns<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, 1>(a, st);
+    return run_bf16_ns<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, 1, 4, BF16_MT>(a, st);
 }
 
 bool conv_bf16_supported(int layer, int width) { return (width == 64 || width == 128) && layer >= 1 && layer <= 7; }
@@ -501,20 +537,36 @@ int launch_conv_up_dgrad_bf16(int layer, int width, int ns, int B, const float* 
 
 // ---------------------------------------------------------------------------------------------
 // weight gradients on the bf16 MFMA: dW[tap][ci][co] = sum_{img,y,x} in[img][y+r-2][x+s-2][ci] * dy[img][y][x][co]
-// (the wgrad half of loss.backward() for nn.Conv2d E2..E4 / D0).  GEMM M = ci (32), N = co (32),
-// K = pixels.  The MFMA wants 8 consecutive k per lane; a tap shift must not break 16-byte
-// alignment, so k runs over IMAGES: one 16-byte LDS unit = the values of 8 images at one (pixel,
-// channel), lanes 0-31 take pixel p and lanes 32-63 pixel p+1 — one instruction contracts 2 pixels
-// x 8 images.  Workgroup = 8 images x (4 x TW) pixels x 32 ci x 32 co, all 25 taps; wave w owns
-// taps w, w+4, .., w+20 and row w of tap 24 (as conv_wgrad.hip).  Staging transposes on the fly:
-// a thread loads the same 8 channels (one 16-byte unit of the bf16 tensor) of the 8 images and writes the
-// 8 image-major units.  The bias gradient is summed (fp32) from the values while they pass through
-// the registers.  Split-K slabs + fixed-order reduce_slabs as in the fp32 kernel.
+// (the wgrad half of loss.backward() for nn.Conv2d E2..E4 / D0).  GEMM M = ci (32), N = co (32), K = pixels.
+// Both operands want 8 consecutive k (pixels) per lane for a FIXED channel, i.e. a column of the [pixel][channel]
+// tensors as they sit in HBM.  ds_read_b64_tr_b16 does that transposition inside the LDS read (4 pixels x 16
+// channels per 16-lane group; map verified by profiles/experiments/tr16_probe.hip), so staging is a plain
+// 16-byte copy HBM -> registers (one tile ahead, in flight under the MFMAs) -> LDS, with no conversion and no
+// shuffling, and a tap shift is just a different row offset of the same halo image.
+// One MFMA contracts 16 pixels = 4 quads of 4 x-consecutive pixels (lane half h takes quads 2h, 2h+1).
+// Workgroup = 32 ci x 32 co, all 25 taps, over its share of the 256-pixel tiles (split-K slabs, fixed-order
+// reduce_slabs as in the fp32 kernel); 8 waves: wave w owns taps w, w+8, w+16 and every 8th pixel group of tap 24
+// (80 accumulator registers, so two workgroups = 4 waves per SIMD fit without spilling).
+// The bias gradient (column sums of dy) is one more MFMA per 8 pixel groups against an all-ones A operand.
 // ---------------------------------------------------------------------------------------------
-template <int H> struct WgTile {
-    static constexpr int TW = H < 8 ? H : 8, TH = 4;
-    static constexpr int HTW = TW + 4, HTH = TH + 4, HP = HTW * HTH, NPX = TH * TW;
-    static constexpr int TILES_X = H / TW, TILES_Y = H / TH, TILES_PER_GRP = TILES_X * TILES_Y;
+
+template <int H> struct WtTile {
+    static constexpr int TW = H < 32 ? H : 32;
+    static constexpr int TH = H < 256 / TW ? H : 256 / TW;
+    static constexpr int IMGS = H == 4 ? 8 : 256 / (TW * TH);
+    static constexpr int NPX = IMGS * TH * TW, KG = NPX / 16;
+    static constexpr int HTW = TW + 4, HTH = TH + 4, HPI = HTW * HTH, HP = IMGS * HPI;
+    static constexpr int TILES_X = H / TW, TPI = TILES_X * (H / TH);
+    // lane half h (k = 8h..8h+7) and the second read t (k += 4) move by these many dy pixels / halo pixels
+    static constexpr int DH = 8, DT = 4;
+    static constexpr int IH = TW >= 16 ? 8 : (TW == 8 ? HTW : 2 * HTW), IT = TW >= 8 ? 4 : HTW;
+    static constexpr int pixbase(int kg) {
+        return TW >= 16 ? (kg / (TW / 16)) * TW + (kg % (TW / 16)) * 16 : (TW == 8 ? (kg / 4) * 64 + (kg % 4) * 16 : kg * 16);
+    }
+    static constexpr int halobase(int kg) {
+        return TW >= 16 ? (kg / (TW / 16)) * HTW + (kg % (TW / 16)) * 16
+                        : (TW == 8 ? (kg / 4) * HPI + (kg % 4) * 2 * HTW : kg * HPI);
+    }
 };
 
 struct WgradBf16Args {
@@ -524,140 +576,151 @@ struct WgradBf16Args {
     int B, numTiles, tilesPerSplit;
 };
 
-template <int H, int W>
-__device__ __forceinline__ void wgrad_bf16_body(f32x16 (&acc)[7], const bf16x8* lds_in, const bf16x8* lds_d, int li, int lh) {
-    using T = WgTile<H>;
+// WT_NW waves per workgroup (4: two workgroups per CU, 8 accumulator tiles per wave; 8: one workgroup per CU whose
+// 8 waves share every staged tile, 5 accumulator tiles per wave — better for the 32-channel layer E2)
+template <int H, int WT_NW, int W>
+__device__ __forceinline__ void wgrad_tr_body(f32x16 (&acc)[24 / WT_NW + 2], const __bf16* lds_in, const __bf16* lds_d, int ibase, int dbase,
+                                              bf16x8 ones) {
+    using T = WtTile<H>;
+    constexpr int JT = 24 / WT_NW;
+    static_assert(T::KG % WT_NW == 0, "pixel groups per tile must split evenly over the waves");
 #pragma unroll
-    for (int pp = 0; pp < T::NPX / 2; ++pp) {
-        const int py = pp / (T::TW / 2), px = (pp % (T::TW / 2)) * 2;
-        const bf16x8 bv = lds_d[(py * T::TW + px + lh) * 32 + li];
-        const bf16x8* ip = lds_in + (py * T::HTW + px + lh) * 32 + li;
+    for (int kg = 0; kg < T::KG; ++kg) {
+        const __bf16* dp = lds_d + dbase + T::pixbase(kg) * 32;
+        const bf16x8 bv = tr_frag(dp, dp + T::DT * 32);
+        const __bf16* ip = lds_in + ibase + T::halobase(kg) * 32;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int tap = 4 * j + W, r = tap / 5, s = tap % 5;
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ip[(r * T::HTW + s) * 32], bv, acc[j], 0, 0, 0);
+        for (int j = 0; j < JT; ++j) {
+            const int tap = WT_NW * j + W, r = tap / 5, s = tap % 5;
+            const __bf16* q = ip + (r * T::HTW + s) * 32;
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(q, q + T::IT * 32), bv, acc[j], 0, 0, 0);
         }
-        if (py == W) acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ip[(4 * T::HTW + 4) * 32], bv, acc[6], 0, 0, 0);
+        if ((kg % WT_NW) == W) {
+            const __bf16* q = ip + (4 * T::HTW + 4) * 32;
+            acc[JT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(q, q + T::IT * 32), bv, acc[JT], 0, 0, 0);
+        }
+        if ((kg % WT_NW) == ((W + 1) % WT_NW)) acc[JT + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bv, acc[JT + 1], 0, 0, 0);
     }
 }
 
-template <int CIN, int COUT, int H>
-__global__ __launch_bounds__(256, 2) void conv5x5_wgrad_bf16_kernel(WgradBf16Args a) {
-    using T = WgTile<H>;
+template <int CIN, int COUT, int H, int WT_NW>
+__global__ __launch_bounds__(WT_NW * 64, 2) void conv5x5_wgrad_tr_kernel(WgradBf16Args a) {
+    using T = WtTile<H>;
+    constexpr int WT_NT = WT_NW * 64, JT = 24 / WT_NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16x8* lds_in = reinterpret_cast<bf16x8*>(smem_raw);       // [halo pixel][32 ci] units of 8 images
-    bf16x8* lds_d = lds_in + T::HP * 32;                        // [pixel][32 co]
+    __bf16* lds_in = reinterpret_cast<__bf16*>(smem_raw);       // [halo pixel][32 ci], 64-byte rows
+    __bf16* lds_d = lds_in + T::HP * 32;                        // [pixel][32 co]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int split = blockIdx.x, ci0 = blockIdx.y * 32, n0 = blockIdx.z * 32;
-    const int oct = tid & 3;                                    // the 8 channels this thread stages (fixed)
+    // transposed-read address of this lane inside a block: row (pixel) (lane&15)>>2, columns 16*(group&1) + 4*(lane&3)
+    const int g = lane >> 4, h = g >> 1, laneoff = ((lane & 15) >> 2) * 32 + 16 * (g & 1) + 4 * (lane & 3);
+    const int ibase = h * T::IH * 32 + laneoff, dbase = h * T::DH * 32 + laneoff;
 
-    f32x16 acc[7];
+    f32x16 acc[JT + 2];
 #pragma unroll
-    for (int j = 0; j < 7; ++j)
+    for (int j = 0; j < JT + 2; ++j)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
-    float bsum[8];
+    bf16x8 zero8, ones;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) bsum[c] = 0.f;
-    bf16x8 zero8;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) zero8[c] = (__bf16)0.f;
+    for (int c = 0; c < 8; ++c) { zero8[c] = (__bf16)0.f; ones[c] = (__bf16)1.f; }
 
+    constexpr int IU = T::HP * 4, DU = T::NPX * 4, NI = (IU + WT_NT - 1) / WT_NT, ND = (DU + WT_NT - 1) / WT_NT;
+    bf16x8 rin[NI], rdo[ND];
+    auto fetch = [&](int mt) {
+        const int grp = mt / T::TPI, t = mt % T::TPI;
+        const int img0 = grp * T::IMGS, ty0 = (t / T::TILES_X) * T::TH, tx0 = (t % T::TILES_X) * T::TW;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int q = tid + i * WT_NT, hp = q >> 2, oc = q & 3;
+            const int img = hp / T::HPI, rem = hp % T::HPI;
+            const int gy = ty0 + rem / T::HTW - 2, gx = tx0 + rem % T::HTW - 2, ib = img0 + img;
+            const bool ok = (IU % WT_NT == 0 || q < IU) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B;
+            const size_t e = ok ? ((size_t)(ib * H + gy) * H + gx) * CIN + ci0 + oc * 8 : 0;
+            const bf16x8 l = Act<__bf16>::ld8(a.in, e);          // unconditional load from a clamped address + select
+            rin[i] = ok ? l : zero8;
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int q = tid + i * WT_NT, px = q >> 2, oc = q & 3;
+            const int img = px / (T::TH * T::TW), rem = px % (T::TH * T::TW);
+            const int gy = ty0 + rem / T::TW, gx = tx0 + rem % T::TW, ib = img0 + img;
+            const bool ok = (DU % WT_NT == 0 || q < DU) && ib < a.B;
+            const size_t e = ok ? ((size_t)(ib * H + gy) * H + gx) * COUT + n0 + oc * 8 : 0;
+            const bf16x8 l = Act<__bf16>::ld8(a.dout, e);
+            rdo[i] = ok ? l : zero8;
+        }
+    };
     const int t0 = split * a.tilesPerSplit;
     int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
+    if (t0 < t1) fetch(t0);
     for (int mt = t0; mt < t1; ++mt) {
-        const int grp = mt / T::TILES_PER_GRP, t = mt % T::TILES_PER_GRP;
-        const int img0 = grp * 8, ty0 = (t / T::TILES_X) * T::TH, tx0 = (t % T::TILES_X) * T::TW;
-        __syncthreads();
-        for (int q = tid; q < T::HP * 4; q += 256) {
-            const int hp = q >> 2;
-            const int gy = ty0 + hp / T::HTW - 2, gx = tx0 + hp % T::HTW - 2;
-            const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H;
-            bf16x8 v[8];
+        __syncthreads();                        // every wave is done reading the previous tile
 #pragma unroll
-            for (int im = 0; im < 8; ++im) {
-                const bool ok = inb && img0 + im < a.B;
-                const size_t e = ok ? ((size_t)((img0 + im) * H + gy) * H + gx) * CIN + ci0 + oct * 8 : 0;
-                const bf16x8 l = Act<__bf16>::ld8(a.in, e);
-                v[im] = ok ? l : zero8;
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                bf16x8 u;
-#pragma unroll
-                for (int im = 0; im < 8; ++im) u[im] = v[im][c];
-                lds_in[hp * 32 + oct * 8 + c] = u;
-            }
+        for (int i = 0; i < NI; ++i) {
+            const int q = tid + i * WT_NT;
+            if (IU % WT_NT == 0 || q < IU) *reinterpret_cast<bf16x8*>(lds_in + (size_t)q * 8) = rin[i];
         }
-        for (int q = tid; q < T::NPX * 4; q += 256) {
-            const int px = q >> 2;
-            const int gy = ty0 + px / T::TW, gx = tx0 + px % T::TW;
-            bf16x8 v[8];
 #pragma unroll
-            for (int im = 0; im < 8; ++im) {
-                const bool ok = img0 + im < a.B;
-                const size_t e = ok ? ((size_t)((img0 + im) * H + gy) * H + gx) * COUT + n0 + oct * 8 : 0;
-                const bf16x8 l = Act<__bf16>::ld8(a.dout, e);
-                v[im] = ok ? l : zero8;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) bsum[c] += (float)v[im][c];
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                bf16x8 u;
-#pragma unroll
-                for (int im = 0; im < 8; ++im) u[im] = v[im][c];
-                lds_d[px * 32 + oct * 8 + c] = u;
-            }
+        for (int i = 0; i < ND; ++i) {
+            const int q = tid + i * WT_NT;
+            if (DU % WT_NT == 0 || q < DU) *reinterpret_cast<bf16x8*>(lds_d + (size_t)q * 8) = rdo[i];
         }
         __syncthreads();
+        if (mt + 1 < t1) fetch(mt + 1);         // in flight while this tile computes
         switch (wave) {
-            case 0: wgrad_bf16_body<H, 0>(acc, lds_in, lds_d, li, lh); break;
-            case 1: wgrad_bf16_body<H, 1>(acc, lds_in, lds_d, li, lh); break;
-            case 2: wgrad_bf16_body<H, 2>(acc, lds_in, lds_d, li, lh); break;
-            default: wgrad_bf16_body<H, 3>(acc, lds_in, lds_d, li, lh); break;
+            case 0: wgrad_tr_body<H, WT_NW, 0>(acc, lds_in, lds_d, ibase, dbase, ones); break;
+            case 1: wgrad_tr_body<H, WT_NW, 1>(acc, lds_in, lds_d, ibase, dbase, ones); break;
+            case 2: wgrad_tr_body<H, WT_NW, 2>(acc, lds_in, lds_d, ibase, dbase, ones); break;
+            case 3: wgrad_tr_body<H, WT_NW, 3>(acc, lds_in, lds_d, ibase, dbase, ones); break;
+            case 4: if constexpr (WT_NW == 8) wgrad_tr_body<H, WT_NW, 4>(acc, lds_in, lds_d, ibase, dbase, ones); break;
+            case 5: if constexpr (WT_NW == 8) wgrad_tr_body<H, WT_NW, 5>(acc, lds_in, lds_d, ibase, dbase, ones); break;
+            case 6: if constexpr (WT_NW == 8) wgrad_tr_body<H, WT_NW, 6>(acc, lds_in, lds_d, ibase, dbase, ones); break;
+            default: if constexpr (WT_NW == 8) wgrad_tr_body<H, WT_NW, 7>(acc, lds_in, lds_d, ibase, dbase, ones); break;
         }
     }
 
     float* out = a.slab + (size_t)split * (25 * CIN * COUT + COUT);     // slab row: [25][CIN][COUT] | bias[COUT]
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
+    for (int j = 0; j < JT; ++j)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int ci = ci0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-            out[((size_t)(4 * j + wave) * CIN + ci) * COUT + n0 + li] = acc[j][v];
+            out[((size_t)(WT_NW * j + wave) * CIN + ci) * COUT + n0 + li] = acc[j][v];
         }
-    // tap 24: each wave holds the partial of its pixel rows; bias: 32 threads per channel quad
-    float* red = reinterpret_cast<float*>(smem_raw);
+    // tap 24 and the bias row: every wave holds the partial of its pixel groups -> fixed-order sum through LDS
+    float* red = reinterpret_cast<float*>(smem_raw);                    // [NW-1 waves][16][64]
+    float* bred = red + (WT_NW - 1) * 16 * 64;                          // [NW waves][32]
     __syncthreads();
     if (wave > 0) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) red[((wave - 1) * 16 + v) * 64 + lane] = acc[6][v];
+        for (int v = 0; v < 16; ++v) red[((wave - 1) * 16 + v) * 64 + lane] = acc[JT][v];
     }
-    f32x4* bred = reinterpret_cast<f32x4*>(red + 3 * 16 * 64);      // [256 threads][2 halves of the thread's 8 channels]
-    bred[tid * 2] = f32x4{bsum[0], bsum[1], bsum[2], bsum[3]};
-    bred[tid * 2 + 1] = f32x4{bsum[4], bsum[5], bsum[6], bsum[7]};
+    if (lh == 0) bred[wave * 32 + li] = acc[JT + 1][0];                       // row 0 of (ones x dy) = column sums of dy
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            const float x = ((acc[6][v] + red[v * 64 + lane]) + red[(16 + v) * 64 + lane]) + red[(32 + v) * 64 + lane];
+            float x = acc[JT][v];
+#pragma unroll
+            for (int w2 = 0; w2 < WT_NW - 1; ++w2) x += red[(w2 * 16 + v) * 64 + lane];
             const int ci = ci0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
             out[((size_t)24 * CIN + ci) * COUT + n0 + li] = x;
         }
-    }
-    if (blockIdx.y == 0 && tid < 8) {          // channel quad tid = half (tid & 1) of octet (tid >> 1): 64 threads staged it
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < 64; ++k) s += bred[(k * 4 + (tid >> 1)) * 2 + (tid & 1)];
-        *reinterpret_cast<f32x4*>(out + (size_t)25 * CIN * COUT + n0 + tid * 4) = s;
+        if (blockIdx.y == 0 && lh == 0) {
+            float b = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < WT_NW; ++w2) b += bred[w2 * 32 + li];
+            out[(size_t)25 * CIN * COUT + n0 + li] = b;
+        }
     }
 }
 
 template <int H>
 static int wgrad_bf16_splits(int B, int blocksPerSplit, int* tilesPerSplit, int* numTilesOut) {
-    using T = WgTile<H>;
-    const int numTiles = cdiv(B, 8) * T::TILES_PER_GRP;
-    int S = cdiv(512, blocksPerSplit);                // ~2 workgroups per CU (256 and 1024 measured slower)
+    using T = WtTile<H>;
+    const int numTiles = cdiv(B, T::IMGS) * T::TPI;
+    int S = cdiv(512, blocksPerSplit);                // ~2 workgroups per CU
     if (S > numTiles) S = numTiles;
     if (S < 1) S = 1;
     const int tps = cdiv(numTiles, S);
@@ -669,19 +732,20 @@ static int wgrad_bf16_splits(int B, int blocksPerSplit, int* tilesPerSplit, int*
 template <int CIN, int COUT, int H>
 static int run_wgrad_bf16(int B, const float* in, const float* dout, float* dw, float* dbias, float* ws, hipStream_t st,
                           int64_t* need) {
-    using T = WgTile<H>;
+    using T = WtTile<H>;
     int tps, numTiles;
     const int S = wgrad_bf16_splits<H>(B, (CIN / 32) * (COUT / 32), &tps, &numTiles);
     const int64_t n = (int64_t)25 * CIN * COUT, row = n + COUT;
     if (need) { *need = (int64_t)(S + 16) * row; return 0; }
     WgradBf16Args a{in, dout, ws, B, numTiles, tps};
-    constexpr int STAGE = (T::HP + T::NPX) * 32 * 16, RED = (3 * 16 * 64) * 4 + 256 * 32;
+    constexpr int WT_NW = CIN == 32 ? 8 : 4, WT_NT = WT_NW * 64;
+    constexpr int STAGE = (T::HP + T::NPX) * 64, RED = ((WT_NW - 1) * 16 * 64 + WT_NW * 32) * 4;
     constexpr int SMEM = STAGE > RED ? STAGE : RED;
-    auto kern = conv5x5_wgrad_bf16_kernel<CIN, COUT, H>;
+    auto kern = conv5x5_wgrad_tr_kernel<CIN, COUT, H, WT_NW>;
     static DeviceOnce once;
     { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(kern), SMEM); if (rc) return rc; }
     cvae_probe_begin(st);
-    hipLaunchKernelGGL(kern, dim3(S, CIN / 32, COUT / 32), dim3(256), SMEM, st, a);
+    hipLaunchKernelGGL(kern, dim3(S, CIN / 32, COUT / 32), dim3(WT_NT), SMEM, st, a);
     cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();
     float* mid = ws + (size_t)S * row;

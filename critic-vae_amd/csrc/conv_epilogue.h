@@ -13,7 +13,7 @@ enum { EPI_BIAS_BNSTAT = 0, EPI_BIAS_RELU = 1, EPI_PLAIN = 2, EPI_POOLSUM_MASK =
 template <int H, int NT, int NCH, int EPI, typename AT = float>      // AT: storage type of `out` (bf16 in precision mode 1)
 __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[NT / 32], const float* bias, float* out,
                                                float* bnpart, float* smem, int B, int mt, int n0,
-                                               int img0, int ty0, int tx0) {
+                                               int img0, int ty0, int tx0, int numTiles = -1) {
     using T = Tile<H>;
     constexpr int NB = NT / 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -99,11 +99,11 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[NT / 32], const flo
             if (lh == 0) red[4 * NT + wave * NT + nb * 32 + li] = t;
         }
         __syncthreads();
-        if (tid < NT) {
+        const size_t nt = numTiles < 0 ? gridDim.x : numTiles;     // multi-tile workgroups pass the true tile count
+        if (tid < NT && (size_t)mt < nt) {
             const int c = tid;
             const float sum = red[c] + red[NT + c] + red[2 * NT + c] + red[3 * NT + c];
             const float m2 = red[4 * NT + c] + red[5 * NT + c] + red[6 * NT + c] + red[7 * NT + c];
-            const size_t nt = gridDim.x;
             bnpart[(size_t)mt * NCH + n0 + c] = sum;
             bnpart[(nt + mt) * NCH + n0 + c] = m2;
         }

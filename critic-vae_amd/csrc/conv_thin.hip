@@ -143,6 +143,113 @@ __global__ __launch_bounds__(256) void e1_fwd_kernel(const float* __restrict__ x
     (void)B;
 }
 
+// precision mode 1, E1 forward.  The frame strip is staged ONCE as bf16 pixels of 4 channels (r, g, b, 0) — 8 bytes per
+// pixel, rows of 40 pixels — so the 5 taps x 4 channels of one kernel row are 20 CONSECUTIVE bf16 values: an A
+// fragment (8 consecutive k of one pixel) is two 8-byte LDS reads instead of 8 scalar reads + 8 conversions.
+// K per kernel row = 20 padded to 32 (zero weights): 10 MFMAs per 32 pixels, 40 weight registers per lane.
+// y1 leaves as bf16 (16-byte units), the BatchNorm partials come from the fp32 accumulators.
+template <int H>
+__global__ __launch_bounds__(256) void e1_fwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          float* __restrict__ bnpart, int B) {
+    constexpr int SR = 16, SW = 32, HR_ = SR + 4, HWX = 40;
+    constexpr int SX = H / SW, SY = H / SR;
+    __shared__ __attribute__((aligned(16))) bf16x4 lds_x[HR_ * HWX];
+    __shared__ __attribute__((aligned(16))) float patch_all[4 * 32 * 36];
+    __shared__ float red[2][4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int ib = blockIdx.x / (SX * SY), t = blockIdx.x % (SX * SY);
+    const int ty0 = (t / SX) * SR, tx0 = (t % SX) * SW;
+    bf16x8 bw[5][2];                    // B[k = 16kb + 8lh + j][n = li] of kernel row r: k = 4*s + c
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * kb + 8 * lh + j, sI = k >> 2, c = k & 3;
+                bw[r][kb][j] = (__bf16)((sI < 5 && c < 3) ? w[((r * 5 + sI) * 3 + c) * 32 + li] : 0.f);
+            }
+    {
+        constexpr int NIT = (HR_ * HWX + 255) / 256;
+        float v0[NIT], v1[NIT], v2[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {          // all loads first (clamped address + select), then the LDS writes
+            const int q = tid + i * 256, hy = q / HWX, hx = q % HWX;
+            const int gy = ty0 + hy - 2, gx = tx0 + hx - 2;
+            const bool ok = q < HR_ * HWX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H;
+            const size_t e = ok ? ((size_t)(ib * 3) * H + gy) * H + gx : 0;
+            const float a0 = x[e], a1 = x[e + (size_t)H * H], a2 = x[e + 2 * (size_t)H * H];
+            v0[i] = ok ? a0 : 0.f; v1[i] = ok ? a1 : 0.f; v2[i] = ok ? a2 : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int q = tid + i * 256;
+            if (q < HR_ * HWX) { bf16x4 u; u[0] = (__bf16)v0[i]; u[1] = (__bf16)v1[i]; u[2] = (__bf16)v2[i]; u[3] = (__bf16)0.f; lds_x[q] = u; }
+        }
+    }
+    __syncthreads();
+    f32x16 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[r][v] = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const bf16x4* p = lds_x + (wave * 4 + rr + r) * HWX + li + 4 * kb + 2 * lh;
+                const bf16x4 lo = p[0], hi = p[1];
+                const bf16x8 av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw[r][kb], acc[rr], 0, 0, 0);
+            }
+    // epilogue: element v of lane (li, lh) in tile r = pixel column (v&3)+8*(v>>2)+4*lh of row 4*wave+r, channel li
+    const float bv = bias[li];
+    float s = 0.f;
+    float* patch = patch_all + wave * (32 * 36);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float val = acc[r][v] + bv;
+            acc[r][v] = val;
+            s += val;
+            patch[((v & 3) + 8 * (v >> 2) + 4 * lh) * 36 + li] = val;
+        }
+        const int gy = ty0 + wave * 4 + r;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = it * 64 + lane, px = idx >> 2, c8 = idx & 3;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(patch + px * 36 + c8 * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(patch + px * 36 + c8 * 8 + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = (__bf16)lo[e]; o[4 + e] = (__bf16)hi[e]; }
+            Act<__bf16>::st8(y, ((size_t)(ib * H + gy) * H + tx0 + px) * 32 + c8 * 8, o);
+        }
+    }
+    s += __shfl_xor(s, 32, 64);
+    if (lh == 0) red[0][wave][li] = s;
+    __syncthreads();
+    const float mean = ((red[0][0][li] + red[0][1][li]) + (red[0][2][li] + red[0][3][li])) * (1.0f / (SR * SW));
+    float m2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { const float d = acc[r][v] - mean; m2 += d * d; }
+    m2 += __shfl_xor(m2, 32, 64);
+    if (lh == 0) red[1][wave][li] = m2;
+    __syncthreads();
+    if (tid < 32) {
+        const size_t nt = gridDim.x;
+        bnpart[(size_t)blockIdx.x * 32 + tid] = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
+        bnpart[(nt + blockIdx.x) * 32 + tid] = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+    }
+    (void)B;
+}
+
 struct ThinWgradArgs {
     const float* a0;     // E1: x (NCHW)          D4: dOut planes (NCHW)
     const float* a1;     // E1: dy (NHWC, 32)     D4: o3 (NHWC, 32)
@@ -346,8 +453,8 @@ int64_t e1_wgrad_ws_floats(int width, int B) {
 
 int launch_e1_fwd(int width, int B, const float* x, const float* w, const float* bias, float* y,
                   float* bnpart, hipStream_t st, bool bf16) {
-    if (width == 64 && bf16) hipLaunchKernelGGL((e1_fwd_kernel<64, true>), dim3(B * 8), dim3(256), 0, st, x, w, bias, y, bnpart, B);
-    else if (width == 128 && bf16) hipLaunchKernelGGL((e1_fwd_kernel<128, true>), dim3(B * 32), dim3(256), 0, st, x, w, bias, y, bnpart, B);
+    if (width == 64 && bf16) hipLaunchKernelGGL(e1_fwd_bf16_kernel<64>, dim3(B * 8), dim3(256), 0, st, x, w, bias, y, bnpart, B);
+    else if (width == 128 && bf16) hipLaunchKernelGGL(e1_fwd_bf16_kernel<128>, dim3(B * 32), dim3(256), 0, st, x, w, bias, y, bnpart, B);
     else if (width == 64) hipLaunchKernelGGL((e1_fwd_kernel<64, false>), dim3(B * 8), dim3(256), 0, st, x, w, bias, y, bnpart, B);
     else if (width == 128) hipLaunchKernelGGL((e1_fwd_kernel<128, false>), dim3(B * 32), dim3(256), 0, st, x, w, bias, y, bnpart, B);
     else { cvae_set_error("e1_fwd: width %d unsupported", width); return -2; }
@@ -455,6 +562,92 @@ __global__ __launch_bounds__(256) void d4_fwd_kernel(const float* __restrict__ i
             for (int s = 0; s < 5; ++s) {
                 const int sc = ((tx0 + ox + s - 2) >> 1) - sx0;
                 const float* qv = lds_q + (sr * 10 + sc) * 97 + (r * 5 + s) * 3;
+                s0 += qv[0]; s1 += qv[1]; s2 += qv[2];
+            }
+        }
+        const size_t o = ((size_t)(ib * 3) * H + ty0 + oy) * H + tx0 + ox;
+        recon[o] = fast_tanh(s0);
+        recon[o + (size_t)H * H] = fast_tanh(s1);
+        recon[o + 2 * (size_t)H * H] = fast_tanh(s2);
+    }
+}
+
+// precision mode 1: the same forward with o3 read as bf16 and Q = o3 . W on v_mfma_f32_32x32x16_bf16 (K = 32 channels
+// = 2 k-steps x 3 column blocks: 6 MFMAs per 32 source pixels instead of 48 fp32 ones).  The source tile sits in LDS
+// as bf16 rows of 80 bytes (conflict-free 16-byte fragment reads); gather-sum, Tanh and the NCHW fp32 store are unchanged.
+template <int H>
+__global__ __launch_bounds__(256) void d4_fwd_bf16_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ recon, int B) {
+    constexpr int HS = H / 2, TX = H / 16, TPI = TX * TX, AS = 40;      // AS: row stride of the source tile in elements
+    __shared__ __attribute__((aligned(16))) __bf16 lds_a[128 * AS];
+    __shared__ float lds_q[128 * 97];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    bf16x8 bw[2][3];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = nb * 32 + li, ci = 16 * ks + 8 * lh + j;
+                bw[ks][nb][j] = (__bf16)(n < 75 ? w[((n / 3) * 32 + ci) * 3 + n % 3] : 0.f);
+            }
+    const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
+    const int numTiles = B * TPI;
+    bf16x8 zero8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) zero8[c] = (__bf16)0.f;
+    for (int q = tid; q < 28 * 4; q += 256) *reinterpret_cast<bf16x8*>(lds_a + (100 + (q >> 2)) * AS + (q & 3) * 8) = zero8;   // rows 100..127 stay 0
+    bf16x8 ra[2];
+    auto fetch = [&](int tile) {
+        const int ib = tile / TPI, t = tile % TPI;
+        const int sy0 = (t / TX) * 8 - 1, sx0 = (t % TX) * 8 - 1;           // 10x10 source window
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + i * 256, c8 = q & 3, sp = q >> 2;
+            const int sy = sy0 + sp / 10, sx = sx0 + sp % 10;
+            const bool ok = sp < 100 && (unsigned)sy < (unsigned)HS && (unsigned)sx < (unsigned)HS;
+            const bf16x8 l = Act<__bf16>::ld8(in, ok ? ((size_t)(ib * HS + sy) * HS + sx) * 32 + c8 * 8 : 0);
+            ra[i] = ok ? l : zero8;
+        }
+    };
+    if ((int)blockIdx.x < numTiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+        const int ib = tile / TPI, t = tile % TPI;
+        const int ty0 = (t / TX) * 16, tx0 = (t % TX) * 16, sy0 = ty0 / 2 - 1, sx0 = tx0 / 2 - 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + i * 256;
+            if (q < 400) *reinterpret_cast<bf16x8*>(lds_a + (q >> 2) * AS + (q & 3) * 8) = ra[i];
+        }
+        __syncthreads();       // also: every thread is past the previous tile's gather, lds_q is free
+        if (tile + (int)gridDim.x < numTiles) fetch(tile + gridDim.x);
+        f32x16 acc[3];
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[nb][v] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 av = *reinterpret_cast<const bf16x8*>(lds_a + (wave * 32 + li) * AS + (2 * ks + lh) * 8);
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw[ks][nb], acc[nb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                lds_q[(wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh) * 97 + nb * 32 + li] = acc[nb][v];
+        __syncthreads();
+        const int oy = tid >> 4, ox = tid & 15;
+        float s0 = b0, s1 = b1, s2 = b2;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const int sr = ((ty0 + oy + r - 2) >> 1) - sy0;
+#pragma unroll
+            for (int s5 = 0; s5 < 5; ++s5) {
+                const int sc = ((tx0 + ox + s5 - 2) >> 1) - sx0;
+                const float* qv = lds_q + (sr * 10 + sc) * 97 + (r * 5 + s5) * 3;
                 s0 += qv[0]; s1 += qv[1]; s2 += qv[2];
             }
         }
@@ -603,6 +796,128 @@ __global__ __launch_bounds__(256) void d4_bwd_kernel(ThinWgradArgs a) {
     thin_slab_out(accw, smem, a.slab + (size_t)blockIdx.x * 96 * 32);
 }
 
+// precision mode 1: the fused D4 backward on the bf16 MFMA.  G is built in LDS as bf16 rows of 88 elements; the input
+// gradient is 5 MFMAs (K = 75 padded to 80, weights in registers), the weight gradient contracts each wave's 32 source
+// pixels in 2 k-steps x 3 row blocks with both operands read TRANSPOSED out of the row-major G / o3 tiles
+// (ds_read_b64_tr_b16): 11 MFMAs per 32 source pixels and wave instead of 86 fp32 ones.  o3 / d_o3 are bf16 in HBM.
+template <int H>
+__global__ __launch_bounds__(256) void d4_bwd_bf16_kernel(ThinWgradArgs a) {
+    constexpr int HS = H / 2, TPI = (HS / 8) * (HS / 16);
+    constexpr int G0 = 3 * 720, GS = 88;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* lds_g0 = smem;                                              // dOut halo planes [3][20][36] fp32
+    __bf16* lds_o = reinterpret_cast<__bf16*>(smem + G0);              // o3 tile [128][32]
+    __bf16* lds_G = lds_o + 128 * 32;                                  // [128][88] (+16 pad)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    bf16x8 bwd[5];                                                     // W4r[k = tap*3+co][ci = li], k = 16kb + 8lh + j
+#pragma unroll
+    for (int kb = 0; kb < 5; ++kb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * kb + 8 * lh + j;
+            bwd[kb][j] = (__bf16)(k < 75 ? a.w[((k / 3) * 32 + li) * 3 + k % 3] : 0.f);
+        }
+    for (int q = tid; q < 128 * 13; q += 256) lds_G[(q / 13) * GS + 75 + q % 13] = (__bf16)0.f;     // K pad columns stay zero
+    if (tid < 16) lds_G[128 * GS + tid] = (__bf16)0.f;
+    f32x16 accw[3];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) accw[mb][v] = 0.f;
+    const int t0 = blockIdx.x * a.tilesPerSplit;
+    int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
+    constexpr int GQ = (G0 + 255) / 256;
+    float rg[GQ];
+    bf16x8 ro[2];
+    auto fetch = [&](int mt) {
+        const int ib = mt / TPI, t = mt % TPI;
+        const int sy0 = (t / (HS / 16)) * 8, sx0 = (t % (HS / 16)) * 16;
+#pragma unroll
+        for (int i = 0; i < GQ; ++i) {
+            const int q = tid + i * 256, c = q / 720, rem = q % 720;
+            const int uy = 2 * sy0 - 2 + rem / 36, ux = 2 * sx0 - 2 + rem % 36;
+            float v = 0.f;
+            if (q < G0 && (unsigned)uy < (unsigned)H && (unsigned)ux < (unsigned)H)
+                v = a.a0[((size_t)(ib * 3 + c) * H + uy) * H + ux];
+            rg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + i * 256, c8 = q & 3, sp = q >> 2;
+            ro[i] = Act<__bf16>::ld8(a.a1, ((size_t)(ib * HS + sy0 + sp / 16) * HS + sx0 + sp % 16) * 32 + c8 * 8);
+        }
+    };
+    if (t0 < t1) fetch(t0);
+    const int gsp = tid & 127, ghalf = tid >> 7, gsy = gsp >> 4, gsx = gsp & 15;
+    // transposed-read lane address inside a 4-row block (rows = source pixels)
+    const int g = lane >> 4, h = g >> 1, qrow = (lane & 15) >> 2, cb = 16 * (g & 1) + 4 * (lane & 3);
+    for (int mt = t0; mt < t1; ++mt) {
+        const int ib = mt / TPI, t = mt % TPI;
+        const int sy0 = (t / (HS / 16)) * 8, sx0 = (t % (HS / 16)) * 16;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < GQ; ++i) {
+            const int q = tid + i * 256;
+            if (q < G0) lds_g0[q] = rg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + i * 256;
+            *reinterpret_cast<bf16x8*>(lds_o + (size_t)q * 8) = ro[i];
+        }
+        __syncthreads();
+        if (mt + 1 < t1) fetch(mt + 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pr = ghalf * 8 + i;                     // wave-uniform
+            if (pr < 15) {
+                const int co = pr / 5, r = pr % 5;
+                const float* p = lds_g0 + co * 720 + (2 * gsy - r + 4) * 36 + 2 * gsx;
+                float cs[6];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float2 u = *reinterpret_cast<const float2*>(p + 2 * j);
+                    const float2 d = *reinterpret_cast<const float2*>(p + 36 + 2 * j);
+                    cs[2 * j] = u.x + d.x; cs[2 * j + 1] = u.y + d.y;
+                }
+                __bf16* gp = lds_G + gsp * GS + r * 15 + co;
+#pragma unroll
+                for (int sI = 0; sI < 5; ++sI) gp[sI * 3] = (__bf16)(cs[4 - sI] + cs[5 - sI]);
+            }
+        }
+        __syncthreads();
+        // dgrad: d_o3[src][ci] = relu'(o3) * sum_k G[src][k] * W4r[k][ci]
+        f32x16 accd;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) accd[v] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 5; ++kb) {
+            const bf16x8 av = *reinterpret_cast<const bf16x8*>(lds_G + (wave * 32 + li) * GS + 16 * kb + 8 * lh);
+            accd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bwd[kb], accd, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int sp = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            const float x = (float)lds_o[sp * 32 + li] > 0.f ? accd[v] : 0.f;
+            Act<__bf16>::st(a.din, ((size_t)(ib * HS + sy0 + sp / 16) * HS + sx0 + sp % 16) * 32 + li, x);
+        }
+        // wgrad: dW[k][ci] += sum over this wave's 32 source pixels of G[src][k] * o3[src][ci]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int row = wave * 32 + 16 * ks + 8 * h + qrow;
+            const bf16x8 bv = tr_frag(lds_o + row * 32 + cb, lds_o + (row + 4) * 32 + cb);
+#pragma unroll
+            for (int mb = 0; mb < 3; ++mb) {
+                const bf16x8 av = tr_frag(lds_G + row * GS + mb * 32 + cb, lds_G + (row + 4) * GS + mb * 32 + cb);
+                accw[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, accw[mb], 0, 0, 0);
+            }
+        }
+    }
+    thin_slab_out(accw, smem, a.slab + (size_t)blockIdx.x * 96 * 32);
+}
+static constexpr int D4_BWD_BF16_SMEM = 3 * 720 * 4 + 128 * 32 * 2 + (128 * 88 + 16) * 2;
+static_assert(D4_BWD_BF16_SMEM >= 3 * 3 * 1024 * 4, "thin_slab_out reuses the staging buffers");
+
 static constexpr int D4_BWD_SMEM = (3 * 720 + 128 * 32 + 128 * 77 + 32 + 76 * 32) * 4;
 
 static int d4_splits(int width, int B, int* tps) {
@@ -617,8 +932,8 @@ int64_t d4_bwd_ws_floats(int width, int B) {
 int launch_d4_fwd(int width, int B, const float* in, const float* w, const float* bias, float* recon, hipStream_t st, bool bf16io) {
     // 66 KB of LDS -> two workgroups per CU, each looping over its share of the 16x16 tiles
     const int tiles = B * (width / 16) * (width / 16), grid = tiles < 512 ? tiles : 512;
-    if (width == 64 && bf16io) hipLaunchKernelGGL((d4_fwd_kernel<64, __bf16>), dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
-    else if (width == 128 && bf16io) hipLaunchKernelGGL((d4_fwd_kernel<128, __bf16>), dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
+    if (width == 64 && bf16io) hipLaunchKernelGGL(d4_fwd_bf16_kernel<64>, dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
+    else if (width == 128 && bf16io) hipLaunchKernelGGL(d4_fwd_bf16_kernel<128>, dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
     else if (width == 64) hipLaunchKernelGGL((d4_fwd_kernel<64, float>), dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
     else if (width == 128) hipLaunchKernelGGL((d4_fwd_kernel<128, float>), dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
     else { cvae_set_error("d4_fwd: width %d unsupported", width); return -2; }
@@ -638,10 +953,11 @@ int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const
     CVAE_CHECK_LAUNCH();
     ThinWgradArgs a{dout, o3, w, d_o3, ws, B, tiles, tps};
     static DeviceOnce once[4];
-    void (*kern)(ThinWgradArgs) = width == 64 ? (bf16io ? d4_bwd_kernel<64, __bf16> : d4_bwd_kernel<64, float>)
-                                              : (bf16io ? d4_bwd_kernel<128, __bf16> : d4_bwd_kernel<128, float>);
-    { int rc = cvae_grant_lds(once[(width == 128) * 2 + bf16io], reinterpret_cast<const void*>(kern), D4_BWD_SMEM); if (rc) return rc; }
-    hipLaunchKernelGGL(kern, dim3(S), dim3(256), D4_BWD_SMEM, st, a);
+    void (*kern)(ThinWgradArgs) = width == 64 ? (bf16io ? d4_bwd_bf16_kernel<64> : d4_bwd_kernel<64, float>)
+                                              : (bf16io ? d4_bwd_bf16_kernel<128> : d4_bwd_kernel<128, float>);
+    const int smem_bytes = bf16io ? D4_BWD_BF16_SMEM : D4_BWD_SMEM;
+    { int rc = cvae_grant_lds(once[(width == 128) * 2 + bf16io], reinterpret_cast<const void*>(kern), smem_bytes); if (rc) return rc; }
+    hipLaunchKernelGGL(kern, dim3(S), dim3(256), smem_bytes, st, a);
     CVAE_CHECK_LAUNCH();
     float* red = plane_sums + align_up((int64_t)B * 3, 64);
     { int rc = launch_col_reduce(ws, S, 3072, 3072, red, red + 3072, st); if (rc) return rc; }

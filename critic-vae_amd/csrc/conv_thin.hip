@@ -53,12 +53,22 @@ __global__ __launch_bounds__(256) void e1_fwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int j = 0; j < 38; ++j) bw[j] = (2 * j + lh < 75) ? w[(2 * j + lh) * 32 + li] : 0.f;
     }
-    for (int q = tid; q < 3 * HW_ * HR_; q += 256) {
-        const int c = q / (HW_ * HR_), hp = q % (HW_ * HR_);
-        const int gy = ty0 + hp / HW_ - 2, gx = tx0 + hp % HW_ - 2;
-        float v = 0.f;
-        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H) v = x[((size_t)(ib * 3 + c) * H + gy) * H + gx];
-        lds_x[c * PS + hp] = v;
+    {       // all halo loads are issued before the first LDS write (clamped address + select: no branch per element)
+        constexpr int NQ = 3 * HW_ * HR_, NIT = (NQ + 255) / 256;
+        float xv[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int q = tid + i * 256, c = q / (HW_ * HR_), hp = q % (HW_ * HR_);
+            const int gy = ty0 + hp / HW_ - 2, gx = tx0 + hp % HW_ - 2;
+            const bool ok = q < NQ && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H;
+            const float l = x[ok ? ((size_t)(ib * 3 + c) * H + gy) * H + gx : 0];
+            xv[i] = ok ? l : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int q = tid + i * 256;
+            if (q < NQ) lds_x[(q / (HW_ * HR_)) * PS + q % (HW_ * HR_)] = xv[i];
+        }
     }
     __syncthreads();
     f32x16 acc[4];
@@ -305,10 +315,9 @@ __device__ __forceinline__ void e1_wgrad_fetch(const ThinWgradArgs& a, int mt, f
         const int q = tid + i * 256;
         const int c = q / T::HPI, hp = q % T::HPI;
         const int gy = ty0 + hp / T::HTW - 2, gx = tx0 + hp % T::HTW - 2;
-        float v = 0.f;
-        if (q < 3 * T::HPI && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H)
-            v = a.a0[((size_t)(ib * 3 + c) * H + gy) * H + gx];
-        rx[i] = v;
+        const bool ok = q < 3 * T::HPI && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H;
+        const float l = a.a0[ok ? ((size_t)(ib * 3 + c) * H + gy) * H + gx : 0];      // no branch around the load
+        rx[i] = ok ? l : 0.f;
     }
     if (BF16) {          // dy is bf16 (precision mode 1): two 16-byte units per thread, widened to the same 4 x f32x4
 #pragma unroll
@@ -516,11 +525,9 @@ __global__ __launch_bounds__(256) void d4_fwd_kernel(const float* __restrict__ i
         for (int i = 0; i < 4; ++i) {
             const int q = tid + i * 256, c4 = q & 7, sp = q >> 3;
             const int sy = sy0 + sp / 10, sx = sx0 + sp % 10;
-            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (sp < 100 && (unsigned)sy < (unsigned)HS && (unsigned)sx < (unsigned)HS) {
-                const f32x4 v = Act<AT>::ld4(in, ((size_t)(ib * HS + sy) * HS + sx) * 32 + c4 * 4);
-                ra[i] = make_float4(v[0], v[1], v[2], v[3]);
-            }
+            const bool ok = sp < 100 && (unsigned)sy < (unsigned)HS && (unsigned)sx < (unsigned)HS;
+            const f32x4 v = Act<AT>::ld4(in, ok ? ((size_t)(ib * HS + sy) * HS + sx) * 32 + c4 * 4 : 0);
+            ra[i] = ok ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     if ((int)blockIdx.x < numTiles) fetch(blockIdx.x);
@@ -690,10 +697,9 @@ __device__ __forceinline__ void d4_bwd_fetch(const ThinWgradArgs& a, int mt, flo
     for (int i = 0; i < (G0 + 255) / 256; ++i) {
         const int q = tid + i * 256, c = q / 720, rem = q % 720;
         const int uy = 2 * sy0 - 2 + rem / 36, ux = 2 * sx0 - 2 + rem % 36;
-        float v = 0.f;
-        if (q < G0 && (unsigned)uy < (unsigned)H && (unsigned)ux < (unsigned)H)
-            v = a.a0[((size_t)(ib * 3 + c) * H + uy) * H + ux];
-        rg[i] = v;
+        const bool ok = q < G0 && (unsigned)uy < (unsigned)H && (unsigned)ux < (unsigned)H;
+        const float l = a.a0[ok ? ((size_t)(ib * 3 + c) * H + uy) * H + ux : 0];
+        rg[i] = ok ? l : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -836,10 +842,9 @@ __global__ __launch_bounds__(256) void d4_bwd_bf16_kernel(ThinWgradArgs a) {
         for (int i = 0; i < GQ; ++i) {
             const int q = tid + i * 256, c = q / 720, rem = q % 720;
             const int uy = 2 * sy0 - 2 + rem / 36, ux = 2 * sx0 - 2 + rem % 36;
-            float v = 0.f;
-            if (q < G0 && (unsigned)uy < (unsigned)H && (unsigned)ux < (unsigned)H)
-                v = a.a0[((size_t)(ib * 3 + c) * H + uy) * H + ux];
-            rg[i] = v;
+            const bool ok = q < G0 && (unsigned)uy < (unsigned)H && (unsigned)ux < (unsigned)H;
+            const float l = a.a0[ok ? ((size_t)(ib * 3 + c) * H + uy) * H + ux : 0];
+            rg[i] = ok ? l : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {

@@ -10,7 +10,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcvae_hip.so")
+LIB_PATH = os.environ.get("CVAE_LIB") or os.path.join(_HERE, "libcvae_hip.so")     # CVAE_LIB: A/B another build of the same sources
 N_SCALARS = 16
 
 

@@ -429,6 +429,118 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
     thin_slab_out(acc, smem, a.slab + (size_t)blockIdx.x * 96 * 32, bsum, true);
 }
 
+// precision mode 1, E1 weight gradient.  GEMM per kernel row r: dW_r[m = 4s + c][co] = sum_px P_r[px][m] * dy[px][co]
+// with P_r[px][m] = x[c][y + r - 2][px + s - 2].  The frame strip is staged as bf16 pixels of 4 channels (as in the
+// forward), so P_r is an OVERLAPPED row-major view of it (row px starts 4 elements after row px-1) and both MFMA
+// operands are transposed LDS reads (ds_read_b64_tr_b16) — no per-element gather, no conversion in the loop.
+// Wave w owns tile row w (32 pixels, 2 k-steps): 10 MFMAs + 2 for the bias row (ones x dy) per tile.
+// Slab row of a workgroup: [5 kernel rows][32 m][32 co] (m >= 20 and c == 3 are padding) | bias[32] = 5152 floats.
+static constexpr int E1W_ROW = 5 * 32 * 32 + 32;
+template <int H>
+__global__ __launch_bounds__(256) void e1_wgrad_bf16_kernel(ThinWgradArgs a) {
+    using T = Tile<H>;
+    static_assert(T::TW == 32 && T::TH == 4 && T::IMGS == 1, "one tile row per wave");
+    constexpr int HWX = 40, HR_ = T::TH + 4, NPXH = HR_ * HWX;
+    __shared__ __attribute__((aligned(16))) bf16x4 lds_x[NPXH + 8];
+    __shared__ __attribute__((aligned(16))) __bf16 lds_d[128 * 32];
+    __shared__ float red[3 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int g = lane >> 4, h = g >> 1, qrow = (lane & 15) >> 2, cb = 16 * (g & 1) + 4 * (lane & 3);
+    f32x16 acc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) ones[c] = (__bf16)1.f;
+    if (tid < 8) { bf16x4 z; z[0] = z[1] = z[2] = z[3] = (__bf16)0.f; lds_x[NPXH + tid] = z; }      // over-read pad of the last row
+    const int t0 = blockIdx.x * a.tilesPerSplit;
+    int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
+    constexpr int XQ = (NPXH + 255) / 256;
+    float rx[XQ][3];
+    bf16x8 rd[2];
+    auto fetch = [&](int mt) {
+        const int ib = mt / T::TILES_PER_IMG, tileInImg = mt % T::TILES_PER_IMG;
+        const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;
+#pragma unroll
+        for (int i = 0; i < XQ; ++i) {
+            const int q = tid + i * 256, hy = q / HWX, hx = q % HWX;
+            const int gy = ty0 + hy - 2, gx = tx0 + hx - 2;
+            const bool ok = q < NPXH && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H;
+            const size_t e = ok ? ((size_t)(ib * 3) * H + gy) * H + gx : 0;
+            const float v0 = a.a0[e], v1 = a.a0[e + (size_t)H * H], v2 = a.a0[e + 2 * (size_t)H * H];
+            rx[i][0] = ok ? v0 : 0.f; rx[i][1] = ok ? v1 : 0.f; rx[i][2] = ok ? v2 : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + i * 256, c8 = q & 3, mm = q >> 2;
+            const int gy = ty0 + mm / T::TW, gx = tx0 + mm % T::TW;
+            rd[i] = Act<__bf16>::ld8(a.a1, ((size_t)(ib * H + gy) * H + gx) * 32 + c8 * 8);
+        }
+    };
+    if (t0 < t1) fetch(t0);
+    const __bf16* xs = reinterpret_cast<const __bf16*>(lds_x);
+    for (int mt = t0; mt < t1; ++mt) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < XQ; ++i) {
+            const int q = tid + i * 256;
+            if (q < NPXH) { bf16x4 u; u[0] = (__bf16)rx[i][0]; u[1] = (__bf16)rx[i][1]; u[2] = (__bf16)rx[i][2]; u[3] = (__bf16)0.f; lds_x[q] = u; }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<bf16x8*>(lds_d + (size_t)(tid + i * 256) * 8) = rd[i];
+        __syncthreads();
+        if (mt + 1 < t1) fetch(mt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int px = 16 * ks + 8 * h + qrow;                       // this lane's block row (pixel) for read 0; read 1: +4
+            const __bf16* dp = lds_d + (wave * 32 + px) * 32 + cb;
+            const bf16x8 bv = tr_frag(dp, dp + 4 * 32);
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const __bf16* ap = xs + ((wave + r) * HWX + px) * 4 + cb;
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(ap, ap + 16), bv, acc[r], 0, 0, 0);
+            }
+            acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bv, acc[5], 0, 0, 0);
+        }
+    }
+    // every wave contracted its own tile rows: fixed-order sum over the 4 waves, one accumulator at a time
+    float* out = a.slab + (size_t)blockIdx.x * E1W_ROW;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        __syncthreads();
+        if (wave > 0) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) red[((wave - 1) * 16 + v) * 64 + lane] = acc[j][v];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            if (j < 5) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float x = ((acc[j][v] + red[v * 64 + lane]) + red[(16 + v) * 64 + lane]) + red[(32 + v) * 64 + lane];
+                    const int m = (v & 3) + 8 * (v >> 2) + 4 * lh;
+                    out[(j * 32 + m) * 32 + li] = x;
+                }
+            } else if (lh == 0) {
+                out[5 * 32 * 32 + li] = ((acc[5][0] + red[lane]) + red[16 * 64 + lane]) + red[32 * 64 + lane];     // row 0 = column sums of dy
+            }
+        }
+    }
+}
+
+// dW1[(r*5+s)*3+c][co] <- reduced slab row [r][4s+c][co]; db1 <- its bias tail
+__global__ __launch_bounds__(256) void e1_perm_kernel(const float* __restrict__ red, float* __restrict__ dw, float* __restrict__ db) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 2400) {
+        const int n = i & 31, k = i >> 5, c = k % 3, tap = k / 3, r = tap / 5, sI = tap % 5;
+        dw[i] = red[(r * 32 + 4 * sI + c) * 32 + n];
+    } else if (i < 2432 && db) {
+        db[i - 2400] = red[5 * 32 * 32 + i - 2400];
+    }
+}
+
 // dst (W4 [tap][ci][co]) <- reduced slab row (k = tap*3+co, col ci); the last workgroup also sums the
 // per-plane dOut sums into the three bias gradients (one launch instead of two)
 __global__ __launch_bounds__(256) void d4_perm_kernel(const float* __restrict__ red, float* __restrict__ dst,
@@ -457,7 +569,10 @@ static int thin_splits(int numTiles, int* tps) {
 
 int64_t e1_wgrad_ws_floats(int width, int B) {
     int tps; const int tiles = B * (width / 4) * (width / 32);
-    return (int64_t)thin_splits(tiles, &tps) * 3072 + col_reduce_ws_floats(3072);
+    const int64_t S = thin_splits(tiles, &tps);
+    const int64_t f32 = S * 3072 + col_reduce_ws_floats(3072);
+    const int64_t b16 = S * E1W_ROW + E1W_ROW + 32 + col_reduce_ws_floats(E1W_ROW);     // slabs | reduced row | column-reduce scratch
+    return f32 > b16 ? f32 : b16;
 }
 
 int launch_e1_fwd(int width, int B, const float* x, const float* w, const float* bias, float* y,
@@ -476,9 +591,17 @@ int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw
     int tps; const int tiles = B * (width / 4) * (width / 32);
     const int S = thin_splits(tiles, &tps);
     ThinWgradArgs a{x, dy, nullptr, nullptr, ws, B, tiles, tps};
-    if (width == 64 && bf16) hipLaunchKernelGGL((e1_wgrad_kernel<64, true>), dim3(S), dim3(256), 0, st, a);
-    else if (bf16) hipLaunchKernelGGL((e1_wgrad_kernel<128, true>), dim3(S), dim3(256), 0, st, a);
-    else if (width == 64) hipLaunchKernelGGL((e1_wgrad_kernel<64, false>), dim3(S), dim3(256), 0, st, a);
+    if (bf16) {          // precision mode 1: transposed-read kernel, its own slab layout + a permuting finish
+        if (width == 64) hipLaunchKernelGGL(e1_wgrad_bf16_kernel<64>, dim3(S), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(e1_wgrad_bf16_kernel<128>, dim3(S), dim3(256), 0, st, a);
+        CVAE_CHECK_LAUNCH();
+        float* red = ws + (size_t)S * E1W_ROW;
+        { int rc = launch_col_reduce(ws, S, E1W_ROW, E1W_ROW, red, red + E1W_ROW + 32, st); if (rc) return rc; }
+        hipLaunchKernelGGL(e1_perm_kernel, dim3(10), dim3(256), 0, st, red, dw, dbias);
+        CVAE_CHECK_LAUNCH();
+        return 0;
+    }
+    if (width == 64) hipLaunchKernelGGL((e1_wgrad_kernel<64, false>), dim3(S), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((e1_wgrad_kernel<128, false>), dim3(S), dim3(256), 0, st, a);
     CVAE_CHECK_LAUNCH();
     // slab row = [75 x 32 weights | 32 zeros (K pad) | 32 bias partials]: in the flat buffer enc0.b sits at

@@ -260,6 +260,146 @@ __global__ __launch_bounds__(256) void fc_bwd_dw_kernel(const float* __restrict_
     dwfc[(size_t)(k + 2) * 64 + n] = a2; dwfc[(size_t)(k + 3) * 64 + n] = a3;
 }
 
+// precision mode 1: the two batch-contracted weight gradients  C[m][n] = sum_b A[b][m] * Bm[b][n]  on the bf16 MFMA
+// (fc_mu|fc_var: A = flat (bf16 activations), Bm = dml;  decoder_input: A = [zcat | 1] (the ones column yields the
+// bias gradient), Bm = dh (bf16)).  Both inputs are row-major in b, i.e. the contraction index is the ROW: tiles of 64
+// images are copied to LDS as they are (fp32 inputs rounded to bf16 on the way) and both MFMA operands are transposed
+// LDS reads (ds_read_b64_tr_b16).  Workgroup = (32*MBLK) x (32*NBLK) outputs over the whole batch (no split-K slabs);
+// wave w contracts images 16w..16w+15 of every 64-image tile, the four partial tiles are summed through LDS.
+struct BGemmArgs {
+    const float* A; const float* Bm;      // opaque: bf16 or fp32 per template flags
+    int lda, ldb;                         // row strides in elements
+    int a_cols;                           // valid columns of A (fp32 A only); column a_cols reads as 1.0, beyond as 0
+    float* out; int ldo;                  // C rows [0, out_rows) -> out[m*ldo + n0 + n]
+    int out_rows;
+    float* out_last;                      // row `out_rows` (the ones column) -> out_last[n0 + n], may be null
+    int B;
+};
+
+template <int MBLK, int NBLK, bool A_F32, bool B_F32>
+__global__ __launch_bounds__(256) void bgemm_tr_kernel(BGemmArgs a) {
+    constexpr int MC = 32 * MBLK, NC = 32 * NBLK;
+    __shared__ __attribute__((aligned(16))) __bf16 lds_a[64 * MC];
+    __shared__ __attribute__((aligned(16))) __bf16 lds_b[64 * NC];
+    __shared__ float red[3 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int g = lane >> 4, h = g >> 1, qrow = (lane & 15) >> 2, cb = 16 * (g & 1) + 4 * (lane & 3);
+    const int m0 = A_F32 ? 0 : blockIdx.x * MC, n0 = (A_F32 ? blockIdx.x : 0) * NC;   // fp32-A form tiles N, bf16-A form tiles M
+    f32x16 acc[MBLK][NBLK];
+#pragma unroll
+    for (int i = 0; i < MBLK; ++i)
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    constexpr int AU = A_F32 ? (64 * MC) / 256 : (64 * MC / 8 + 255) / 256;        // per-thread staging items
+    constexpr int BU = B_F32 ? (64 * NC / 4) / 256 : (64 * NC / 8 + 255) / 256;
+    float ra32[A_F32 ? AU : 1];
+    bf16x8 ra16[A_F32 ? 1 : AU];
+    f32x4 rb32[B_F32 ? BU : 1];
+    bf16x8 rb16[B_F32 ? 1 : BU];
+    bf16x8 zero8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) zero8[c] = (__bf16)0.f;
+    auto fetch = [&](int b0) {
+        if constexpr (A_F32) {
+#pragma unroll
+            for (int i = 0; i < AU; ++i) {
+                const int q = tid + i * 256, r = q / MC, c = q % MC, b = b0 + r;
+                const bool ok = b < a.B && c < a.a_cols;
+                const float l = a.A[ok ? (size_t)b * a.lda + c : 0];
+                ra32[i] = ok ? l : ((b < a.B && c == a.a_cols) ? 1.0f : 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < AU; ++i) {
+                const int q = tid + i * 256, r = q / (MC / 8), c8 = q % (MC / 8), b = b0 + r;
+                const bool ok = (64 * MC / 8) % 256 == 0 || q < 64 * MC / 8;
+                const bool inb = ok && b < a.B;
+                const bf16x8 l = Act<__bf16>::ld8(a.A, inb ? (size_t)b * a.lda + m0 + c8 * 8 : 0);
+                ra16[i] = inb ? l : zero8;
+            }
+        }
+        if constexpr (B_F32) {
+#pragma unroll
+            for (int i = 0; i < BU; ++i) {
+                const int q = tid + i * 256, r = q / (NC / 4), c4 = q % (NC / 4), b = b0 + r;
+                const bool ok = b < a.B;
+                const f32x4 l = *reinterpret_cast<const f32x4*>(a.Bm + (ok ? (size_t)b * a.ldb + n0 + c4 * 4 : 0));
+                rb32[i] = ok ? l : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BU; ++i) {
+                const int q = tid + i * 256, r = q / (NC / 8), c8 = q % (NC / 8), b = b0 + r;
+                const bool ok = ((64 * NC / 8) % 256 == 0 || q < 64 * NC / 8) && b < a.B;
+                const bf16x8 l = Act<__bf16>::ld8(a.Bm, ok ? (size_t)b * a.ldb + n0 + c8 * 8 : 0);
+                rb16[i] = ok ? l : zero8;
+            }
+        }
+    };
+    fetch(0);
+    for (int b0 = 0; b0 < a.B; b0 += 64) {
+        __syncthreads();
+        if constexpr (A_F32) {
+#pragma unroll
+            for (int i = 0; i < AU; ++i) lds_a[tid + i * 256] = (__bf16)ra32[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < AU; ++i) {
+                const int q = tid + i * 256;
+                if ((64 * MC / 8) % 256 == 0 || q < 64 * MC / 8) *reinterpret_cast<bf16x8*>(lds_a + (size_t)q * 8) = ra16[i];
+            }
+        }
+        if constexpr (B_F32) {
+#pragma unroll
+            for (int i = 0; i < BU; ++i) {
+                bf16x4 u;
+                u[0] = (__bf16)rb32[i][0]; u[1] = (__bf16)rb32[i][1]; u[2] = (__bf16)rb32[i][2]; u[3] = (__bf16)rb32[i][3];
+                *reinterpret_cast<bf16x4*>(lds_b + (size_t)(tid + i * 256) * 4) = u;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BU; ++i) {
+                const int q = tid + i * 256;
+                if ((64 * NC / 8) % 256 == 0 || q < 64 * NC / 8) *reinterpret_cast<bf16x8*>(lds_b + (size_t)q * 8) = rb16[i];
+            }
+        }
+        __syncthreads();
+        if (b0 + 64 < a.B) fetch(b0 + 64);
+        const int row = 16 * wave + 8 * h + qrow;            // this wave's 16 images of the tile
+        bf16x8 bv[NBLK];
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) bv[j] = tr_frag(lds_b + row * NC + j * 32 + cb, lds_b + (row + 4) * NC + j * 32 + cb);
+#pragma unroll
+        for (int i = 0; i < MBLK; ++i) {
+            const bf16x8 av = tr_frag(lds_a + row * MC + i * 32 + cb, lds_a + (row + 4) * MC + i * 32 + cb);
+#pragma unroll
+            for (int j = 0; j < NBLK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MBLK; ++i)
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) {
+            __syncthreads();
+            if (wave > 0) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) red[((wave - 1) * 16 + v) * 64 + lane] = acc[i][j][v];
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float x = ((acc[i][j][v] + red[v * 64 + lane]) + red[(16 + v) * 64 + lane]) + red[(32 + v) * 64 + lane];
+                    const int m = m0 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh, n = n0 + j * 32 + li;
+                    if (m < a.out_rows) a.out[(size_t)m * a.ldo + n] = x;
+                    else if (m == a.out_rows && a.out_last) a.out_last[n] = x;
+                }
+            }
+        }
+}
+
 static inline int bott(int width) { return 256 * (width / 16) * (width / 16); }
 static inline int decin_splits(int B) { int s = cdiv(B, 16); return s > 16 ? 16 : s; }
 
@@ -298,9 +438,14 @@ int launch_decin_bwd(int width, int B, const float* zcat, const float* dh, const
     CVAE_CHECK_LAUNCH();
     hipLaunchKernelGGL(decin_dz_finish_kernel, dim3(cdiv(B * 33, 256)), dim3(256), 0, st, ws, dzcat, B, FC_KS);
     CVAE_CHECK_LAUNCH();
+    if (bf16io) {        // [zcat | 1]^T . dh on the bf16 MFMA, whole batch per workgroup: dWd and dbd written directly
+        BGemmArgs g{zcat, dh, 33, K, 33, dwd, K, 33, dbd, B};
+        hipLaunchKernelGGL((bgemm_tr_kernel<2, 1, true, false>), dim3(K / 32), dim3(256), 0, st, g);
+        CVAE_CHECK_LAUNCH();
+        return 0;
+    }
     const int S = decin_splits(B), bps = cdiv(B, S);
-    if (bf16io) hipLaunchKernelGGL(decin_bwd_dw_kernel<__bf16>, dim3(K / 256, S), dim3(256), 0, st, zcat, dh, ws, B, K, bps);
-    else hipLaunchKernelGGL(decin_bwd_dw_kernel<float>, dim3(K / 256, S), dim3(256), 0, st, zcat, dh, ws, B, K, bps);
+    hipLaunchKernelGGL(decin_bwd_dw_kernel<float>, dim3(K / 256, S), dim3(256), 0, st, zcat, dh, ws, B, K, bps);
     CVAE_CHECK_LAUNCH();
     int rc = launch_reduce_slabs(ws, dwd, (int64_t)33 * K, S, (int64_t)34 * K, st);
     if (rc) return rc;
@@ -321,8 +466,10 @@ int launch_fc_bwd(int width, int B, const float* flat, const float* wfc, const f
     if (bf16io) hipLaunchKernelGGL(fc_bwd_dflat_kernel<__bf16>, dim3(cdiv(B, 8), K / 256), dim3(256), 0, st, dml, wfc, dflat, B, K);
     else hipLaunchKernelGGL(fc_bwd_dflat_kernel<float>, dim3(cdiv(B, 8), K / 256), dim3(256), 0, st, dml, wfc, dflat, B, K);
     CVAE_CHECK_LAUNCH();
-    if (bf16io) hipLaunchKernelGGL(fc_bwd_dw_kernel<__bf16>, dim3(K / 16), dim3(256), 0, st, flat, dml, dwfc, B, K);
-    else hipLaunchKernelGGL(fc_bwd_dw_kernel<float>, dim3(K / 16), dim3(256), 0, st, flat, dml, dwfc, B, K);
+    if (bf16io) {        // flat^T . dml on the bf16 MFMA
+        BGemmArgs g{flat, dml, K, 64, 0, dwfc, 64, K, nullptr, B};
+        hipLaunchKernelGGL((bgemm_tr_kernel<1, 2, false, true>), dim3(K / 32), dim3(256), 0, st, g);
+    } else hipLaunchKernelGGL(fc_bwd_dw_kernel<float>, dim3(K / 16), dim3(256), 0, st, flat, dml, dwfc, B, K);
     CVAE_CHECK_LAUNCH();
     return 0;
 }

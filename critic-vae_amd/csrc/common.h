@@ -128,6 +128,12 @@ __device__ __forceinline__ bool wg_arrive_last(unsigned* counter, unsigned total
 void cvae_probe_begin(hipStream_t st);
 void cvae_probe_end(hipStream_t st);
 
+// Split-K slab reductions of the weight gradients are off the critical path (nothing reads dW before the phase
+// ends): when the orchestration arms a side stream (api.hip), a wgrad launcher calls cvae_reduce_stream(st) right
+// after its main kernel and enqueues its small reduce / expand kernels on the stream it returns (ordered behind
+// the main kernel by an event), so their ~5 us launch floors overlap the next input-gradient kernel.
+hipStream_t cvae_reduce_stream(hipStream_t st);
+
 // error plumbing (api.hip)
 void cvae_set_error(const char* fmt, ...);
 #define CVAE_CHECK_LAUNCH()                                                        \

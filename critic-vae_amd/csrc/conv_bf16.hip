@@ -749,6 +749,7 @@ static int run_wgrad_bf16(int B, const float* in, const float* dout, float* dw, 
     cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();
     float* mid = ws + (size_t)S * row;
+    st = cvae_reduce_stream(st);
     if (dbias == dw + n) return launch_reduce_slabs(ws, dw, row, S, row, st, mid);
     int rc = launch_reduce_slabs(ws, dw, n, S, row, st, mid);
     if (rc || !dbias) return rc;

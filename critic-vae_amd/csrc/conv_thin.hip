@@ -595,6 +595,7 @@ int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw
         if (width == 64) hipLaunchKernelGGL(e1_wgrad_bf16_kernel<64>, dim3(S), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(e1_wgrad_bf16_kernel<128>, dim3(S), dim3(256), 0, st, a);
         CVAE_CHECK_LAUNCH();
+        st = cvae_reduce_stream(st);
         float* red = ws + (size_t)S * E1W_ROW;
         { int rc = launch_col_reduce(ws, S, E1W_ROW, E1W_ROW, red, red + E1W_ROW + 32, st); if (rc) return rc; }
         hipLaunchKernelGGL(e1_perm_kernel, dim3(10), dim3(256), 0, st, red, dw, dbias);
@@ -604,6 +605,7 @@ int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw
     if (width == 64) hipLaunchKernelGGL((e1_wgrad_kernel<64, false>), dim3(S), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((e1_wgrad_kernel<128, false>), dim3(S), dim3(256), 0, st, a);
     CVAE_CHECK_LAUNCH();
+    st = cvae_reduce_stream(st);
     // slab row = [75 x 32 weights | 32 zeros (K pad) | 32 bias partials]: in the flat buffer enc0.b sits at
     // enc0.w + 2432 (2400 weights padded to 64 floats), so ONE column reduction fills both
     if (dbias == dw + 2432)

@@ -591,6 +591,7 @@ static int run_up_wgrad(int B, const float* in, const float* dout, float* dw, fl
     }
     float* mid = ws + (size_t)S * row;
     float* red = mid + (size_t)16 * row;
+    st = cvae_reduce_stream(st);              // reduce + expand are off the critical path
     { int rc = launch_reduce_slabs(ws, red, row, S, row, st, mid); if (rc) return rc; }
     const float* rows = red;
     const int R = 1;

@@ -259,6 +259,7 @@ static int run_wgrad(int B, const float* in, const float* dout, float* dw, float
     cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();
     float* mid = ws + (size_t)S * row;
+    st = cvae_reduce_stream(st);              // the slab reduction is off the critical path
     if (dbias == dw + n)                      // flat gradient buffer: bias follows its weight -> one reduction
         return launch_reduce_slabs(ws, dw, row, S, row, st, mid);
     int rc = launch_reduce_slabs(ws, dw, n, S, row, st, mid);

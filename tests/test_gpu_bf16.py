@@ -212,3 +212,94 @@ def test_bf16x9_emulation_meets_the_fp32_parity_bar(B, mode):
             assert err <= 5e-3 * max(want.abs().max().item(), 1e-30), (k, err)
     # and it sits as close to the fp32-MFMA mode as that mode sits to the oracle
     assert (mu - res["f32"][0]).abs().max() < 2e-5 and (recon - res["f32"][1]).abs().max() < 2e-5
+
+
+def test_bf16_kernels_exact_on_their_stored_operands():
+    """Layout / indexing check of every bf16-mode contraction, independent of the bf16 rounding noise: after one
+    bf16 step the workspace holds the bf16 activations and activation gradients the kernels actually consumed.
+    Recomputing each layer's result on the CPU in fp32 from THOSE operands (weights rounded to bf16 as the packed
+    copies are) must reproduce the kernel outputs up to fp32 summation order (weight / bias gradients: 2e-3 of the
+    tensor max) or up to the bf16 rounding of the stored result (activations: 2^-8 of the tensor max).  Catches
+    what the statistical bounds above cannot: a wrong tap, channel or pixel permutation in the transposed-LDS-read
+    weight-gradient kernels, the phase-collapsed up-convs or the E1 / fc permuting finishes."""
+    import torch.nn.functional as F
+    from critic_vae_amd.nets import VariationalAutoencoder
+    from critic_vae_amd.train import FusedTrainer
+    from critic_vae_amd import layout as L
+    dev = torch.device("cuda:0")
+    B, W = 8, 64
+    vae = VariationalAutoencoder(width=W, max_batch=B, seed=0, precision="bf16").to(dev)
+    tr = FusedTrainer(vae)
+    x, pred, eps = (torch.from_numpy(v).to(dev) for v in synth.make_batch(1234, 0, B, W))
+    h, theta = vae.handle, vae.theta.data
+    h.forward(B, x, pred, eps, theta, vae.bn_state, tr.mu, tr.logvar, tr.recon, tr.ws, train=True)
+    h.loss(B, x, tr.mu, tr.logvar, tr.recon, tr.ws, tr.scalars, tr.d_recon, tr.d_mu, tr.d_logvar)
+    h.backward(B, x, pred, eps, theta, tr.logvar, tr.recon, tr.d_recon, tr.d_mu, tr.d_logvar, tr.ws, tr.grads)
+    torch.cuda.synchronize()
+    ws16 = tr.ws.view(torch.bfloat16)
+
+    def act(name, c, s):            # stored bf16 NHWC tensor -> fp32 NCHW on the CPU
+        off = h.lib.cvae_ws_offset(h.h, B, name.encode())
+        assert off >= 0, name
+        return ws16[2 * off:2 * off + B * s * s * c].float().view(B, s, s, c).permute(0, 3, 1, 2).contiguous().cpu()
+
+    ref = L.native_to_ref(h.layout, theta.cpu())
+    grd = L.native_to_ref(h.layout, tr.grads.cpu())
+    bf = lambda t: t.to(torch.bfloat16).float()      # noqa: E731
+    enc = [(3, 32, 64), (32, 64, 32), (64, 128, 16), (128, 256, 8)]
+    dec = [(256, 128, 4), (128, 64, 8), (64, 32, 16), (32, 32, 32), (32, 3, 64)]
+
+    def close(got, want, what, rel):
+        scale = want.abs().max().item()
+        err = (got - want).abs().max().item()
+        assert err <= rel * scale + 1e-12, f"{what}: err {err:.3e} vs max {scale:.3e}"
+
+    def wgrad(inp, dout):           # dW (O,I,5,5), db of a 5x5 / pad 2 conv from its input and output gradient
+        return torch.nn.grad.conv2d_weight(inp, (dout.shape[1], inp.shape[1], 5, 5), dout, padding=2), dout.sum(dim=(0, 2, 3))
+
+    # ---- encoder: forward conv, weight / bias gradient, input gradient ----
+    for l, (ci, co, s) in enumerate(enc):
+        inp = bf(x.cpu()) if l == 0 else act(f"a{l - 1}", ci, s)
+        wk, bk = f"encoder.model.{4 * l}.weight", f"encoder.model.{4 * l}.bias"
+        y = F.conv2d(inp, bf(ref[wk]), ref[bk], padding=2)
+        close(act(f"y{l}", co, s), y, f"y{l}", 2.0 ** -8)
+        dy = act(f"d_y{l}", co, s)
+        dw, db = wgrad(inp, dy)
+        close(grd[wk], dw, f"dW enc{l}", 2e-3)
+        # pre-BatchNorm bias: the true gradient cancels to ~0, so compare against the size of the summed terms
+        assert (grd[bk] - db).abs().max().item() <= 1e-5 * dy.abs().sum(dim=(0, 2, 3)).max().item() + 1e-7, f"db enc{l}"
+        if l > 0:
+            da = F.conv_transpose2d(dy, bf(ref[wk]), padding=2)
+            close(act(f"d_a{l - 1}", ci, s), da, f"d_a{l - 1}", 2.0 ** -8)
+    # ---- decoder: D0 plain, D1..D3 behind a nearest-2x upsample (phase-collapsed in the kernels) ----
+    for i, (ci, co, s) in enumerate(dec[:4]):
+        src = act("h", 256, 4) if i == 0 else act(f"o{i - 1}", ci, s // 2)
+        inp = src if i == 0 else F.interpolate(src, scale_factor=2, mode="nearest")
+        wk, bk = f"decoder.model.{3 * i}.weight", f"decoder.model.{3 * i}.bias"
+        o = torch.relu(F.conv2d(inp, bf(ref[wk]), ref[bk], padding=2))
+        # D1..D3 round the PRE-SUMMED collapsed weights to bf16, not the 5x5 ones: allow one more bf16 rounding
+        close(act(f"o{i}", co, s), o, f"o{i}", 2.0 ** -8 if i == 0 else 2.0 ** -6)
+        do = act(f"d_o{i}", co, s)
+        dw, db = wgrad(inp, do)
+        close(grd[wk], dw, f"dW dec{i}", 2e-3)
+        close(grd[bk], db, f"db dec{i}", 2e-3)
+    # ---- decoder_input: [zcat | 1]^T . d_h ----
+    off = h.lib.cvae_ws_offset(h.h, B, b"zcat")
+    zcat = tr.ws[off:off + B * 33].view(B, 33).cpu()
+    dh = act("d_h", 256, 4)                                            # (B,256,4,4) = the reference's view(-1,256,4,4)
+    dwd = bf(zcat).t() @ dh.reshape(B, -1)                             # (33, 4096) in (C,H,W) column order
+    close(grd["decoder.decoder_input.weight"], dwd.t().contiguous(), "dW decoder_input", 2e-3)
+    close(grd["decoder.decoder_input.bias"], dh.reshape(B, -1).sum(0), "db decoder_input", 2e-3)
+    # ---- D4 (Upsample -> Conv(32->3) -> Tanh): forward on exact bf16 products; backward through G rounded to bf16 ----
+    o3 = act("o3", 32, 32)
+    up3 = F.interpolate(o3, scale_factor=2, mode="nearest")
+    w4, b4 = ref["decoder.model.12.weight"], ref["decoder.model.12.bias"]
+    recon = torch.tanh(F.conv2d(up3, bf(w4), b4, padding=2))
+    close(tr.recon[:B].cpu(), recon, "recon", 1e-4)
+    dout = (tr.d_recon[:B] * (1.0 - tr.recon[:B] ** 2)).cpu()
+    dw4, db4 = wgrad(up3, dout)
+    close(grd["decoder.model.12.weight"], dw4, "dW dec4", 1e-2)         # the 2x2-block sums G are rounded to bf16
+    close(grd["decoder.model.12.bias"], db4, "db dec4", 1e-4)            # summed in fp32 from dOut itself
+    d_up = F.conv_transpose2d(dout, bf(w4), padding=2)
+    d_o3 = F.avg_pool2d(d_up, 2) * 4.0 * (o3 > 0).float()                # Upsample backward = 2x2 sum, then the ReLU mask
+    close(act("d_o3", 32, 32), d_o3, "d_o3", 2.0 ** -6)

@@ -24,10 +24,8 @@ __device__ __forceinline__ constexpr int e1_off(int k) {
 // (four 32-pixel accumulator tiles).  The whole B operand (76 x 32 weights) lives in 38 registers per
 // lane, read once from global; the x halo (3 planes) is staged once per strip.  Epilogue: bias,
 // NHWC store, and the strip's BatchNorm partial (sum, M2 about the strip mean).
-// BF16 (precision mode 1): the same kernel with the contraction on v_mfma_f32_32x32x16_bf16 — the lane gathers
-// its 8 consecutive k = (tap, channel) values from the fp32 planes and rounds them to bf16 (K = 75 padded to
-// 80: 5 MFMAs per 32 pixels instead of 38), which leaves the kernel bound by the y1 store.
-template <int H, bool BF16 = false>
+// (precision mode 1 runs e1_fwd_bf16_kernel below instead.)
+template <int H>
 __global__ __launch_bounds__(256) void e1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ y,
                                                      float* __restrict__ bnpart, int B) {
@@ -39,20 +37,9 @@ __global__ __launch_bounds__(256) void e1_fwd_kernel(const float* __restrict__ x
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int ib = blockIdx.x / (SX * SY), t = blockIdx.x % (SX * SY);
     const int ty0 = (t / SX) * SR, tx0 = (t % SX) * SW;
-    float bw[BF16 ? 1 : 38];
-    bf16x8 bwb[BF16 ? 5 : 1];
-    if (BF16) {
+    float bw[38];
 #pragma unroll
-        for (int kb = 0; kb < 5; ++kb)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 16 * kb + 8 * lh + j;
-                bwb[kb][j] = (__bf16)(k < 75 ? w[k * 32 + li] : 0.f);
-            }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 38; ++j) bw[j] = (2 * j + lh < 75) ? w[(2 * j + lh) * 32 + li] : 0.f;
-    }
+    for (int j = 0; j < 38; ++j) bw[j] = (2 * j + lh < 75) ? w[(2 * j + lh) * 32 + li] : 0.f;
     {       // all halo loads are issued before the first LDS write (clamped address + select: no branch per element)
         constexpr int NQ = 3 * HW_ * HR_, NIT = (NQ + 255) / 256;
         float xv[NIT];
@@ -77,27 +64,12 @@ __global__ __launch_bounds__(256) void e1_fwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[r][v] = 0.f;
     const int aBase = (wave * 4) * HW_ + li;
-    if (BF16) {
+#pragma unroll
+    for (int j = 0; j < 38; ++j) {
+        const int off = lh ? e1_off<PS, HW_>(2 * j + 1) : e1_off<PS, HW_>(2 * j);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int kb = 0; kb < 5; ++kb) {
-                bf16x8 av;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {       // k >= 75 reads offset 0 (finite pixels) against a zero weight
-                    const int off = lh ? e1_off<PS, HW_>(16 * kb + 8 + j) : e1_off<PS, HW_>(16 * kb + j);
-                    av[j] = (__bf16)lds_x[aBase + r * HW_ + off];
-                }
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bwb[kb], acc[r], 0, 0, 0);
-            }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 38; ++j) {
-            const int off = lh ? e1_off<PS, HW_>(2 * j + 1) : e1_off<PS, HW_>(2 * j);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds_x[aBase + r * HW_ + off], bw[j], acc[r], 0, 0, 0);
-        }
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds_x[aBase + r * HW_ + off], bw[j], acc[r], 0, 0, 0);
     }
     // epilogue: element v of lane (li, lh) in tile r = pixel column (v&3)+8*(v>>2)+4*lh of row 4*wave+r, channel li
     const float bv = bias[li];
@@ -113,24 +85,11 @@ __global__ __launch_bounds__(256) void e1_fwd_kernel(const float* __restrict__ x
             patch[((v & 3) + 8 * (v >> 2) + 4 * lh) * 36 + li] = val;
         }
         const int gy = ty0 + wave * 4 + r;
-        if (BF16) {             // precision mode 1: y1 is stored as bf16, 8 channels = one 16-byte unit per lane
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int idx = it * 64 + lane, px = idx >> 2, c8 = idx & 3;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(patch + px * 36 + c8 * 8);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(patch + px * 36 + c8 * 8 + 4);
-                bf16x8 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { o[e] = (__bf16)lo[e]; o[4 + e] = (__bf16)hi[e]; }
-                Act<__bf16>::st8(y, ((size_t)(ib * H + gy) * H + tx0 + px) * 32 + c8 * 8, o);
-            }
-        } else {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int idx = it * 64 + lane, px = idx >> 3, c4 = idx & 7;
             const float4 val = *reinterpret_cast<const float4*>(patch + px * 36 + c4 * 4);
             *reinterpret_cast<float4*>(y + ((size_t)(ib * H + gy) * H + tx0 + px) * 32 + c4 * 4) = val;
-        }
         }
     }
     s += __shfl_xor(s, 32, 64);
@@ -303,7 +262,7 @@ __device__ __forceinline__ void thin_slab_out(f32x16 (&acc)[3], float* red, floa
 }
 
 // tile mt of E1 wgrad into registers: x halo (3 planes, zero padded) and the 128x32 dy tile
-template <int H, bool BF16>
+template <int H>
 __device__ __forceinline__ void e1_wgrad_fetch(const ThinWgradArgs& a, int mt, float (&rx)[(3 * Tile<H>::HPI + 255) / 256],
                                                f32x4 (&rd)[4]) {
     using T = Tile<H>;
@@ -319,17 +278,6 @@ __device__ __forceinline__ void e1_wgrad_fetch(const ThinWgradArgs& a, int mt, f
         const float l = a.a0[ok ? ((size_t)(ib * 3 + c) * H + gy) * H + gx : 0];      // no branch around the load
         rx[i] = ok ? l : 0.f;
     }
-    if (BF16) {          // dy is bf16 (precision mode 1): two 16-byte units per thread, widened to the same 4 x f32x4
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int q = tid + i * 256, c8 = q & 3, mm = q >> 2;
-            const int gy = ty0 + mm / T::TW, gx = tx0 + mm % T::TW;
-            const bf16x8 v = Act<__bf16>::ld8(a.a1, ((size_t)(ib * H + gy) * H + gx) * 32 + c8 * 8);
-            rd[2 * i] = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-            rd[2 * i + 1] = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
-        }
-        return;
-    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int q = tid + i * 256, c4 = q & 7, mm = q >> 3;
@@ -338,10 +286,8 @@ __device__ __forceinline__ void e1_wgrad_fetch(const ThinWgradArgs& a, int mt, f
     }
 }
 
-// BF16 (precision mode 1): k of the MFMA runs over 8 consecutive pixels of a tile row per lane half
-// (v_mfma_f32_32x32x16_bf16: 6 instructions per 128-pixel tile and wave instead of 48); operands are
-// rounded to bf16 as they leave LDS, the bias gradient is still summed from the fp32 values.
-template <int H, bool BF16 = false>
+// (precision mode 1 runs e1_wgrad_bf16_kernel below instead.)
+template <int H>
 __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
     using T = Tile<H>;
     constexpr int X_FLOATS = ((3 * T::PS + 3) / 4) * 4;
@@ -370,7 +316,7 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
     constexpr int XQ = (3 * T::HPI + 255) / 256;
     float rx[XQ];
     f32x4 rd[4];
-    if (t0 < t1) e1_wgrad_fetch<H, BF16>(a, t0, rx, rd);
+    if (t0 < t1) e1_wgrad_fetch<H>(a, t0, rx, rd);
     for (int mt = t0; mt < t1; ++mt) {
         __syncthreads();
 #pragma unroll
@@ -380,34 +326,11 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            // BF16: rd[2i], rd[2i+1] = the two halves of 16-byte unit q = tid + i*256 (pixel q>>2, octet q&3)
-            const int q = BF16 ? tid + (i >> 1) * 256 : tid + i * 256;
-            float* d = BF16 ? lds_d + (q >> 2) * 32 + (q & 3) * 8 + (i & 1) * 4 : lds_d + (q >> 3) * 32 + (q & 7) * 4;
-            *reinterpret_cast<f32x4*>(d) = rd[i];
+            const int q = tid + i * 256;
+            *reinterpret_cast<f32x4*>(lds_d + (q >> 3) * 32 + (q & 7) * 4) = rd[i];
         }
         __syncthreads();
-        if (mt + 1 < t1) e1_wgrad_fetch<H, BF16>(a, mt + 1, rx, rd);
-        if (BF16) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int mm0 = wave * 32 + 16 * ks + 8 * lh;          // this lane half's 8 consecutive pixels
-                const int poff0 = (mm0 / T::TW) * T::HTW + mm0 % T::TW;
-                bf16x8 bvv;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float d = lds_d[(mm0 + j) * 32 + li];
-                    bsum += d;
-                    bvv[j] = (__bf16)d;
-                }
-#pragma unroll
-                for (int mb = 0; mb < 3; ++mb) {
-                    bf16x8 av;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) av[j] = (__bf16)lds_x[aoff[mb] + poff0 + j];
-                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bvv, acc[mb], 0, 0, 0);
-                }
-            }
-        } else {
+        if (mt + 1 < t1) e1_wgrad_fetch<H>(a, mt + 1, rx, rd);
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const int mm = wave * 32 + 2 * kk + lh;
@@ -417,7 +340,6 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
 #pragma unroll
             for (int mb = 0; mb < 3; ++mb)
                 acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds_x[aoff[mb] + poff], bv, acc[mb], 0, 0, 0);
-        }
         }
     }
     // each wave summed its own 32 pixels per tile: total over the 4 waves
@@ -579,8 +501,8 @@ int launch_e1_fwd(int width, int B, const float* x, const float* w, const float*
                   float* bnpart, hipStream_t st, bool bf16) {
     if (width == 64 && bf16) hipLaunchKernelGGL(e1_fwd_bf16_kernel<64>, dim3(B * 8), dim3(256), 0, st, x, w, bias, y, bnpart, B);
     else if (width == 128 && bf16) hipLaunchKernelGGL(e1_fwd_bf16_kernel<128>, dim3(B * 32), dim3(256), 0, st, x, w, bias, y, bnpart, B);
-    else if (width == 64) hipLaunchKernelGGL((e1_fwd_kernel<64, false>), dim3(B * 8), dim3(256), 0, st, x, w, bias, y, bnpart, B);
-    else if (width == 128) hipLaunchKernelGGL((e1_fwd_kernel<128, false>), dim3(B * 32), dim3(256), 0, st, x, w, bias, y, bnpart, B);
+    else if (width == 64) hipLaunchKernelGGL(e1_fwd_kernel<64>, dim3(B * 8), dim3(256), 0, st, x, w, bias, y, bnpart, B);
+    else if (width == 128) hipLaunchKernelGGL(e1_fwd_kernel<128>, dim3(B * 32), dim3(256), 0, st, x, w, bias, y, bnpart, B);
     else { cvae_set_error("e1_fwd: width %d unsupported", width); return -2; }
     CVAE_CHECK_LAUNCH();
     return 0;
@@ -602,8 +524,8 @@ int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw
         CVAE_CHECK_LAUNCH();
         return 0;
     }
-    if (width == 64) hipLaunchKernelGGL((e1_wgrad_kernel<64, false>), dim3(S), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((e1_wgrad_kernel<128, false>), dim3(S), dim3(256), 0, st, a);
+    if (width == 64) hipLaunchKernelGGL(e1_wgrad_kernel<64>, dim3(S), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(e1_wgrad_kernel<128>, dim3(S), dim3(256), 0, st, a);
     CVAE_CHECK_LAUNCH();
     st = cvae_reduce_stream(st);
     // slab row = [75 x 32 weights | 32 zeros (K pad) | 32 bias partials]: in the flat buffer enc0.b sits at

@@ -6,7 +6,8 @@
  * (ctypes stub in INTEGRATION.md); each entry point names the reference call it replaces.
  *
  * Conventions
- *   - Plain C types only.  Every pointer is a DEVICE pointer unless stated; all tensors fp32.
+ *   - Plain C types only.  Every pointer is a DEVICE pointer unless stated; every tensor that crosses this
+ *     boundary is fp32 (precision mode 1 keeps bf16 tensors only inside the workspace it is handed).
  *   - The caller owns every buffer (parameters, gradients, inputs, outputs, workspace); the
  *     library owns only the opaque handle.  No allocation, no device synchronisation inside.
  *   - All work is enqueued on the caller's hipStream_t (passed as void*).
@@ -34,11 +35,13 @@ typedef struct cvae_config {
     int32_t width;        /* frame width == height: 64 (vae_parameters.py:5) or 128 (BASELINE config 5 shape) */
     int32_t max_batch;    /* largest per-call batch the workspace is sized for                 */
     int32_t overlap_wgrad;    /* != 0: run weight-gradient kernels on an internal low-priority side stream */
-    int32_t precision;    /* precision: 0 = fp32 everywhere (the 1e-4-parity path); 1 = bf16-MFMA contractions
-                           * (fp32 accumulate, fp32 tensors and master weights in HBM) for every pass of the convs
-                           * E2..E4 and D0..D3 (BASELINE.json configs 3-5); 2 = fp32 emulation: forward/dgrad of E2..E4 and D0 on
-                           * the bf16 MFMA with exact 3-way bf16 operand splits (9 MFMAs per block), everything else as 0; 3 = as 2 with the six leading
-                           * partial products only; other values are rejected */
+    int32_t precision;    /* 0 = fp32 everywhere (the 1e-4-parity path, bench default);
+                           * 1 = bf16 mode (BASELINE.json configs 3-5): every contraction on the bf16 MFMA (fp32 accumulate) AND
+                           *     activations / activation gradients stored as bf16 inside the workspace; x, recon, mu, logvar, the loss
+                           *     gradients, parameters, gradients, BatchNorm statistics and Adam state stay fp32 at this boundary;
+                           * 2 = fp32 emulation: forward/dgrad of E2..E4 and D0 on the bf16 MFMA with exact 3-way bf16 operand splits
+                           *     (9 MFMAs per block), everything else as 0;  3 = as 2 with the six leading partial products only;
+                           * other values are rejected */
 } cvae_config;
 
 enum { CVAE_OK = 0, CVAE_EINVAL = -1, CVAE_EUNSUPPORTED = -2, CVAE_ENOWS = -3 };

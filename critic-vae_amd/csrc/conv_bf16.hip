@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
         img0v[tl] = ((mt0 + tl) / T::TILES_PER_IMG) * T::IMGS;
         ty0v[tl] = (tileInImg / T::TILES_X) * T::TH; tx0v[tl] = (tileInImg % T::TILES_X) * T::TW;
     }
-    const int m = wave * 32 + li;
+    const int m = wave * 32 + lane_pix<H, NS == 1>(li);      // conflict-free lane -> pixel map (conv_epilogue.h)
     const int pimg = m / (T::TH * T::TW), prem = m % (T::TH * T::TW);
     const int aPix = pimg * T::HPI + (prem / T::TW) * T::HTW + (prem % T::TW);
 
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
                     bf16x8 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { o[e] = (__bf16)lo[e]; o[4 + e] = (__bf16)hi[e]; }
-                    const int mm = wave * 32 + px;
+                    const int mm = wave * 32 + lane_pix<H, NS == 1>(px);
                     const int im = mm / (T::TH * T::TW), rem = mm % (T::TH * T::TW);
                     const int gy = ty0 + rem / T::TW, gx = tx0 + rem % T::TW, ib = img0 + im;
                     if (ib >= a.B) continue;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
             for (int it = 0; it < 4; ++it) {
                 const int idx = it * 64 + lane, px = idx >> 3, c4 = idx & 7;
                 f32x4 val = *reinterpret_cast<const f32x4*>(patch + px * 36 + c4 * 4);
-                const int mm = wave * 32 + px;
+                const int mm = wave * 32 + lane_pix<H, NS == 1>(px);
                 const int im = mm / (T::TH * T::TW), rem = mm % (T::TH * T::TW);
                 const int gy = ty0 + rem / T::TW, gx = tx0 + rem % T::TW, ib = img0 + im;
                 if (ib >= a.B) continue;
@@ -330,10 +330,10 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
             }
         }
     } else if (KSPLIT > 1) {
-        epilogue_store<H, NT, NCH, EPI_PLAIN>(acc[tl], nullptr, a.out + (size_t)blockIdx.z * a.sliceFloats, nullptr, smem, a.B,
-                                              mt, n0, img0, ty0, tx0, numTiles);
+        epilogue_store<H, NT, NCH, EPI_PLAIN, float, NS == 1>(acc[tl], nullptr, a.out + (size_t)blockIdx.z * a.sliceFloats, nullptr, smem, a.B,
+                                                              mt, n0, img0, ty0, tx0, numTiles);
     } else {
-        if constexpr (NS == 1) epilogue_store<H, NT, NCH, EPI, __bf16>(acc[tl], a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0, numTiles);
+        if constexpr (NS == 1) epilogue_store<H, NT, NCH, EPI, __bf16, true>(acc[tl], a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0, numTiles);
         else epilogue_store<H, NT, NCH, EPI>(acc[tl], a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0, numTiles);
     }
     }

@@ -4,13 +4,30 @@
 
 enum { EPI_BIAS_BNSTAT = 0, EPI_BIAS_RELU = 1, EPI_PLAIN = 2, EPI_POOLSUM_MASK = 3 };
 
+// Row r (0..31) of a wave's 32-pixel MFMA sub-tile -> pixel of that sub-tile (row-major tile order).  Identity for
+// the fp32 kernels.  The bf16 kernels read their A fragments as 16-byte units `[octet][halo pixel]` with
+// ds_read_b128, whose 16-lane groups are {0-3,12-15,20-27} and {4-11,16-19,28-31}: with halo rows TW+4 units apart,
+// the identity map puts two lanes of a group on the same 16-byte bank slot for the 16- and 8-pixel-wide tiles
+// (25-38 % of the LDS cycles of those kernels were conflicts).  These permutations give every group 16 distinct slots.
+template <int H, bool PERM>
+__device__ __forceinline__ int lane_pix(int r) {
+    if constexpr (!PERM) return r;
+    else if constexpr (Tile<H>::TW == 16) {        // rows of 16: second row takes columns 8-11 | 0-7 | 12-15
+        if (r < 16) return r;
+        const int j = r - 16;
+        return 16 + (j < 4 ? j + 8 : (j < 12 ? j - 4 : j));
+    } else if constexpr (Tile<H>::TW == 8) {       // rows of 8: group A gets rows 0 and 2, group B rows 1 and 3
+        return r < 4 ? r : (r < 12 ? r + 4 : (r < 16 ? r - 8 : (r < 20 ? r + 8 : (r < 28 ? r - 4 : r))));
+    } else return r;
+}
+
 // Store a 128-pixel x NT-channel tile held as NT/32 32x32 accumulators per wave (wave w = tile
 // rows [32w, 32w+32); element v of lane (li, lh) is row (v&3)+8*(v>>2)+4*lh, column li) to an
 // NHWC tensor, adding the bias (and ReLU), and — for the encoder convs — emit the per-tile,
 // per-channel BatchNorm partials (sum, M2 about the tile mean) that bn_fwd_finalize merges
 // (train-mode batch statistics of nn.BatchNorm2d, vae_nets.py:70,75,80,85).
 // `smem` is reused (a barrier precedes the first write) and must hold >= max(8*NT, 4*32*36) floats.
-template <int H, int NT, int NCH, int EPI, typename AT = float>      // AT: storage type of `out` (bf16 in precision mode 1)
+template <int H, int NT, int NCH, int EPI, typename AT = float, bool PERM = false>      // AT: storage type of `out`; PERM: lane_pix
 __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[NT / 32], const float* bias, float* out,
                                                float* bnpart, float* smem, int B, int mt, int n0,
                                                int img0, int ty0, int tx0, int numTiles = -1) {
@@ -44,7 +61,7 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[NT / 32], const flo
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { o[e] = (__bf16)lo[e]; o[4 + e] = (__bf16)hi[e]; }
-                const int mm = wave * 32 + px;
+                const int mm = wave * 32 + lane_pix<H, PERM>(px);
                 const int im = mm / (T::TH * T::TW), rem = mm % (T::TH * T::TW);
                 const int gy = ty0 + rem / T::TW, gx = tx0 + rem % T::TW, ib = img0 + im;
                 if (ib < B) Act<AT>::st8(out, ((size_t)(ib * H + gy) * H + gx) * NCH + n0 + nb * 32 + c8 * 8, o);
@@ -54,7 +71,7 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[NT / 32], const flo
         for (int it = 0; it < 4; ++it) {
             const int idx = it * 64 + lane, px = idx >> 3, c4 = idx & 7;
             const float4 val = *reinterpret_cast<const float4*>(patch + px * 36 + c4 * 4);
-            const int mm = wave * 32 + px;
+            const int mm = wave * 32 + lane_pix<H, PERM>(px);
             const int im = mm / (T::TH * T::TW), rem = mm % (T::TH * T::TW);
             const int gy = ty0 + rem / T::TW, gx = tx0 + rem % T::TW, ib = img0 + im;
             if (ib < B)

@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
         __syncthreads();
         const bf16x8* ap = lds_a + lh * PSP + aPix + (r + OFF) * T::HTW + OFF;
         const bf16x8* bp = lds_w + lh * NT + li;
+        if (NS == 1) __builtin_amdgcn_iglp_opt(0);         // interleave the LDS fragment reads with the MFMAs
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll

@@ -400,6 +400,105 @@ __global__ __launch_bounds__(256) void bgemm_tr_kernel(BGemmArgs a) {
         }
 }
 
+// fp32 mode: the same batch-contracted weight gradients on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: one A and one B
+// value per lane and k-step, read as conflict-free LDS rows — no transposition needed).  Replaces the serial VALU loops
+// over the batch (fc_bwd_dw_kernel) and the batch-split slabs + two slab reductions (decin_bwd_dw_kernel).
+// A_PAD: A is [b][a_cols] fp32 with an implicit ones column at a_cols (decoder_input); else A is [b][lda] and the
+// workgroup takes columns m0..m0+MC.
+template <int MBLK, int NBLK, bool A_PAD>
+__global__ __launch_bounds__(256) void bgemm_f32_kernel(BGemmArgs a) {
+    constexpr int MC = 32 * MBLK, NC = 32 * NBLK;
+    __shared__ __attribute__((aligned(16))) float lds_a[64 * MC];
+    __shared__ __attribute__((aligned(16))) float lds_b[64 * NC];
+    __shared__ float red[3 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int m0 = A_PAD ? 0 : blockIdx.x * MC, n0 = (A_PAD ? blockIdx.x : 0) * NC;
+    f32x16 acc[MBLK][NBLK];
+#pragma unroll
+    for (int i = 0; i < MBLK; ++i)
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    constexpr int AU = A_PAD ? (64 * MC) / 256 : (64 * MC / 4) / 256, BU = (64 * NC / 4) / 256;
+    float ra1[A_PAD ? AU : 1];
+    f32x4 ra4[A_PAD ? 1 : AU], rb4[BU];
+    auto fetch = [&](int b0) {
+        if constexpr (A_PAD) {
+#pragma unroll
+            for (int i = 0; i < AU; ++i) {
+                const int q = tid + i * 256, r = q / MC, c = q % MC, b = b0 + r;
+                const bool ok = b < a.B && c < a.a_cols;
+                const float l = a.A[ok ? (size_t)b * a.lda + c : 0];
+                ra1[i] = ok ? l : ((b < a.B && c == a.a_cols) ? 1.0f : 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < AU; ++i) {
+                const int q = tid + i * 256, r = q / (MC / 4), c4 = q % (MC / 4), b = b0 + r;
+                const bool ok = b < a.B;
+                const f32x4 l = *reinterpret_cast<const f32x4*>(a.A + (ok ? (size_t)b * a.lda + m0 + c4 * 4 : 0));
+                ra4[i] = ok ? l : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BU; ++i) {
+            const int q = tid + i * 256, r = q / (NC / 4), c4 = q % (NC / 4), b = b0 + r;
+            const bool ok = b < a.B;
+            const f32x4 l = *reinterpret_cast<const f32x4*>(a.Bm + (ok ? (size_t)b * a.ldb + n0 + c4 * 4 : 0));
+            rb4[i] = ok ? l : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    fetch(0);
+    for (int b0 = 0; b0 < a.B; b0 += 64) {
+        __syncthreads();
+        if constexpr (A_PAD) {
+#pragma unroll
+            for (int i = 0; i < AU; ++i) lds_a[tid + i * 256] = ra1[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < AU; ++i) *reinterpret_cast<f32x4*>(lds_a + (size_t)(tid + i * 256) * 4) = ra4[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BU; ++i) *reinterpret_cast<f32x4*>(lds_b + (size_t)(tid + i * 256) * 4) = rb4[i];
+        __syncthreads();
+        if (b0 + 64 < a.B) fetch(b0 + 64);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {                       // this wave's 16 images of the tile, two per MFMA
+            const int row = 16 * wave + 2 * kk + lh;
+            float bv[NBLK];
+#pragma unroll
+            for (int j = 0; j < NBLK; ++j) bv[j] = lds_b[row * NC + j * 32 + li];
+#pragma unroll
+            for (int i = 0; i < MBLK; ++i) {
+                const float av = lds_a[row * MC + i * 32 + li];
+#pragma unroll
+                for (int j = 0; j < NBLK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MBLK; ++i)
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) {
+            __syncthreads();
+            if (wave > 0) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) red[((wave - 1) * 16 + v) * 64 + lane] = acc[i][j][v];
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float x = ((acc[i][j][v] + red[v * 64 + lane]) + red[(16 + v) * 64 + lane]) + red[(32 + v) * 64 + lane];
+                    const int m = m0 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh, n = n0 + j * 32 + li;
+                    if (m < a.out_rows) a.out[(size_t)m * a.ldo + n] = x;
+                    else if (m == a.out_rows && a.out_last) a.out_last[n] = x;
+                }
+            }
+        }
+}
+
 static inline int bott(int width) { return 256 * (width / 16) * (width / 16); }
 static inline int decin_splits(int B) { int s = cdiv(B, 16); return s > 16 ? 16 : s; }
 
@@ -444,6 +543,12 @@ int launch_decin_bwd(int width, int B, const float* zcat, const float* dh, const
         CVAE_CHECK_LAUNCH();
         return 0;
     }
+    {                    // fp32: [zcat | 1]^T . dh on the fp32 MFMA, whole batch per workgroup
+        BGemmArgs g{zcat, dh, 33, K, 33, dwd, K, 33, dbd, B};
+        hipLaunchKernelGGL((bgemm_f32_kernel<2, 1, true>), dim3(K / 32), dim3(256), 0, st, g);
+        CVAE_CHECK_LAUNCH();
+        return 0;
+    }
     const int S = decin_splits(B), bps = cdiv(B, S);
     hipLaunchKernelGGL(decin_bwd_dw_kernel<float>, dim3(K / 256, S), dim3(256), 0, st, zcat, dh, ws, B, K, bps);
     CVAE_CHECK_LAUNCH();
@@ -469,7 +574,10 @@ int launch_fc_bwd(int width, int B, const float* flat, const float* wfc, const f
     if (bf16io) {        // flat^T . dml on the bf16 MFMA
         BGemmArgs g{flat, dml, K, 64, 0, dwfc, 64, K, nullptr, B};
         hipLaunchKernelGGL((bgemm_tr_kernel<1, 2, false, true>), dim3(K / 32), dim3(256), 0, st, g);
-    } else hipLaunchKernelGGL(fc_bwd_dw_kernel<float>, dim3(K / 16), dim3(256), 0, st, flat, dml, dwfc, B, K);
+    } else {             // fp32: flat^T . dml on the fp32 MFMA
+        BGemmArgs g{flat, dml, K, 64, 0, dwfc, 64, K, nullptr, B};
+        hipLaunchKernelGGL((bgemm_f32_kernel<1, 2, false>), dim3(K / 32), dim3(256), 0, st, g);
+    }
     CVAE_CHECK_LAUNCH();
     return 0;
 }

@@ -126,16 +126,24 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     // weight slab of stage (cc, r): units [s][kb][half][n] <- wp[(r*5+s)][cc*KB + kb][half][n0 + n]
     constexpr int WPT = (W_UNITS + 255) / 256;
     bf16x8 wreg[NS * WPT];
+    // per-thread part of every staging address is fixed for the whole launch: computed once, so a stage adds one
+    // wave-uniform term per load instead of redoing the div/mod chains (they were ~3 VALU instructions per MFMA)
+    int wbase[WPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int q = tid + i * 256;
+        const int n = q % NT, row = q / NT, half = row & 1, kb = (row >> 1) % KB, s = row / (2 * KB);
+        wbase[i] = ((s * (KCH / 16) + kb) * 2 + half) * NCH + n0 + n;
+    }
     auto load_w = [&](int st) {
         const int cc = st / KS, r = st % KS;
+        const bf16x8* wst = a.wp + (size_t)(r * KS * (KCH / 16) + cc * KB) * 2 * NCH;
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int q = tid + i * 256;
             if (W_UNITS % 256 == 0 || q < W_UNITS) {
-                const int n = q % NT, row = q / NT, half = row & 1, kb = (row >> 1) % KB, s = row / (2 * KB);
-                const size_t u = ((size_t)((r * KS + s) * (KCH / 16) + cc * KB + kb) * 2 + half) * NCH + n0 + n;
 #pragma unroll
-                for (int sp = 0; sp < NS; ++sp) wreg[sp * WPT + i] = a.wp[u + sp * a.splitStride];
+                for (int sp = 0; sp < NS; ++sp) wreg[sp * WPT + i] = wst[wbase[i] + sp * a.splitStride];
             }
         }
     };
@@ -154,24 +162,41 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     constexpr int NQ = T::HP * OCT, IPT = (NQ + 255) / 256;
     f32x4 ireg[NS == 1 ? 1 : 2 * IPT];
     bf16x8 breg[NS == 1 ? MT * IPT : 1];
+    // element index of each staged unit's first channel at chunk 0 (-1: zero padding / past the batch / no unit)
+    int ebase[MODE == MODE_UP_DGRAD ? 1 : MT * IPT];
+    if constexpr (MODE != MODE_UP_DGRAD) {
+#pragma unroll
+        for (int tl = 0; tl < MT; ++tl)
+#pragma unroll
+            for (int i = 0; i < IPT; ++i) {
+                const int q = tid + i * 256;
+                const int oct = q % OCT, hp = q / OCT;
+                const int img = hp / T::HPI, rem = hp - img * T::HPI;
+                const int gy = ty0v[tl] + rem / T::HTW - 2, gx = tx0v[tl] + rem % T::HTW - 2, ib = img0v[tl] + img;
+                const bool ok = (NQ % 256 == 0 || q < NQ) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B;
+                ebase[tl * IPT + i] = ok ? ((ib * H + gy) * H + gx) * KCH + oct * 8 : -1;
+            }
+    }
     auto load_input = [&](int cc) {
 #pragma unroll
       for (int tl = 0; tl < MT; ++tl)
 #pragma unroll
         for (int i = 0; i < IPT; ++i) {
-            const int q = tid + i * 256;
-            const int oct = q % OCT, hp = q / OCT;
-            const int img = hp / T::HPI, rem = hp - img * T::HPI;
-            const int gy = ty0v[tl] + rem / T::HTW - 2, gx = tx0v[tl] + rem % T::HTW - 2, ib = img0v[tl] + img;
-            const bool ok = (NQ % 256 == 0 || q < NQ) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B;
+            bool ok;
             size_t e = 0;                           // element index of the unit's first channel
-            if (ok) {
-                if (MODE == MODE_UP_DGRAD) {        // channel k = p*COUT + co of the low-res view = dout[2y+py][2x+px][co]
+            if constexpr (MODE == MODE_UP_DGRAD) {
+                const int q = tid + i * 256;
+                const int oct = q % OCT, hp = q / OCT;
+                const int img = hp / T::HPI, rem = hp - img * T::HPI;
+                const int gy = ty0v[tl] + rem / T::HTW - 2, gx = tx0v[tl] + rem % T::HTW - 2, ib = img0v[tl] + img;
+                ok = (NQ % 256 == 0 || q < NQ) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B;
+                if (ok) {                           // channel k = p*COUT + co of the low-res view = dout[2y+py][2x+px][co]
                     const int k0 = cc * KCB + oct * 8, p = k0 / COUT_UP, co = k0 % COUT_UP;
                     e = ((size_t)(ib * 2 * H + 2 * gy + (p >> 1)) * (2 * H) + 2 * gx + (p & 1)) * COUT_UP + co;
-                } else {
-                    e = ((size_t)(ib * H + gy) * H + gx) * KCH + cc * KCB + oct * 8;
                 }
+            } else {
+                ok = ebase[tl * IPT + i] >= 0;
+                e = ok ? (size_t)(ebase[tl * IPT + i] + cc * KCB) : 0;
             }
             if constexpr (NS == 1) {
                 bf16x8 z;

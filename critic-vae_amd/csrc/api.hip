@@ -64,6 +64,7 @@ struct cvae_handle_s {
     hipStream_t side = nullptr;
     hipEvent_t ev_ready[8] = {}, ev_side = nullptr, ev_red = nullptr, ev_red_done = nullptr;
     bool streams_ready = false;
+    bool fuse_e1 = true;             // block 0's BatchNorm backward applied inside E1's weight-gradient kernel (CVAE_FUSE_E1=0: separate apply pass, for A/B runs)
     bool side_reduce = false;        // weight-gradient slab reductions on the side stream: measured -2.8 % (fp32, B=256) and
                                      // -1.6 % (bf16, B=2048) against in-order launches, so OFF; CVAE_SIDE_REDUCE=1 enables it for A/B runs
     ProbeState probe;
@@ -156,6 +157,7 @@ int cvae_create(const cvae_config* cfg, cvae_handle* out) {
     cvae_handle_s* h = new cvae_handle_s();
     h->cfg = *cfg;
     { const char* e = getenv("CVAE_SIDE_REDUCE"); h->side_reduce = e && e[0] == '1'; }
+    { const char* e = getenv("CVAE_FUSE_E1"); h->fuse_e1 = !(e && e[0] == '0'); }
     h->param_total = 0;
     h->K = 256 * (cfg->width / 16) * (cfg->width / 16);
     char nm[64];
@@ -438,13 +440,17 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
     // encoder
     for (int l = 3; l >= 0; --l) {
         if (!(phase_mask & (l == 3 ? 2 : 4))) continue;
+        // block 0: only the statistics pass runs here; E1's weight-gradient kernel applies the BatchNorm/pool/ReLU
+        // backward while it stages its tiles (d_y[0] is never written: nothing else would read it)
+        const bool fuse0 = l == 0 && h->fuse_e1;
         { ProbeArm pa(h, 3, l);
           RC(launch_bn_pool_act_bwd(l, W, B, ws + w.y[l], ws + w.a[l], ws + w.d_a[l], ws + w.coef[l], P_(h->enc_g[l]),
-                                    ws + w.d_y[l], G_(h->enc_g[l]), G_(h->enc_be[l]), nullptr, sc, st, io_bf16(h))); }
+                                    fuse0 ? nullptr : ws + w.d_y[l], G_(h->enc_g[l]), G_(h->enc_be[l]), nullptr, sc, st, io_bf16(h))); }
         RC(fork(7 - l));
         if (l == 0) {
+            const float* fu[5] = {ws + w.y[0], ws + w.a[0], ws + w.d_a[0], ws + w.coef[0], bn_bwd_bcoef(0, W, B, sc)};
             { RedArm ra(h, side_red, &red_pending, st); ra.arm(&sred);
-              RC(launch_e1_wgrad(W, B, x, ws + w.d_y[0], G_(h->enc_w[0]), G_(h->enc_b[0]), scw, sd, h->cfg.precision == 1)); }
+              RC(launch_e1_wgrad(W, B, x, ws + w.d_y[0], G_(h->enc_w[0]), G_(h->enc_b[0]), scw, sd, h->cfg.precision == 1, fuse0 ? fu : nullptr)); }
         } else {
             { ProbeArm pa(h, 2, l); RedArm ra(h, side_red, &red_pending, st); ra.arm(&sred);
               if (use_bf16_wgrad(h, l)) RC(launch_conv_wgrad_bf16(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd));
@@ -577,14 +583,14 @@ int cvae_op_bn_pool_act_fwd(cvae_handle h, int32_t layer, int32_t B, const float
                             float* a, void* scratch, int32_t train, void* stream) {
     const int W = h->cfg.width;
     RC(launch_bn_fwd_finalize(layer, W, B, bn_partials, gamma, beta, run_mean, run_var, coef, (float*)scratch, train, (hipStream_t)stream));
-    return launch_bn_pool_act_fwd(layer, W, B, y, coef, a, (hipStream_t)stream);
+    return launch_bn_pool_act_fwd(layer, W, B, y, coef, a, (hipStream_t)stream, io_bf16(h));     // y, a in the handle's storage type
 }
 
 int cvae_op_bn_pool_act_bwd(cvae_handle h, int32_t layer, int32_t B, const float* y, const float* a, const float* da,
                             const float* coef, const float* gamma, float* dy, float* dgamma, float* dbeta, float* dbias,
                             void* scratch, void* stream) {
     return launch_bn_pool_act_bwd(layer, h->cfg.width, B, y, a, da, coef, gamma, dy, dgamma, dbeta, dbias,
-                                  (float*)scratch, (hipStream_t)stream);
+                                  (float*)scratch, (hipStream_t)stream, io_bf16(h));                 // y, a, da, dy in the handle's storage type
 }
 
 int64_t cvae_op_bn_partial_floats(cvae_handle h, int32_t layer, int32_t B) {

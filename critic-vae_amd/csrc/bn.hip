@@ -501,6 +501,13 @@ int64_t bn_bwd_ws_floats(int layer, int width, int B) {
     return (int64_t)bn_bwd_blocks(totalPx, g.C) * 2 * g.C + 4 * g.C + col_reduce_ws_floats(2 * g.C);
 }
 
+const float* bn_bwd_bcoef(int layer, int width, int B, const float* ws) {
+    const BnGeom g = bn_geom(layer, width);
+    return ws + (size_t)bn_bwd_blocks((int64_t)B * (g.H / 2) * (g.H / 2), g.C) * 2 * g.C;
+}
+
+// dy == nullptr: statistics only (dgamma, dbeta and the (k1, k2) pair at bn_bwd_bcoef(ws)); the caller's next kernel
+// applies the backward itself (block 0: launch_e1_wgrad's fused staging).
 int launch_bn_pool_act_bwd(int layer, int width, int B, const float* y, const float* a, const float* da,
                            const float* coef, const float* gamma, float* dy, float* dgamma, float* dbeta,
                            float* dbias, float* ws, hipStream_t st, bool bf16io) {
@@ -523,6 +530,10 @@ int launch_bn_pool_act_bwd(int layer, int width, int B, const float* y, const fl
     { int rc = launch_col_reduce_partial(part, nblk, 2 * g.C, 2 * g.C, crws, st, &rows, &R, &rstride); if (rc) return rc; }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(g.C, 16)), dim3(256), 0, st, rows, R, rstride, g.C, invN, dgamma, dbeta, bcoef);
     CVAE_CHECK_LAUNCH();
+    if (!dy) {
+        if (dbias) { cvae_set_error("bn_bwd: dbias needs the apply pass (dy)"); return -2; }
+        return 0;
+    }
     cvae_probe_begin(st);                       // the apply pass: reads y, a, da, writes dy — the step's largest HBM-bound kernel
     if (bf16io && g.act) hipLaunchKernelGGL((bn_bwd_bf16_kernel<1, 1>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, bcoef, dy, part, g.C, g.H, totalPx, ppb);
     else if (bf16io) hipLaunchKernelGGL((bn_bwd_bf16_kernel<0, 1>), dim3(nblk), dim3(256), 0, st, y, a, da, coef, bcoef, dy, part, g.C, g.H, totalPx, ppb);

@@ -35,6 +35,7 @@ template <> struct Act<__bf16> {
         o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
         *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p) + i) = o;
     }
+    static __device__ __forceinline__ bf16x4 ld4raw(const float* p, size_t i) { return *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p) + i); }
     // 8 consecutive elements = one 16-byte unit
     static __device__ __forceinline__ bf16x8 ld8(const float* p, size_t i) { return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p) + i); }
     static __device__ __forceinline__ void st8(float* p, size_t i, bf16x8 v) { *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p) + i) = v; }
@@ -199,7 +200,8 @@ int launch_col_reduce(const float* in, int R, int W, int64_t stride, float* out,
 int launch_e1_fwd(int width, int B, const float* x, const float* w, const float* bias, float* y,
                   float* bnpart, hipStream_t st, bool bf16 = false);
 int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw, float* dbias, float* ws,
-                    hipStream_t st, bool bf16 = false);
+                    hipStream_t st, bool bf16 = false, const float* const* fuse = nullptr);   // fuse: {y0, a0, d_a0, coef0, bcoef0}, dy unused
+const float* bn_bwd_bcoef(int layer, int width, int B, const float* ws);                       // where launch_bn_pool_act_bwd left (k1, k2)
 int64_t e1_wgrad_ws_floats(int width, int B);
 int launch_d4_fwd(int width, int B, const float* in, const float* w, const float* bias, float* recon,
                   hipStream_t st, bool bf16io = false);

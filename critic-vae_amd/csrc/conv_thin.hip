@@ -261,10 +261,18 @@ __device__ __forceinline__ void thin_slab_out(f32x16 (&acc)[3], float* red, floa
     }
 }
 
+// FUSE: the weight-gradient kernels take E1's BatchNorm/MaxPool/ReLU backward in while they stage a tile, instead of
+// reading a dy tensor that bn.hip's apply pass wrote (nothing else reads dy of block 0 — E1 has no input gradient):
+// per 2x2 window and channel, dy[p] = scale*((p == argmax ? g : 0) - k1 - xhat[p]*k2) with g = da*[a > 0],
+// xhat = (y - mean)*invstd and (k1, k2) = bcoef — the arithmetic of bn_bwd_kernel<0,1>, so the result is the
+// same to the bit; the step saves one write and one read of the largest activation gradient (B x 64 x 64 x 32).
+struct E1Fuse { const float *y, *a, *da, *coef, *bcoef; };
+
 // tile mt of E1 wgrad into registers: x halo (3 planes, zero padded) and the 128x32 dy tile
-template <int H>
-__device__ __forceinline__ void e1_wgrad_fetch(const ThinWgradArgs& a, int mt, float (&rx)[(3 * Tile<H>::HPI + 255) / 256],
-                                               f32x4 (&rd)[4]) {
+// (FUSE: thread = (channel quad, window column, window row): the window's four y quads in rd, a and da quads in rf)
+template <int H, bool FUSE>
+__device__ __forceinline__ void e1_wgrad_fetch(const ThinWgradArgs& a, const E1Fuse& fu, int mt, float (&rx)[(3 * Tile<H>::HPI + 255) / 256],
+                                               f32x4 (&rd)[4], f32x4 (&rf)[2]) {
     using T = Tile<H>;
     const int tid = threadIdx.x;
     const int ib = mt / T::TILES_PER_IMG, tileInImg = mt % T::TILES_PER_IMG;
@@ -278,18 +286,29 @@ __device__ __forceinline__ void e1_wgrad_fetch(const ThinWgradArgs& a, int mt, f
         const float l = a.a0[ok ? ((size_t)(ib * 3 + c) * H + gy) * H + gx : 0];      // no branch around the load
         rx[i] = ok ? l : 0.f;
     }
+    if constexpr (FUSE) {
+        const int c4 = tid & 7, gy = ty0 + 2 * (tid >> 7), gx = tx0 + 2 * ((tid >> 3) & 15);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = tid + i * 256, c4 = q & 7, mm = q >> 3;
-        const int gy = ty0 + mm / T::TW, gx = tx0 + mm % T::TW;
-        rd[i] = *reinterpret_cast<const f32x4*>(a.a1 + ((size_t)(ib * H + gy) * H + gx) * 32 + c4 * 4);
+        for (int p = 0; p < 4; ++p)
+            rd[p] = *reinterpret_cast<const f32x4*>(fu.y + ((size_t)(ib * H + gy + (p >> 1)) * H + gx + (p & 1)) * 32 + c4 * 4);
+        const size_t pe = ((size_t)(ib * (H / 2) + gy / 2) * (H / 2) + gx / 2) * 32 + c4 * 4;
+        rf[0] = *reinterpret_cast<const f32x4*>(fu.a + pe);
+        rf[1] = *reinterpret_cast<const f32x4*>(fu.da + pe);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + i * 256, c4 = q & 7, mm = q >> 3;
+            const int gy = ty0 + mm / T::TW, gx = tx0 + mm % T::TW;
+            rd[i] = *reinterpret_cast<const f32x4*>(a.a1 + ((size_t)(ib * H + gy) * H + gx) * 32 + c4 * 4);
+        }
     }
 }
 
 // (precision mode 1 runs e1_wgrad_bf16_kernel below instead.)
-template <int H>
-__global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
+template <int H, bool FUSE>
+__global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a, E1Fuse fu) {
     using T = Tile<H>;
+    static_assert(!FUSE || (T::TW == 32 && T::TH == 4 && T::IMGS == 1), "fused staging: 2 x 16 windows per tile");
     constexpr int X_FLOATS = ((3 * T::PS + 3) / 4) * 4;
     constexpr int RED = 3 * 3 * 1024;
     constexpr int SM = (X_FLOATS + 128 * 32) > RED ? (X_FLOATS + 128 * 32) : RED;
@@ -315,8 +334,17 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
     // MFMAs of the current tile run; LDS is refilled between two barriers
     constexpr int XQ = (3 * T::HPI + 255) / 256;
     float rx[XQ];
-    f32x4 rd[4];
-    if (t0 < t1) e1_wgrad_fetch<H>(a, t0, rx, rd);
+    f32x4 rd[4], rf[2];
+    float bsc[4], bsh[4], bmean[4], binv[4], bk1[4], bk2[4];          // FUSE: this thread's four channels
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (tid & 7) * 4 + e;
+            bsc[e] = fu.coef[c * 4]; bsh[e] = fu.coef[c * 4 + 1]; bmean[e] = fu.coef[c * 4 + 2]; binv[e] = fu.coef[c * 4 + 3];
+            bk1[e] = fu.bcoef[c * 2]; bk2[e] = fu.bcoef[c * 2 + 1];
+        }
+    }
+    if (t0 < t1) e1_wgrad_fetch<H, FUSE>(a, fu, t0, rx, rd, rf);
     for (int mt = t0; mt < t1; ++mt) {
         __syncthreads();
 #pragma unroll
@@ -324,13 +352,37 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
             const int q = tid + i * 256;
             if (q < 3 * T::HPI) lds_x[(q / T::HPI) * T::PS + q % T::HPI] = rx[i];
         }
+        if constexpr (FUSE) {
+            f32x4 d[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = tid + i * 256;
-            *reinterpret_cast<f32x4*>(lds_d + (q >> 3) * 32 + (q & 7) * 4) = rd[i];
+            for (int e = 0; e < 4; ++e) {
+                float m = 0.f; int pos = 0;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {                           // first maximum in scan order, like the forward
+                    const float n = fmaf(rd[p][e], bsc[e], bsh[e]);
+                    if (p == 0 || n > m) { m = n; pos = p; }
+                }
+                const float g = rf[0][e] > 0.f ? rf[1][e] : 0.f;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float xhat = (rd[p][e] - bmean[e]) * binv[e];
+                    d[p][e] = bsc[e] * ((p == pos ? g : 0.f) - bk1[e] - xhat * bk2[e]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int mm = (2 * (tid >> 7) + (p >> 1)) * 32 + 2 * ((tid >> 3) & 15) + (p & 1);
+                *reinterpret_cast<f32x4*>(lds_d + mm * 32 + (tid & 7) * 4) = d[p];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = tid + i * 256;
+                *reinterpret_cast<f32x4*>(lds_d + (q >> 3) * 32 + (q & 7) * 4) = rd[i];
+            }
         }
         __syncthreads();
-        if (mt + 1 < t1) e1_wgrad_fetch<H>(a, mt + 1, rx, rd);
+        if (mt + 1 < t1) e1_wgrad_fetch<H, FUSE>(a, fu, mt + 1, rx, rd, rf);
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const int mm = wave * 32 + 2 * kk + lh;
@@ -358,8 +410,11 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a) {
 // Wave w owns tile row w (32 pixels, 2 k-steps): 10 MFMAs + 2 for the bias row (ones x dy) per tile.
 // Slab row of a workgroup: [5 kernel rows][32 m][32 co] (m >= 20 and c == 3 are padding) | bias[32] = 5152 floats.
 static constexpr int E1W_ROW = 5 * 32 * 32 + 32;
-template <int H>
-__global__ __launch_bounds__(256) void e1_wgrad_bf16_kernel(ThinWgradArgs a) {
+// FUSE (see E1Fuse): thread = (channel quad, window column, window row); y / a / da arrive as 8-byte bf16 quads and
+// dy = (p == argmax ? g*scale : 0) - (A + Bc*y) with Bc = scale*k2*invstd, A = scale*k1 - Bc*mean — the apply pass's
+// formula with the per-channel constants folded (this kernel is issue-bound: ~7 VALU instructions per element).
+template <int H, bool FUSE>
+__global__ __launch_bounds__(256) void e1_wgrad_bf16_kernel(ThinWgradArgs a, E1Fuse fu) {
     using T = Tile<H>;
     static_assert(T::TW == 32 && T::TH == 4 && T::IMGS == 1, "one tile row per wave");
     constexpr int HWX = 40, HR_ = T::TH + 4, NPXH = HR_ * HWX;
@@ -382,6 +437,18 @@ __global__ __launch_bounds__(256) void e1_wgrad_bf16_kernel(ThinWgradArgs a) {
     constexpr int XQ = (NPXH + 255) / 256;
     float rx[XQ][3];
     bf16x8 rd[2];
+    bf16x4 ry[4], ra, rg;                            // FUSE: the window's y quads, a and da
+    float bsc[4], bsh[4], bA[4], bB[4];
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (tid & 7) * 4 + e;
+            const float sc = fu.coef[c * 4], mean = fu.coef[c * 4 + 2], invstd = fu.coef[c * 4 + 3];
+            bsc[e] = sc; bsh[e] = fu.coef[c * 4 + 1];
+            bB[e] = sc * fu.bcoef[c * 2 + 1] * invstd;
+            bA[e] = sc * fu.bcoef[c * 2] - bB[e] * mean;
+        }
+    }
     auto fetch = [&](int mt) {
         const int ib = mt / T::TILES_PER_IMG, tileInImg = mt % T::TILES_PER_IMG;
         const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;
@@ -394,11 +461,20 @@ __global__ __launch_bounds__(256) void e1_wgrad_bf16_kernel(ThinWgradArgs a) {
             const float v0 = a.a0[e], v1 = a.a0[e + (size_t)H * H], v2 = a.a0[e + 2 * (size_t)H * H];
             rx[i][0] = ok ? v0 : 0.f; rx[i][1] = ok ? v1 : 0.f; rx[i][2] = ok ? v2 : 0.f;
         }
+        if constexpr (FUSE) {
+            const int c4 = tid & 7, gy = ty0 + 2 * (tid >> 7), gx = tx0 + 2 * ((tid >> 3) & 15);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int q = tid + i * 256, c8 = q & 3, mm = q >> 2;
-            const int gy = ty0 + mm / T::TW, gx = tx0 + mm % T::TW;
-            rd[i] = Act<__bf16>::ld8(a.a1, ((size_t)(ib * H + gy) * H + gx) * 32 + c8 * 8);
+            for (int p = 0; p < 4; ++p) ry[p] = Act<__bf16>::ld4raw(fu.y, ((size_t)(ib * H + gy + (p >> 1)) * H + gx + (p & 1)) * 32 + c4 * 4);
+            const size_t pe = ((size_t)(ib * (H / 2) + gy / 2) * (H / 2) + gx / 2) * 32 + c4 * 4;
+            ra = Act<__bf16>::ld4raw(fu.a, pe);
+            rg = Act<__bf16>::ld4raw(fu.da, pe);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int q = tid + i * 256, c8 = q & 3, mm = q >> 2;
+                const int gy = ty0 + mm / T::TW, gx = tx0 + mm % T::TW;
+                rd[i] = Act<__bf16>::ld8(a.a1, ((size_t)(ib * H + gy) * H + gx) * 32 + c8 * 8);
+            }
         }
     };
     if (t0 < t1) fetch(t0);
@@ -410,8 +486,30 @@ __global__ __launch_bounds__(256) void e1_wgrad_bf16_kernel(ThinWgradArgs a) {
             const int q = tid + i * 256;
             if (q < NPXH) { bf16x4 u; u[0] = (__bf16)rx[i][0]; u[1] = (__bf16)rx[i][1]; u[2] = (__bf16)rx[i][2]; u[3] = (__bf16)0.f; lds_x[q] = u; }
         }
+        if constexpr (FUSE) {
+            bf16x4 d[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<bf16x8*>(lds_d + (size_t)(tid + i * 256) * 8) = rd[i];
+            for (int e = 0; e < 4; ++e) {
+                float yv[4], m = 0.f; int pos = 0;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {                           // first maximum in scan order, like the forward
+                    yv[p] = (float)ry[p][e];
+                    const float n = fmaf(yv[p], bsc[e], bsh[e]);
+                    if (p == 0 || n > m) { m = n; pos = p; }
+                }
+                const float gs = (float)ra[e] > 0.f ? (float)rg[e] * bsc[e] : 0.f;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) d[p][e] = (__bf16)((p == pos ? gs : 0.f) - fmaf(bB[e], yv[p], bA[e]));
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int mm = (2 * (tid >> 7) + (p >> 1)) * 32 + 2 * ((tid >> 3) & 15) + (p & 1);
+                *reinterpret_cast<bf16x4*>(lds_d + mm * 32 + (tid & 7) * 4) = d[p];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *reinterpret_cast<bf16x8*>(lds_d + (size_t)(tid + i * 256) * 8) = rd[i];
+        }
         __syncthreads();
         if (mt + 1 < t1) fetch(mt + 1);
 #pragma unroll
@@ -508,14 +606,19 @@ int launch_e1_fwd(int width, int B, const float* x, const float* w, const float*
     return 0;
 }
 
-int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw, float* dbias, float* ws, hipStream_t st, bool bf16) {
+int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw, float* dbias, float* ws, hipStream_t st, bool bf16,
+                    const float* const* fuse) {
     if (width != 64 && width != 128) { cvae_set_error("e1_wgrad: width %d unsupported", width); return -2; }
     int tps; const int tiles = B * (width / 4) * (width / 32);
     const int S = thin_splits(tiles, &tps);
     ThinWgradArgs a{x, dy, nullptr, nullptr, ws, B, tiles, tps};
+    // fuse = {y0, a0, d_a0, coef0, bcoef0}: block 0's BatchNorm/pool/ReLU backward is applied while staging (no dy tensor)
+    const E1Fuse fu = fuse ? E1Fuse{fuse[0], fuse[1], fuse[2], fuse[3], fuse[4]} : E1Fuse{};
     if (bf16) {          // precision mode 1: transposed-read kernel, its own slab layout + a permuting finish
-        if (width == 64) hipLaunchKernelGGL(e1_wgrad_bf16_kernel<64>, dim3(S), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(e1_wgrad_bf16_kernel<128>, dim3(S), dim3(256), 0, st, a);
+        if (width == 64 && fuse) hipLaunchKernelGGL((e1_wgrad_bf16_kernel<64, true>), dim3(S), dim3(256), 0, st, a, fu);
+        else if (width == 64) hipLaunchKernelGGL((e1_wgrad_bf16_kernel<64, false>), dim3(S), dim3(256), 0, st, a, fu);
+        else if (fuse) hipLaunchKernelGGL((e1_wgrad_bf16_kernel<128, true>), dim3(S), dim3(256), 0, st, a, fu);
+        else hipLaunchKernelGGL((e1_wgrad_bf16_kernel<128, false>), dim3(S), dim3(256), 0, st, a, fu);
         CVAE_CHECK_LAUNCH();
         st = cvae_reduce_stream(st);
         float* red = ws + (size_t)S * E1W_ROW;
@@ -524,8 +627,10 @@ int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw
         CVAE_CHECK_LAUNCH();
         return 0;
     }
-    if (width == 64) hipLaunchKernelGGL(e1_wgrad_kernel<64>, dim3(S), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(e1_wgrad_kernel<128>, dim3(S), dim3(256), 0, st, a);
+    if (width == 64 && fuse) hipLaunchKernelGGL((e1_wgrad_kernel<64, true>), dim3(S), dim3(256), 0, st, a, fu);
+    else if (width == 64) hipLaunchKernelGGL((e1_wgrad_kernel<64, false>), dim3(S), dim3(256), 0, st, a, fu);
+    else if (fuse) hipLaunchKernelGGL((e1_wgrad_kernel<128, true>), dim3(S), dim3(256), 0, st, a, fu);
+    else hipLaunchKernelGGL((e1_wgrad_kernel<128, false>), dim3(S), dim3(256), 0, st, a, fu);
     CVAE_CHECK_LAUNCH();
     st = cvae_reduce_stream(st);
     // slab row = [75 x 32 weights | 32 zeros (K pad) | 32 bias partials]: in the flat buffer enc0.b sits at

@@ -236,6 +236,8 @@ def test_bf16_kernels_exact_on_their_stored_operands():
     h.loss(B, x, tr.mu, tr.logvar, tr.recon, tr.ws, tr.scalars, tr.d_recon, tr.d_mu, tr.d_logvar)
     h.backward(B, x, pred, eps, theta, tr.logvar, tr.recon, tr.d_recon, tr.d_mu, tr.d_logvar, tr.ws, tr.grads)
     torch.cuda.synchronize()
+    from ws_tools import recompute_d_y0
+    recompute_d_y0(h, tr.ws, B, bf16_storage=True)     # block 0's dy exists only inside the fused E1 weight-gradient kernel
     ws16 = tr.ws.view(torch.bfloat16)
 
     def act(name, c, s):            # stored bf16 NHWC tensor -> fp32 NCHW on the CPU

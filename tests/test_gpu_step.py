@@ -90,9 +90,37 @@ def test_intermediates_against_oracle_taps():
     assert (view("h", 256, 4) - taps["dec_h"]).abs().max() < TOL
     for i, (c, s) in enumerate(dec):
         assert (view(f"o{i}", c, s) - taps[f"dec_o{i}"]).abs().max() < TOL, f"o{i}"
+    from ws_tools import recompute_d_y0
+    recompute_d_y0(h, ws, B)         # the step applies block 0's BatchNorm backward inside E1's weight-gradient kernel
     for l, (c, s) in enumerate(enc):
         g = taps[f"enc_y{l}"].grad
         assert (view(f"d_y{l}", c, s) - g).abs().max() <= TOL * max(1.0, 0) + 1e-4 * g.abs().max(), f"d_y{l}"
+
+
+@pytest.mark.parametrize("prec,width,rel", [("f32", 64, 1e-6), ("f32", 128, 1e-6), ("bf16", 64, 2e-2)])
+def test_fused_e1_backward_equals_the_separate_apply_pass(monkeypatch, prec, width, rel):
+    """Block 0's BatchNorm / pool / ReLU backward runs inside E1's weight-gradient kernel (E1Fuse, the default) or as
+    bn.hip's apply pass that writes d_y0 (CVAE_FUSE_E1=0).  fp32: the same arithmetic per element, so dW1 / db1 agree to
+    fp32 summation noise; bf16: the fused form folds the per-channel constants before the bf16 rounding of dy."""
+    from critic_vae_amd import layout as L
+    B = 8
+    x, pred, eps = (t.cuda() for t in _inputs(1234, 0, B, width=width))
+    grads = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("CVAE_FUSE_E1", fuse)
+        vae = VariationalAutoencoder(max_batch=B, seed=0, width=width, precision=prec).cuda()
+        vae.load_reference_params(synth.make_params(0, width))
+        tr = FusedTrainer(vae)
+        tr.step(x, pred, eps)
+        torch.cuda.synchronize()
+        grads[fuse] = {k: v.clone() for k, v in L.native_to_ref(vae.handle.layout, tr.grads.cpu()).items()}
+    for k in grads["1"]:
+        a, b = grads["1"][k], grads["0"][k]
+        if k.startswith("encoder.model.0."):
+            bound = rel * b.abs().max().item() + (1e-6 if k.endswith("bias") else 0.0)      # db1 cancels to ~0
+            assert (a - b).abs().max().item() <= bound, (k, (a - b).abs().max().item(), b.abs().max().item())
+        else:
+            assert torch.equal(a, b), k           # nothing else may change
 
 
 def test_step_b256_fp32_against_oracle():

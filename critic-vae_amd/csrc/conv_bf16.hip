@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
                 bf16x8 z;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) z[k] = (__bf16)0.f;
-                breg[tl * IPT + i] = ok ? Act<__bf16>::ld8(a.in, e) : z;
+                const bf16x8 ld = Act<__bf16>::ld8(a.in, e);          // e = 0 when !ok: the load itself is unconditional (no branch per unit)
+                breg[tl * IPT + i] = ok ? ld : z;
             } else {
                 f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
                 if (ok) { lo = *reinterpret_cast<const f32x4*>(a.in + e); hi = *reinterpret_cast<const f32x4*>(a.in + e + 4); }

@@ -27,7 +27,7 @@ CONV = {  # probe name -> kernel-name prefix
     "conv_dgrad_L5": "void conv_up_dgrad_kernel<128, 64, 4,", "conv_dgrad_L6": "void conv_up_dgrad_kernel<64, 32, 8,", "conv_dgrad_L7": "void conv_up_dgrad_kernel<32, 32, 16,",
     "conv_wgrad_L5": "void conv_up_wgrad_kernel<128, 64, 4>", "conv_wgrad_L6": "void conv_up_wgrad_kernel<64, 32, 8>", "conv_wgrad_L7": "void conv_up_wgrad_kernel<32, 32, 16>",
 }
-BN_RELU_APPLY = "void bn_bwd_kernel<0, 1>"      # launched for blocks 2, 1, 0 in that order every step
+BN_RELU_APPLY = "void bn_bwd_kernel<0, 1>"      # launched for blocks 2, 1 in that order every step (block 0: fused into E1's weight-gradient kernel)
 BN_TANH_APPLY = "void bn_bwd_kernel<1, 1>"      # block 3
 
 
@@ -54,8 +54,8 @@ for name, prefix in CONV.items():
     if f and w:
         out[name] = round(2 * sum(f) / len(f) + sum(w) / len(w))
 f, w = pick(fetch, BN_RELU_APPLY), pick(write, BN_RELU_APPLY)
-for i, layer in enumerate((2, 1, 0)):
-    fi, wi = f[i::3], w[i::3]
+for i, layer in enumerate((2, 1)):
+    fi, wi = f[i::2], w[i::2]
     if fi and wi:
         out[f"bn_pool_bwd_apply_L{layer}"] = round(2 * sum(fi) / len(fi) + sum(wi) / len(wi))
 f, w = pick(fetch, BN_TANH_APPLY), pick(write, BN_TANH_APPLY)

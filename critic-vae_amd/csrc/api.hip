@@ -64,6 +64,7 @@ struct cvae_handle_s {
     hipStream_t side = nullptr;
     hipEvent_t ev_ready[8] = {}, ev_side = nullptr, ev_red = nullptr, ev_red_done = nullptr;
     bool streams_ready = false;
+    bool e1_two_pass = false;        // bf16 mode: E1 forward as statistics pass + fused BatchNorm/pool pass (CVAE_E1_TWO_PASS=0: conv, then bn_pool_act_fwd)
     bool fuse_e1 = true;             // block 0's BatchNorm backward applied inside E1's weight-gradient kernel (CVAE_FUSE_E1=0: separate apply pass, for A/B runs)
     bool side_reduce = false;        // weight-gradient slab reductions on the side stream: measured -2.8 % (fp32, B=256) and
                                      // -1.6 % (bf16, B=2048) against in-order launches, so OFF; CVAE_SIDE_REDUCE=1 enables it for A/B runs
@@ -158,6 +159,7 @@ int cvae_create(const cvae_config* cfg, cvae_handle* out) {
     h->cfg = *cfg;
     { const char* e = getenv("CVAE_SIDE_REDUCE"); h->side_reduce = e && e[0] == '1'; }
     { const char* e = getenv("CVAE_FUSE_E1"); h->fuse_e1 = !(e && e[0] == '0'); }
+    { const char* e = getenv("CVAE_E1_TWO_PASS"); h->e1_two_pass = cfg->precision == 1 && !(e && e[0] == '0'); }
     h->param_total = 0;
     h->K = 256 * (cfg->width / 16) * (cfg->width / 16);
     char nm[64];
@@ -265,6 +267,15 @@ int cvae_forward(cvae_handle h, int32_t B, const float* x, const float* pred, co
     const int W = h->cfg.width;
     RC(pack_bf16_weights(h, params, ws, w, st));
     for (int l = 0; l < 4; ++l) {
+        if (l == 0 && h->e1_two_pass) {
+            // bf16 mode, block 0: conv (statistics only) -> merged statistics -> conv again with BatchNorm/pool/ReLU in its
+            // epilogue (writes y0 for the backward and a0); bn_pool_act_fwd's read of y0 is replaced by a second read of x
+            if (train) RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), nullptr, ws + w.bnpart[0], st, true, 1));
+            RC(launch_bn_fwd_finalize(0, W, B, ws + w.bnpart[0], P_(h->enc_g[0]), P_(h->enc_be[0]), bn_state + kBnOff[0],
+                                      bn_state + 480 + kBnOff[0], ws + w.coef[0], ws + w.scratch, train, st));
+            RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], nullptr, st, true, 2, ws + w.coef[0], ws + w.a[0]));
+            continue;
+        }
         if (l == 0) RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], ws + w.bnpart[0], st, h->cfg.precision == 1));
         else if (use_bf16(h, l)) { ProbeArm pa(h, 0, l); RC(launch_conv_fwd_bf16(l, W, bf16_mode(h), B, ws + w.a[l - 1], ws + w.wpack, P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st)); }
         else { ProbeArm pa(h, 0, l); RC(launch_conv_fwd(l, W, B, ws + w.a[l - 1], P_(h->enc_w[l]), P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st)); }

@@ -198,7 +198,8 @@ int launch_col_reduce_partial(const float* in, int R, int W, int64_t stride, flo
 int launch_col_reduce(const float* in, int R, int W, int64_t stride, float* out, float* ws, hipStream_t st);
 // conv_thin.hip (E1 / D4)
 int launch_e1_fwd(int width, int B, const float* x, const float* w, const float* bias, float* y,
-                  float* bnpart, hipStream_t st, bool bf16 = false);
+                  float* bnpart, hipStream_t st, bool bf16 = false, int pass = 0, const float* coef = nullptr, float* a1 = nullptr);
+                  // bf16 mode: pass 1 = BatchNorm partials only, pass 2 = y + fused BatchNorm/pool/ReLU -> a1 (needs coef)
 int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw, float* dbias, float* ws,
                     hipStream_t st, bool bf16 = false, const float* const* fuse = nullptr);   // fuse: {y0, a0, d_a0, coef0, bcoef0}, dy unused
 const float* bn_bwd_bcoef(int layer, int width, int B, const float* ws);                       // where launch_bn_pool_act_bwd left (k1, k2)

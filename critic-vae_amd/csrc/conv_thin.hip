@@ -117,18 +117,28 @@ __global__ __launch_bounds__(256) void e1_fwd_kernel(const float* __restrict__ x
 // fragment (8 consecutive k of one pixel) is two 8-byte LDS reads instead of 8 scalar reads + 8 conversions.
 // K per kernel row = 20 padded to 32 (zero weights): 10 MFMAs per 32 pixels, 40 weight registers per lane.
 // y1 leaves as bf16 (16-byte units), the BatchNorm partials come from the fp32 accumulators.
-template <int H>
+// PASS (the bf16 training step runs the kernel TWICE instead of reading y1 back — the 75-tap conv is ~1 % of the
+// step's MFMA work, the tensor it produces is the step's largest):
+//   E1_Y     : y1 + BatchNorm partials (the stand-alone conv op).
+//   E1_STATS : BatchNorm partials only — nothing but x is read, 2 x 32 floats per strip are written.
+//   E1_POOL  : after the statistics are merged: y1 again (the backward still reads it), and on the bf16-rounded values,
+//              exactly as bn_pool_act_fwd_bf16_kernel<0> would compute from the stored tensor, scale/shift -> first
+//              maximum of each 2x2 window in scan order -> ReLU -> a1.  Replaces that kernel's read of y1
+//              (B*H*H*32*2 bytes) by a second read of x (B*H*H*3*4 bytes).
+enum { E1_Y = 0, E1_STATS = 1, E1_POOL = 2 };
+template <int H, int PASS>
 __global__ __launch_bounds__(256) void e1_fwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
-                                                          float* __restrict__ bnpart, int B) {
+                                                          float* __restrict__ bnpart, int B,
+                                                          const float* __restrict__ coef, float* __restrict__ a1, int numStrips) {
     constexpr int SR = 16, SW = 32, HR_ = SR + 4, HWX = 40;
     constexpr int SX = H / SW, SY = H / SR;
     __shared__ __attribute__((aligned(16))) bf16x4 lds_x[HR_ * HWX];
     __shared__ __attribute__((aligned(16))) float patch_all[4 * 32 * 36];
     __shared__ float red[2][4][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int ib = blockIdx.x / (SX * SY), t = blockIdx.x % (SX * SY);
-    const int ty0 = (t / SX) * SR, tx0 = (t % SX) * SW;
+    // persistent: the 80 weights of this lane are fetched and converted ONCE per workgroup (one workgroup per strip spent
+    // more instructions on them than on the strip), and the next strip's frame values travel during this strip's MFMAs
     bf16x8 bw[5][2];                    // B[k = 16kb + 8lh + j][n = li] of kernel row r: k = 4*s + c
 #pragma unroll
     for (int r = 0; r < 5; ++r)
@@ -139,82 +149,122 @@ __global__ __launch_bounds__(256) void e1_fwd_bf16_kernel(const float* __restric
                 const int k = 16 * kb + 8 * lh + j, sI = k >> 2, c = k & 3;
                 bw[r][kb][j] = (__bf16)((sI < 5 && c < 3) ? w[((r * 5 + sI) * 3 + c) * 32 + li] : 0.f);
             }
-    {
-        constexpr int NIT = (HR_ * HWX + 255) / 256;
-        float v0[NIT], v1[NIT], v2[NIT];
+    const float bv = bias[li];
+    constexpr int NIT = (HR_ * HWX + 255) / 256;
+    float v0[NIT], v1[NIT], v2[NIT];
+    auto fetch = [&](int strip) {                // all loads first (clamped address + select), the LDS writes follow later
+        const int ib = strip / (SX * SY), t = strip % (SX * SY);
+        const int ty0 = (t / SX) * SR, tx0 = (t % SX) * SW;
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {          // all loads first (clamped address + select), then the LDS writes
+        for (int i = 0; i < NIT; ++i) {
             const int q = tid + i * 256, hy = q / HWX, hx = q % HWX;
             const int gy = ty0 + hy - 2, gx = tx0 + hx - 2;
             const bool ok = q < HR_ * HWX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H;
             const size_t e = ok ? ((size_t)(ib * 3) * H + gy) * H + gx : 0;
-            const float a0 = x[e], a1 = x[e + (size_t)H * H], a2 = x[e + 2 * (size_t)H * H];
-            v0[i] = ok ? a0 : 0.f; v1[i] = ok ? a1 : 0.f; v2[i] = ok ? a2 : 0.f;
+            const float a0 = x[e], a1v = x[e + (size_t)H * H], a2 = x[e + 2 * (size_t)H * H];
+            v0[i] = ok ? a0 : 0.f; v1[i] = ok ? a1v : 0.f; v2[i] = ok ? a2 : 0.f;
         }
+    };
+    if ((int)blockIdx.x < numStrips) fetch(blockIdx.x);
+    for (int strip = blockIdx.x; strip < numStrips; strip += gridDim.x) {
+        const int ib = strip / (SX * SY), t = strip % (SX * SY);
+        const int ty0 = (t / SX) * SR, tx0 = (t % SX) * SW;
+        __syncthreads();                         // every wave is done with the previous strip's LDS image
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int q = tid + i * 256;
             if (q < HR_ * HWX) { bf16x4 u; u[0] = (__bf16)v0[i]; u[1] = (__bf16)v1[i]; u[2] = (__bf16)v2[i]; u[3] = (__bf16)0.f; lds_x[q] = u; }
         }
-    }
-    __syncthreads();
-    f32x16 acc[4];
+        __syncthreads();
+        if (strip + (int)gridDim.x < numStrips) fetch(strip + gridDim.x);
+        f32x16 acc[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[r][v] = 0.f;
+            for (int v = 0; v < 16; ++v) acc[r][v] = 0.f;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
+        for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-        for (int r = 0; r < 5; ++r)
+            for (int r = 0; r < 5; ++r)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const bf16x4* p = lds_x + (wave * 4 + rr + r) * HWX + li + 4 * kb + 2 * lh;
-                const bf16x4 lo = p[0], hi = p[1];
-                const bf16x8 av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw[r][kb], acc[rr], 0, 0, 0);
+                for (int kb = 0; kb < 2; ++kb) {
+                    const bf16x4* p = lds_x + (wave * 4 + rr + r) * HWX + li + 4 * kb + 2 * lh;
+                    const bf16x4 lo = p[0], hi = p[1];
+                    const bf16x8 av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw[r][kb], acc[rr], 0, 0, 0);
+                }
+        // epilogue: element v of lane (li, lh) in tile r = pixel column (v&3)+8*(v>>2)+4*lh of row 4*wave+r, channel li
+        float s = 0.f;
+        float* patch = patch_all + wave * (32 * 36);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float val = acc[r][v] + bv;
+                acc[r][v] = val;
+                s += val;
+                if (PASS != E1_STATS) patch[((v & 3) + 8 * (v >> 2) + 4 * lh) * 36 + li] = val;
             }
-    // epilogue: element v of lane (li, lh) in tile r = pixel column (v&3)+8*(v>>2)+4*lh of row 4*wave+r, channel li
-    const float bv = bias[li];
-    float s = 0.f;
-    float* patch = patch_all + wave * (32 * 36);
+            if (PASS == E1_STATS) continue;
+            const int gy = ty0 + wave * 4 + r;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+            for (int it = 0; it < 2; ++it) {
+                const int idx = it * 64 + lane, px = idx >> 2, c8 = idx & 3;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(patch + px * 36 + c8 * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(patch + px * 36 + c8 * 8 + 4);
+                bf16x8 o;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const float val = acc[r][v] + bv;
-            acc[r][v] = val;
-            s += val;
-            patch[((v & 3) + 8 * (v >> 2) + 4 * lh) * 36 + li] = val;
+                for (int e = 0; e < 4; ++e) { o[e] = (__bf16)lo[e]; o[4 + e] = (__bf16)hi[e]; }
+                Act<__bf16>::st8(y, ((size_t)(ib * H + gy) * H + tx0 + px) * 32 + c8 * 8, o);
+            }
         }
-        const int gy = ty0 + wave * 4 + r;
+        if constexpr (PASS == E1_POOL) {
+            // BatchNorm + 2x2 max + ReLU of this wave's 4 rows x 32 columns: both rows and both columns of a window sit in
+            // this lane's accumulators (rows 2q / 2q+1, elements v / v+1 for even v)
+            const float sc = coef[li * 4], sh = coef[li * 4 + 1];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = it * 64 + lane, px = idx >> 2, c8 = idx & 3;
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(patch + px * 36 + c8 * 8);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(patch + px * 36 + c8 * 8 + 4);
-            bf16x8 o;
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { o[e] = (__bf16)lo[e]; o[4 + e] = (__bf16)hi[e]; }
-            Act<__bf16>::st8(y, ((size_t)(ib * H + gy) * H + tx0 + px) * 32 + c8 * 8, o);
+                for (int v = 0; v < 16; v += 2) {
+                    float m = 0.f;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const float yb = (float)(__bf16)acc[2 * q + (p >> 1)][v + (p & 1)];       // the value y1 holds
+                        const float n = fmaf(yb, sc, sh);
+                        m = (p == 0 || n > m) ? n : m;
+                    }
+                    const int pcol = ((v & 3) + 8 * (v >> 2) + 4 * lh) >> 1;
+                    patch[(q * 16 + pcol) * 36 + li] = fmaxf(m, 0.f);
+                }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int idx = it * 64 + lane, pp = idx >> 2, c8 = idx & 3;                  // pooled pixel pp = q*16 + pcol
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(patch + pp * 36 + c8 * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(patch + pp * 36 + c8 * 8 + 4);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = (__bf16)lo[e]; o[4 + e] = (__bf16)hi[e]; }
+                const int prow = ty0 / 2 + wave * 2 + (pp >> 4), pc = tx0 / 2 + (pp & 15);
+                Act<__bf16>::st8(a1, ((size_t)(ib * (H / 2) + prow) * (H / 2) + pc) * 32 + c8 * 8, o);
+            }
+            continue;                                        // the statistics came from the E1_STATS pass
         }
-    }
-    s += __shfl_xor(s, 32, 64);
-    if (lh == 0) red[0][wave][li] = s;
-    __syncthreads();
-    const float mean = ((red[0][0][li] + red[0][1][li]) + (red[0][2][li] + red[0][3][li])) * (1.0f / (SR * SW));
-    float m2 = 0.f;
+        s += __shfl_xor(s, 32, 64);
+        if (lh == 0) red[0][wave][li] = s;
+        __syncthreads();
+        const float mean = ((red[0][0][li] + red[0][1][li]) + (red[0][2][li] + red[0][3][li])) * (1.0f / (SR * SW));
+        float m2 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) { const float d = acc[r][v] - mean; m2 += d * d; }
-    m2 += __shfl_xor(m2, 32, 64);
-    if (lh == 0) red[1][wave][li] = m2;
-    __syncthreads();
-    if (tid < 32) {
-        const size_t nt = gridDim.x;
-        bnpart[(size_t)blockIdx.x * 32 + tid] = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
-        bnpart[(nt + blockIdx.x) * 32 + tid] = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+            for (int v = 0; v < 16; ++v) { const float d = acc[r][v] - mean; m2 += d * d; }
+        m2 += __shfl_xor(m2, 32, 64);
+        if (lh == 0) red[1][wave][li] = m2;
+        __syncthreads();
+        if (tid < 32) {
+            bnpart[(size_t)strip * 32 + tid] = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
+            bnpart[((size_t)numStrips + strip) * 32 + tid] = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+        }
     }
     (void)B;
 }
@@ -596,9 +646,16 @@ int64_t e1_wgrad_ws_floats(int width, int B) {
 }
 
 int launch_e1_fwd(int width, int B, const float* x, const float* w, const float* bias, float* y,
-                  float* bnpart, hipStream_t st, bool bf16) {
-    if (width == 64 && bf16) hipLaunchKernelGGL(e1_fwd_bf16_kernel<64>, dim3(B * 8), dim3(256), 0, st, x, w, bias, y, bnpart, B);
-    else if (width == 128 && bf16) hipLaunchKernelGGL(e1_fwd_bf16_kernel<128>, dim3(B * 32), dim3(256), 0, st, x, w, bias, y, bnpart, B);
+                  float* bnpart, hipStream_t st, bool bf16, int pass, const float* coef, float* a1) {
+    if (pass != 0 && !bf16) { cvae_set_error("e1_fwd: passes 1/2 exist in bf16 mode only"); return -2; }
+    const int ns64 = B * 8, ns128 = B * 32, cap = 256 * 3;        // persistent: 3 workgroups per CU (VGPR-limited), one strip each per turn
+    const dim3 g64(ns64 < cap ? ns64 : cap), g128(ns128 < cap ? ns128 : cap);
+    if (width == 64 && bf16 && pass == 1) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_STATS>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64);
+    else if (width == 64 && bf16 && pass == 2) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_POOL>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64);
+    else if (width == 128 && bf16 && pass == 1) hipLaunchKernelGGL((e1_fwd_bf16_kernel<128, E1_STATS>), g128, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns128);
+    else if (width == 128 && bf16 && pass == 2) hipLaunchKernelGGL((e1_fwd_bf16_kernel<128, E1_POOL>), g128, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns128);
+    else if (width == 64 && bf16) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_Y>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64);
+    else if (width == 128 && bf16) hipLaunchKernelGGL((e1_fwd_bf16_kernel<128, E1_Y>), g128, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns128);
     else if (width == 64) hipLaunchKernelGGL(e1_fwd_kernel<64>, dim3(B * 8), dim3(256), 0, st, x, w, bias, y, bnpart, B);
     else if (width == 128) hipLaunchKernelGGL(e1_fwd_kernel<128>, dim3(B * 32), dim3(256), 0, st, x, w, bias, y, bnpart, B);
     else { cvae_set_error("e1_fwd: width %d unsupported", width); return -2; }

@@ -214,6 +214,30 @@ def test_bf16x9_emulation_meets_the_fp32_parity_bar(B, mode):
     assert (mu - res["f32"][0]).abs().max() < 2e-5 and (recon - res["f32"][1]).abs().max() < 2e-5
 
 
+def test_two_pass_e1_forward_is_bit_identical(monkeypatch):
+    """bf16 mode runs E1's forward twice (statistics pass, then conv + BatchNorm / pool / ReLU epilogue) instead of
+    conv -> bn_pool_act_fwd reading y1 back (CVAE_E1_TWO_PASS=0).  The epilogue pools the bf16-rounded values exactly
+    as the separate kernel pools the stored tensor, so losses, outputs and every gradient must agree to the bit —
+    train mode at both frame sizes, and the eval-mode encoder."""
+    from critic_vae_amd.nets import VariationalAutoencoder
+    from critic_vae_amd.train import FusedTrainer
+    dev = torch.device("cuda:0")
+    for W, B in ((64, 8), (128, 3)):
+        x, pred, eps = (torch.from_numpy(v).to(dev) for v in synth.make_batch(1234, 0, B, W))
+        res = {}
+        for two in ("1", "0"):
+            monkeypatch.setenv("CVAE_E1_TWO_PASS", two)
+            vae = VariationalAutoencoder(width=W, max_batch=B, seed=0, precision="bf16").to(dev)
+            tr = FusedTrainer(vae)
+            scal = tr.step(x, pred, eps).clone()
+            with torch.no_grad():
+                mu_eval, _ = vae.eval().encoder(x)
+            torch.cuda.synchronize()
+            res[two] = (scal, tr.recon[:B].clone(), tr.grads.clone(), vae.bn_state.clone(), mu_eval.clone())
+        for a, b in zip(res["1"], res["0"]):
+            assert torch.equal(a, b)
+
+
 def test_bf16_kernels_exact_on_their_stored_operands():
     """Layout / indexing check of every bf16-mode contraction, independent of the bf16 rounding noise: after one
     bf16 step the workspace holds the bf16 activations and activation gradients the kernels actually consumed.

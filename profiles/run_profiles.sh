@@ -17,6 +17,7 @@ for cfg in f32 bf16; do
   python3 profiles/summarize_pmc.py $out/pmc_mfma_$cfg $out/pmc_fetch_$cfg $out/pmc_write_$cfg > $out/pmc_summary_$cfg.csv
 done
 python3 profiles/make_traffic_json.py $out/pmc_fetch_f32 $out/pmc_write_f32 > $out/traffic_per_launch.json
+cp $out/traffic_per_launch.json profiles/traffic_per_launch.json      # bench.py reports roofline.traffic from the file stamped with these sources
 python3 bench.py > $out/bench_f32.json 2> $out/bench_f32.err && echo "bench f32 ok"
 python3 bench.py --preset config2 --steps 30 --warmup 5 --no-cpu-baseline > $out/bench_bf16_b2048.json 2> $out/bench_bf16.err && echo "bench bf16 ok"
 python3 bench.py --preset config5 --steps 10 --warmup 3 --no-cpu-baseline --no-probe > $out/bench_w128_bf16_b1024.json 2> $out/bench_w128.err && echo "bench w128 ok"

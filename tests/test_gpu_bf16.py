@@ -214,6 +214,49 @@ def test_bf16x9_emulation_meets_the_fp32_parity_bar(B, mode):
     assert (mu - res["f32"][0]).abs().max() < 2e-5 and (recon - res["f32"][1]).abs().max() < 2e-5
 
 
+def test_bn_pool_ops_follow_the_handle_storage_type():
+    """The stand-alone BatchNorm/pool ops of a bf16-storage handle read and write bf16 tensors (as the step does):
+    eval-mode forward (coefficients from the running statistics) and the backward apply pass against a torch
+    evaluation of the same formulas on the same bf16 operands."""
+    from critic_vae_amd import lib as cvlib
+    dev = torch.device("cuda:0")
+    B, layer, C, H = 4, 1, 64, 32
+    h = cvlib.Handle(64, B, precision="bf16")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    y = (torch.randn(B, H, H, C, generator=g) * 1.5).to(torch.bfloat16).to(dev)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.3).to(dev)
+    rm, rv = (torch.randn(C, generator=g) * 0.2).to(dev), (torch.rand(C, generator=g) + 0.5).to(dev)
+    coef = torch.empty(4 * C, device=dev)
+    a = torch.empty(B, H // 2, H // 2, C, dtype=torch.bfloat16, device=dev)
+    sc = torch.empty(h.op_scratch_floats(B), device=dev)
+    f32v = lambda t: t.view(torch.float32)      # noqa: E731  (opaque pointer: two bf16 elements per float)
+    h.op_bn_pool_act_fwd(layer, B, f32v(y), None, gamma, beta, rm, rv, coef, f32v(a), sc, train=False)
+    torch.cuda.synchronize()
+    invstd = 1.0 / torch.sqrt(rv + 1e-5)
+    scale, shift = gamma * invstd, beta - rm * gamma * invstd
+    n = torch.addcmul(shift, y.float(), scale)                        # fma(y, scale, shift) per element
+    want = torch.relu(n.view(B, H // 2, 2, H // 2, 2, C).amax(dim=(2, 4))).to(torch.bfloat16)
+    assert (a.float() - want.float()).abs().max() <= 2.0 ** -7 * want.float().abs().max()
+    # backward: dy = scale * ((p == argmax ? g : 0) - k1 - xhat * k2), k1 = sum(g)/N, k2 = sum(g*xhat)/N, g = da*[a > 0]
+    da = torch.randn(B, H // 2, H // 2, C, generator=g).to(torch.bfloat16).to(dev)
+    dy = torch.empty_like(y)
+    dgamma, dbeta = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    h.op_bn_pool_act_bwd(layer, B, f32v(y), f32v(a), f32v(da), coef, gamma, f32v(dy), dgamma, dbeta, None, sc)
+    torch.cuda.synchronize()
+    win = n.view(B, H // 2, 2, H // 2, 2, C).permute(0, 1, 3, 5, 2, 4).reshape(B, H // 2, H // 2, C, 4)
+    pos = win.argmax(dim=-1)                                           # first maximum in scan order (ties: measure zero here)
+    gq = da.float() * (a.float() > 0)
+    xhat = (y.float() - rm) * invstd
+    xw = xhat.view(B, H // 2, 2, H // 2, 2, C).permute(0, 1, 3, 5, 2, 4).reshape(B, H // 2, H // 2, C, 4)
+    N = B * H * H
+    k1, k2 = gq.sum(dim=(0, 1, 2)) / N, (gq * xw.gather(-1, pos[..., None])[..., 0]).sum(dim=(0, 1, 2)) / N
+    sel = torch.zeros_like(xw).scatter_(-1, pos[..., None], gq[..., None])
+    dw = scale[:, None] * (sel - k1[:, None] - xw * k2[:, None])
+    dy_ref = dw.view(B, H // 2, H // 2, C, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(B, H, H, C)
+    assert (dy.float() - dy_ref).abs().max() <= 2.0 ** -7 * dy_ref.abs().max() + 1e-6
+    assert (dbeta - gq.sum(dim=(0, 1, 2))).abs().max() <= 1e-3 * gq.abs().sum(dim=(0, 1, 2)).max()
+
+
 def test_two_pass_e1_forward_is_bit_identical(monkeypatch):
     """bf16 mode runs E1's forward twice (statistics pass, then conv + BatchNorm / pool / ReLU epilogue) instead of
     conv -> bn_pool_act_fwd reading y1 back (CVAE_E1_TWO_PASS=0).  The epilogue pools the bf16-rounded values exactly

@@ -145,6 +145,8 @@ def main():
                          "convs (configs[2]: use with --batch 2048)")
     ap.add_argument("--preset", choices=sorted(PRESETS), default=None,
                     help="BASELINE.json configs[2..4] workloads: sets --precision/--batch/--width")
+    ap.add_argument("--allreduce-dtype", choices=["f32", "bf16"], default=None,
+                    help="wire format of the gradient all-reduce at N > 1 (default f32; bf16 halves the bytes, optional per SURVEY 8e)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--no-fwd-bwd-rate", action="store_true", help="skip the extra forward+loss+backward-only loop (profiling runs)")
@@ -175,7 +177,7 @@ def main():
 
     Wd = args.width
     vae = VariationalAutoencoder(width=Wd, max_batch=B, seed=0, precision=args.precision).to(dev)
-    tr = FusedTrainer(vae, world_size=world)
+    tr = FusedTrainer(vae, world_size=world, reduce_dtype=args.allreduce_dtype)
     tr.measure_exposed = world > 1
     H = vae.handle
     # synthetic inputs, resident in HBM before the timed region; each rank its own shard
@@ -228,7 +230,8 @@ def main():
         dist_info = {"backend": torch.distributed.get_backend(), "ranks_counted_by_allreduce": int(ones.item()),
                      "world_size": torch.distributed.get_world_size(), "rank_devices": [int(v) for v in mine.tolist()],
                      "allreduce_exposed_us": None if exposed is None else round(exposed, 1),
-                     "allreduce_bytes": int(tr.grads.numel() * 4)}
+                     "allreduce_dtype": tr.reduce_dtype,
+                     "allreduce_bytes": int(tr.grads.numel() * (2 if tr.reduce_dtype == "bf16" else 4))}
     note(f"timed {args.steps} steps in {dt:.3f}s, loss {loss}")
 
     res = {

@@ -88,3 +88,29 @@ int launch_scale3(const Scale3& a, hipStream_t st) {
     CVAE_CHECK_LAUNCH();
     return 0;
 }
+
+// fp32 <-> bf16 copies of a gradient range for the optional bf16 all-reduce (5.17 MB instead of 10.34 MB on
+// the wire); RNE on the way down, exact on the way up.  n is a multiple of 64 (bucket ranges are).
+__global__ __launch_bounds__(256) void grads_pack_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + i * 4);
+    bf16x4 o;
+    o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+    *reinterpret_cast<bf16x4*>(dst + i * 4) = o;
+}
+__global__ __launch_bounds__(256) void grads_unpack_bf16_kernel(const __bf16* __restrict__ src, float* __restrict__ dst, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(src + i * 4);
+    *reinterpret_cast<f32x4*>(dst + i * 4) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+int launch_grads_bf16(const float* src_f32, void* bf16_buf, float* dst_f32, int64_t n, hipStream_t st) {
+    if (n % 4 != 0) { cvae_set_error("grads bf16 copy: n = %lld is not a multiple of 4", (long long)n); return -2; }
+    const int64_t n4 = n / 4;
+    const unsigned blocks = (unsigned)((n4 + 255) / 256);
+    if (src_f32) hipLaunchKernelGGL(grads_pack_bf16_kernel, dim3(blocks), dim3(256), 0, st, src_f32, reinterpret_cast<__bf16*>(bf16_buf), n4);
+    else hipLaunchKernelGGL(grads_unpack_bf16_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const __bf16*>(bf16_buf), dst_f32, n4);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}

@@ -482,6 +482,15 @@ int cvae_adam_step(cvae_handle h, float* params, const float* grads, float* exp_
     return launch_adam(params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream);
 }
 
+int cvae_grads_to_bf16(cvae_handle h, const float* grads, void* out_bf16, int64_t n, void* stream) {
+    if (!h || !grads || !out_bf16 || n < 0) { cvae_set_error("cvae_grads_to_bf16: bad argument"); return CVAE_EINVAL; }
+    return launch_grads_bf16(grads, out_bf16, nullptr, n, (hipStream_t)stream);
+}
+int cvae_grads_from_bf16(cvae_handle h, const void* in_bf16, float* grads, int64_t n, void* stream) {
+    if (!h || !grads || !in_bf16 || n < 0) { cvae_set_error("cvae_grads_from_bf16: bad argument"); return CVAE_EINVAL; }
+    return launch_grads_bf16(nullptr, const_cast<void*>(in_bf16), grads, n, (hipStream_t)stream);
+}
+
 // d_* (out) = d_* (in) * gscale[0]: total_loss.backward()'s incoming factor applied to the three loss
 // gradients cvae_loss wrote, one launch, gscale a device scalar (no host read)
 int cvae_scale_loss_grads(cvae_handle h, int32_t B, const float* gscale, const float* d_recon, const float* d_mu,

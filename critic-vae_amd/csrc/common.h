@@ -259,6 +259,7 @@ int launch_critic_fwd(int width, int B, const float* x, const float* critic_para
 int launch_preprocess_u8(int width, int B, const uint8_t* u8, float* x, hipStream_t st);
 int launch_diff_grey(int width, int B, const float* a, const float* b, float* diff, hipStream_t st);
 // adam.hip
+int launch_grads_bf16(const float* src_f32, void* bf16_buf, float* dst_f32, int64_t n, hipStream_t st);   // src set: pack; else unpack
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1,
                 float b2, float eps, float gscale, hipStream_t st);
 int launch_zero(float* p, int64_t n, hipStream_t st);

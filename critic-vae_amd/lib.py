@@ -56,6 +56,8 @@ _SIGS = {
     "cvae_grad_bucket": (C.c_int, [_p, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "cvae_scale_loss_grads": (C.c_int, [_p, _i32] + [_p] * 8),
     "cvae_adam_step": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _f, _f, _f, _f, _f, _p]),
+    "cvae_grads_to_bf16": (C.c_int, [_p, _p, _p, _i64, _p]),
+    "cvae_grads_from_bf16": (C.c_int, [_p, _p, _p, _i64, _p]),
     "cvae_critic_param_count": (_i32, []),
     "cvae_critic_forward": (C.c_int, [_p, _i32, _p, _p, _p, _p]),
     "cvae_preprocess_u8": (C.c_int, [_p, _i32, _p, _p, _p]),
@@ -183,6 +185,15 @@ class Handle:
     def scale_loss_grads(self, B, g, d_recon, d_mu, d_logvar, out_recon, out_mu, out_logvar):
         self._check(self.lib.cvae_scale_loss_grads(self.h, B, _ptr(g), _ptr(d_recon), _ptr(d_mu), _ptr(d_logvar),
                                                    _ptr(out_recon), _ptr(out_mu), _ptr(out_logvar), _stream()))
+
+    def grads_to_bf16(self, grads, out_bf16):
+        """fp32 gradient range -> caller's bf16 buffer of the same length (transport of the optional bf16 all-reduce)."""
+        assert out_bf16.is_cuda and out_bf16.dtype == torch.bfloat16 and out_bf16.is_contiguous() and out_bf16.numel() == grads.numel()
+        self._check(self.lib.cvae_grads_to_bf16(self.h, _ptr(grads), out_bf16.data_ptr(), grads.numel(), _stream()))
+
+    def grads_from_bf16(self, in_bf16, grads):
+        assert in_bf16.is_cuda and in_bf16.dtype == torch.bfloat16 and in_bf16.is_contiguous() and in_bf16.numel() == grads.numel()
+        self._check(self.lib.cvae_grads_from_bf16(self.h, in_bf16.data_ptr(), _ptr(grads), grads.numel(), _stream()))
 
     def backward_phase(self, phase, B, x, pred, eps, params, logvar, recon, d_recon, d_mu, d_logvar, ws, grads):
         """Phase 0..2 of the backward (decoder | fc + encoder block 3 | encoder blocks 2..0), in order."""

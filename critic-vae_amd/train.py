@@ -54,20 +54,29 @@ class FusedTrainer:
     """One training step = forward + loss + backward + all-reduce + Adam on flat buffers."""
 
     def __init__(self, vae, lr=P.lr, betas=P.adam_betas, eps=P.adam_eps, process_group=None, world_size=1,
-                 overlap=None):
+                 overlap=None, reduce_dtype=None):
         """overlap: all-reduce the gradient in three buckets while backward still runs (default for
-        world_size > 1; CVAE_DP_OVERLAP=0 or overlap=False = one all-reduce after backward)."""
+        world_size > 1; CVAE_DP_OVERLAP=0 or overlap=False = one all-reduce after backward).
+        reduce_dtype: "f32" (default; the contract of SURVEY 8e: reduced gradient == mean of the shard gradients
+        within 1e-4) or "bf16" (CVAE_DP_REDUCE=bf16): the wire format of the all-reduce is bf16 — half the bytes,
+        the summed gradient carries a relative rounding of 2^-9 per rank, optimizer state stays fp32."""
         self.vae = vae
         self.h = vae.handle
         if overlap is None:
             overlap = os.environ.get("CVAE_DP_OVERLAP", "1") != "0"
         self.overlap = bool(overlap) and world_size > 1
+        if reduce_dtype is None:
+            reduce_dtype = os.environ.get("CVAE_DP_REDUCE", "f32")
+        if reduce_dtype not in ("f32", "bf16"):
+            raise ValueError(f"reduce_dtype {reduce_dtype!r}: 'f32' or 'bf16'")
+        self.reduce_dtype = reduce_dtype
         self.buckets = [self.h.grad_bucket(ph) for ph in range(3)]
         self.lr, self.betas, self.eps = lr, betas, eps
         self.world_size, self.pg = world_size, process_group
         dev = vae.theta.device
         n = vae.theta.numel()
         self.grads = torch.zeros(n, device=dev)
+        self.grads16 = torch.empty(n, dtype=torch.bfloat16, device=dev) if (reduce_dtype == "bf16" and world_size > 1) else None
         self.m = torch.zeros(n, device=dev)
         self.v = torch.zeros(n, device=dev)
         self.step_count = 0
@@ -112,17 +121,28 @@ class FusedTrainer:
                 h.backward_phase(ph, B, x, pred, eps, theta, self.logvar, self.recon, self.d_recon, self.d_mu,
                                  self.d_logvar, self.ws, self.grads)
                 off, n = self.buckets[ph]
-                works.append(torch.distributed.all_reduce(self.grads[off:off + n], group=self.pg, async_op=True))
+                if self.grads16 is not None:
+                    h.grads_to_bf16(self.grads[off:off + n], self.grads16[off:off + n])
+                    works.append(torch.distributed.all_reduce(self.grads16[off:off + n], group=self.pg, async_op=True))
+                else:
+                    works.append(torch.distributed.all_reduce(self.grads[off:off + n], group=self.pg, async_op=True))
             self._exposed_begin()
             for wk in works:
                 wk.wait()                     # nccl: the compute stream waits for the collective's stream
             self._exposed_end()
+            if self.grads16 is not None:
+                h.grads_from_bf16(self.grads16, self.grads)
         else:
             h.backward(B, x, pred, eps, theta, self.logvar, self.recon, self.d_recon, self.d_mu, self.d_logvar,
                        self.ws, self.grads)
             if self.world_size > 1:
                 self._exposed_begin()
-                torch.distributed.all_reduce(self.grads, group=self.pg)      # one flat RCCL all-reduce (sum)
+                if self.grads16 is not None:
+                    h.grads_to_bf16(self.grads, self.grads16)
+                    torch.distributed.all_reduce(self.grads16, group=self.pg)
+                    h.grads_from_bf16(self.grads16, self.grads)
+                else:
+                    torch.distributed.all_reduce(self.grads, group=self.pg)      # one flat RCCL all-reduce (sum)
                 self._exposed_end()
         self.step_count += 1
         v.num_batches_tracked += 1

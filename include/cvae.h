@@ -134,6 +134,15 @@ int cvae_scale_loss_grads(cvae_handle h, int32_t batch, const float* gscale, con
                           float* d_logvar_out, void* stream);
 
 /*
+ * Optional bf16 transport of the gradient all-reduce ("bf16 optional 5.17 MB"): round a range of the flat
+ * fp32 gradient buffer to bf16 (RNE) into a caller-owned buffer of n 2-byte elements, and widen the reduced buffer
+ * back.  n: a multiple of 4 (the ranges of cvae_grad_bucket are multiples of 64).  The all-reduce itself stays the
+ * caller's (torch.distributed / RCCL).
+ */
+int cvae_grads_to_bf16(cvae_handle h, const float* grads, void* out_bf16, int64_t n, void* stream);
+int cvae_grads_from_bf16(cvae_handle h, const void* in_bf16, float* grads, int64_t n, void* stream);
+
+/*
  * Optimizer: torch.optim.Adam.step() with defaults (vae.py:36,58) on the flat buffers.
  * grad_scale multiplies the gradient first (1/world_size after a summing all-reduce).
  */

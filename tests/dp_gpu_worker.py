@@ -51,7 +51,8 @@ dist.broadcast(r0, src=0)
 assert torch.equal(r0, vae_d.theta.data), "replicas diverged after one step"
 del vae_d, tr_d
 
-want_grad = (single_rank_grad(0) + single_rank_grad(1))      # FusedTrainer keeps the SUM; 1/N is folded into Adam
+g_shard = [single_rank_grad(0), single_rank_grad(1)]
+want_grad = g_shard[0] + g_shard[1]                           # FusedTrainer keeps the SUM; 1/N is folded into Adam
 results = {}
 for overlap in (True, False):
     vae = VariationalAutoencoder(max_batch=per, seed=0).to(dev)
@@ -67,6 +68,24 @@ for overlap in (True, False):
     dist.broadcast(other, src=0)
     assert torch.equal(other, results[overlap]), "ranks diverged"
 assert torch.equal(results[True], results[False]), "bucketed and single all-reduce differ"
+# optional bf16 wire format (SURVEY 8e "bf16 optional"): each rank's contribution is rounded to bf16 (2^-9 relative)
+# and so is their sum, so the reduced gradient is the fp32 one within 2^-8 .. 2^-7 of |g_0| + |g_1| per element (NOT of the
+# sum: the shards' gradients partly cancel); every rank ends with the same parameters, and the bucketed / single
+# variants agree to the bit (same per-element operations)
+res16 = {}
+for overlap in (True, False):
+    vae = VariationalAutoencoder(max_batch=per, seed=0).to(dev)
+    tr16 = FusedTrainer(vae, world_size=world, overlap=overlap, reduce_dtype="bf16")
+    tr16.step(*batch(rank))
+    torch.cuda.synchronize()
+    d = (tr16.grads - want_grad).abs()
+    # (2^-7: the backend's own bf16 addition need not round to nearest)
+    assert (d <= 2.0 ** -7 * (g_shard[0].abs() + g_shard[1].abs()) + 1e-12).all(), (overlap, d.max().item())
+    res16[overlap] = vae.theta.data.clone()
+    other = res16[overlap].clone()
+    dist.broadcast(other, src=0)
+    assert torch.equal(other, res16[overlap]), "ranks diverged (bf16 reduce)"
+assert torch.equal(res16[True], res16[False])
 # buckets tile the flat buffer exactly
 b = sorted(tr.buckets)
 assert b[0][0] == 0 and all(b[i][0] + b[i][1] == b[i + 1][0] for i in range(2)) and b[2][0] + b[2][1] == tr.grads.numel()

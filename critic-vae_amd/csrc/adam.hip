@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2,
                 float eps, float gscale, hipStream_t st) {
     if (n % 4 != 0) { cvae_set_error("adam: n=%lld must be a multiple of 4", (long long)n); return -1; }
+    if (n == 0) return 0;
     const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
     const int64_t n4 = n / 4;
     int64_t blocks = (n4 + 255) / 256;
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(256) void grads_unpack_bf16_kernel(const __bf16* __
 }
 int launch_grads_bf16(const float* src_f32, void* bf16_buf, float* dst_f32, int64_t n, hipStream_t st) {
     if (n % 4 != 0) { cvae_set_error("grads bf16 copy: n = %lld is not a multiple of 4", (long long)n); return -2; }
+    if (n == 0) return 0;                                    // an empty range is a no-op, not a zero-block launch
     const int64_t n4 = n / 4;
     const unsigned blocks = (unsigned)((n4 + 255) / 256);
     if (src_f32) hipLaunchKernelGGL(grads_pack_bf16_kernel, dim3(blocks), dim3(256), 0, st, src_f32, reinterpret_cast<__bf16*>(bf16_buf), n4);

@@ -18,9 +18,11 @@ void cvae_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-// ---- in-step kernel probe: ids = kind*9 + layer, kind 0 fwd / 1 dgrad / 2 wgrad (conv kernels);
-//      kind 3 (ids 27..30) = the BatchNorm+pool backward apply kernel of encoder block `layer` (HBM-bound) ----
-static constexpr int PROBE_IDS = 31, PROBE_CAP = 128;
+// ---- in-step kernel probe: ids = kind*9 + layer, kind 0 fwd / 1 dgrad / 2 wgrad (conv kernels; layer 0 = E1: id 0 its
+//      forward — the BatchNorm/pool pass in two-pass mode —, id 18 its weight gradient; layer 8 = D4: id 8 forward,
+//      id 17 the fused backward);  kind 3: ids 27..30 = the BatchNorm+pool backward apply kernel of encoder block
+//      `layer` (HBM-bound), id 31 = the MS-SSIM level-0 tile kernel ----
+static constexpr int PROBE_IDS = 32, PROBE_CAP = 128;
 struct ProbeSlot { hipEvent_t e0[PROBE_CAP], e1[PROBE_CAP]; int n = 0; bool made = false; };
 struct ProbeState { uint32_t mask = 0; ProbeSlot slot[PROBE_IDS]; };
 static thread_local ProbeSlot* g_probe_cur = nullptr;
@@ -273,10 +275,11 @@ int cvae_forward(cvae_handle h, int32_t B, const float* x, const float* pred, co
             if (train) RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), nullptr, ws + w.bnpart[0], st, true, 1));
             RC(launch_bn_fwd_finalize(0, W, B, ws + w.bnpart[0], P_(h->enc_g[0]), P_(h->enc_be[0]), bn_state + kBnOff[0],
                                       bn_state + 480 + kBnOff[0], ws + w.coef[0], ws + w.scratch, train, st));
-            RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], nullptr, st, true, 2, ws + w.coef[0], ws + w.a[0]));
+            { ProbeArm pa(h, 0, 0);
+              RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], nullptr, st, true, 2, ws + w.coef[0], ws + w.a[0])); }
             continue;
         }
-        if (l == 0) RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], ws + w.bnpart[0], st, h->cfg.precision == 1));
+        if (l == 0) { ProbeArm pa(h, 0, 0); RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], ws + w.bnpart[0], st, h->cfg.precision == 1)); }
         else if (use_bf16(h, l)) { ProbeArm pa(h, 0, l); RC(launch_conv_fwd_bf16(l, W, bf16_mode(h), B, ws + w.a[l - 1], ws + w.wpack, P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st)); }
         else { ProbeArm pa(h, 0, l); RC(launch_conv_fwd(l, W, B, ws + w.a[l - 1], P_(h->enc_w[l]), P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st)); }
         RC(launch_bn_fwd_finalize(l, W, B, ws + w.bnpart[l], P_(h->enc_g[l]), P_(h->enc_be[l]), bn_state + kBnOff[l],
@@ -323,7 +326,7 @@ int cvae_decode(cvae_handle h, int32_t B, const float* zcat, const float* params
             RC(launch_conv_up_fwd(4 + i, W, B, ws + w.o[i - 1], ws + w.wc[i - 1], P_(h->dec_b[i]), ws + w.o[i], ws + w.scratch, st));
         }
     }
-    RC(launch_d4_fwd(W, B, ws + w.o[3], P_(h->dec_w[4]), P_(h->dec_b[4]), recon, st, io_bf16(h)));
+    { ProbeArm pa(h, 0, 8); RC(launch_d4_fwd(W, B, ws + w.o[3], P_(h->dec_w[4]), P_(h->dec_b[4]), recon, st, io_bf16(h))); }
     return 0;
 }
 
@@ -336,6 +339,7 @@ int cvae_loss(cvae_handle h, int32_t B, const float* x, const float* mu, const f
     }
     float* ws = (float*)wsv;
     const WsLayout w = carve(h, B);
+    ProbeArm pa(h, 3, 4);            // id 31: the level-0 tile kernel
     return launch_msssim(h->cfg.width, B, recon, x, mu, logvar, ws + w.ms, scalars, d_recon, d_mu, d_logvar, (hipStream_t)stream);
 }
 
@@ -365,10 +369,12 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
     if ((phase_mask & ~15) != 0 || (phase_mask & 7) == 0) { cvae_set_error("cvae_backward_phases: phase_mask %d (bits 0..2 = phases, bit 3 = zero the alignment padding)", phase_mask); return CVAE_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     if (phase_mask & 8) {                               // caller handed an uninitialised gradient buffer
-        PadGaps gaps{};
+        PadGaps gaps{};                                 // 32 gaps per launch; as many launches as the parameter list needs
         for (const ParamEntry& p : h->params) {
             const int64_t pad = align_up(p.numel, 64) - p.numel;
-            if (pad > 0 && gaps.n < 32) { gaps.off[gaps.n] = p.offset + p.numel; gaps.len[gaps.n] = (int)pad; gaps.n++; }
+            if (pad <= 0) continue;
+            gaps.off[gaps.n] = p.offset + p.numel; gaps.len[gaps.n] = (int)pad; gaps.n++;
+            if (gaps.n == 32) { RC(launch_zero_gaps(grads, gaps, st)); gaps.n = 0; }
         }
         RC(launch_zero_gaps(grads, gaps, st));
     }
@@ -420,8 +426,9 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
     };
     if (phase_mask & 1) {
     // decoder, last layer first
-    RC(launch_d4_bwd(W, B, ws + w.o[3], d_recon, recon, P_(h->dec_w[4]), ws + w.dout4, ws + w.d_o[3],
-                     G_(h->dec_w[4]), G_(h->dec_b[4]), sc, st, io_bf16(h)));
+    { ProbeArm pa(h, 1, 8);
+      RC(launch_d4_bwd(W, B, ws + w.o[3], d_recon, recon, P_(h->dec_w[4]), ws + w.dout4, ws + w.d_o[3],
+                       G_(h->dec_w[4]), G_(h->dec_b[4]), sc, st, io_bf16(h))); }
     for (int i = 3; i >= 0; --i) {
         const int l = 4 + i;
         const float* in = i == 0 ? ws + w.h : ws + w.o[i - 1];
@@ -460,7 +467,7 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
         RC(fork(7 - l));
         if (l == 0) {
             const float* fu[5] = {ws + w.y[0], ws + w.a[0], ws + w.d_a[0], ws + w.coef[0], bn_bwd_bcoef(0, W, B, sc)};
-            { RedArm ra(h, side_red, &red_pending, st); ra.arm(&sred);
+            { ProbeArm pa(h, 2, 0); RedArm ra(h, side_red, &red_pending, st); ra.arm(&sred);
               RC(launch_e1_wgrad(W, B, x, ws + w.d_y[0], G_(h->enc_w[0]), G_(h->enc_b[0]), scw, sd, h->cfg.precision == 1, fuse0 ? fu : nullptr)); }
         } else {
             { ProbeArm pa(h, 2, l); RedArm ra(h, side_red, &red_pending, st); ra.arm(&sred);
@@ -483,10 +490,12 @@ int cvae_adam_step(cvae_handle h, float* params, const float* grads, float* exp_
 }
 
 int cvae_grads_to_bf16(cvae_handle h, const float* grads, void* out_bf16, int64_t n, void* stream) {
+    if (h && n == 0) return 0;                       // empty range (its pointers may be null): nothing to do
     if (!h || !grads || !out_bf16 || n < 0) { cvae_set_error("cvae_grads_to_bf16: bad argument"); return CVAE_EINVAL; }
     return launch_grads_bf16(grads, out_bf16, nullptr, n, (hipStream_t)stream);
 }
 int cvae_grads_from_bf16(cvae_handle h, const void* in_bf16, float* grads, int64_t n, void* stream) {
+    if (h && n == 0) return 0;
     if (!h || !grads || !in_bf16 || n < 0) { cvae_set_error("cvae_grads_from_bf16: bad argument"); return CVAE_EINVAL; }
     return launch_grads_bf16(nullptr, const_cast<void*>(in_bf16), grads, n, (hipStream_t)stream);
 }

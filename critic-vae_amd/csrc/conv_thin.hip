@@ -650,6 +650,7 @@ int launch_e1_fwd(int width, int B, const float* x, const float* w, const float*
     if (pass != 0 && !bf16) { cvae_set_error("e1_fwd: passes 1/2 exist in bf16 mode only"); return -2; }
     const int ns64 = B * 8, ns128 = B * 32, cap = 256 * 3;        // persistent: 3 workgroups per CU (VGPR-limited), one strip each per turn
     const dim3 g64(ns64 < cap ? ns64 : cap), g128(ns128 < cap ? ns128 : cap);
+    cvae_probe_begin(st);
     if (width == 64 && bf16 && pass == 1) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_STATS>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64);
     else if (width == 64 && bf16 && pass == 2) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_POOL>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64);
     else if (width == 128 && bf16 && pass == 1) hipLaunchKernelGGL((e1_fwd_bf16_kernel<128, E1_STATS>), g128, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns128);
@@ -659,6 +660,7 @@ int launch_e1_fwd(int width, int B, const float* x, const float* w, const float*
     else if (width == 64) hipLaunchKernelGGL(e1_fwd_kernel<64>, dim3(B * 8), dim3(256), 0, st, x, w, bias, y, bnpart, B);
     else if (width == 128) hipLaunchKernelGGL(e1_fwd_kernel<128>, dim3(B * 32), dim3(256), 0, st, x, w, bias, y, bnpart, B);
     else { cvae_set_error("e1_fwd: width %d unsupported", width); return -2; }
+    cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();
     return 0;
 }
@@ -671,11 +673,13 @@ int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw
     ThinWgradArgs a{x, dy, nullptr, nullptr, ws, B, tiles, tps};
     // fuse = {y0, a0, d_a0, coef0, bcoef0}: block 0's BatchNorm/pool/ReLU backward is applied while staging (no dy tensor)
     const E1Fuse fu = fuse ? E1Fuse{fuse[0], fuse[1], fuse[2], fuse[3], fuse[4]} : E1Fuse{};
+    cvae_probe_begin(st);
     if (bf16) {          // precision mode 1: transposed-read kernel, its own slab layout + a permuting finish
         if (width == 64 && fuse) hipLaunchKernelGGL((e1_wgrad_bf16_kernel<64, true>), dim3(S), dim3(256), 0, st, a, fu);
         else if (width == 64) hipLaunchKernelGGL((e1_wgrad_bf16_kernel<64, false>), dim3(S), dim3(256), 0, st, a, fu);
         else if (fuse) hipLaunchKernelGGL((e1_wgrad_bf16_kernel<128, true>), dim3(S), dim3(256), 0, st, a, fu);
         else hipLaunchKernelGGL((e1_wgrad_bf16_kernel<128, false>), dim3(S), dim3(256), 0, st, a, fu);
+        cvae_probe_end(st);
         CVAE_CHECK_LAUNCH();
         st = cvae_reduce_stream(st);
         float* red = ws + (size_t)S * E1W_ROW;
@@ -688,6 +692,7 @@ int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw
     else if (width == 64) hipLaunchKernelGGL((e1_wgrad_kernel<64, false>), dim3(S), dim3(256), 0, st, a, fu);
     else if (fuse) hipLaunchKernelGGL((e1_wgrad_kernel<128, true>), dim3(S), dim3(256), 0, st, a, fu);
     else hipLaunchKernelGGL((e1_wgrad_kernel<128, false>), dim3(S), dim3(256), 0, st, a, fu);
+    cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();
     st = cvae_reduce_stream(st);
     // slab row = [75 x 32 weights | 32 zeros (K pad) | 32 bias partials]: in the flat buffer enc0.b sits at
@@ -1146,11 +1151,13 @@ int64_t d4_bwd_ws_floats(int width, int B) {
 int launch_d4_fwd(int width, int B, const float* in, const float* w, const float* bias, float* recon, hipStream_t st, bool bf16io) {
     // 66 KB of LDS -> two workgroups per CU, each looping over its share of the 16x16 tiles
     const int tiles = B * (width / 16) * (width / 16), grid = tiles < 512 ? tiles : 512;
+    cvae_probe_begin(st);
     if (width == 64 && bf16io) hipLaunchKernelGGL(d4_fwd_bf16_kernel<64>, dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
     else if (width == 128 && bf16io) hipLaunchKernelGGL(d4_fwd_bf16_kernel<128>, dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
     else if (width == 64) hipLaunchKernelGGL((d4_fwd_kernel<64, float>), dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
     else if (width == 128) hipLaunchKernelGGL((d4_fwd_kernel<128, float>), dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
     else { cvae_set_error("d4_fwd: width %d unsupported", width); return -2; }
+    cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();
     return 0;
 }
@@ -1171,7 +1178,9 @@ int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const
                                               : (bf16io ? d4_bwd_bf16_kernel<128> : d4_bwd_kernel<128, float>);
     const int smem_bytes = bf16io ? D4_BWD_BF16_SMEM : D4_BWD_SMEM;
     { int rc = cvae_grant_lds(once[(width == 128) * 2 + bf16io], reinterpret_cast<const void*>(kern), smem_bytes); if (rc) return rc; }
+    cvae_probe_begin(st);
     hipLaunchKernelGGL(kern, dim3(S), dim3(256), smem_bytes, st, a);
+    cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();
     float* red = plane_sums + align_up((int64_t)B * 3, 64);
     { int rc = launch_col_reduce(ws, S, 3072, 3072, red, red + 3072, st); if (rc) return rc; }

@@ -568,7 +568,9 @@ static int ms_fwd(const MsFwdArgs& a, hipStream_t st) {
     using T = MsT<S>;
     static DeviceOnce once;
     { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(msssim_fwd_kernel<S>), T::SMEM); if (rc) return rc; }
+    if (a.ticket) cvae_probe_begin(st);                 // level 0 only (the launch that also zeroes the ticket)
     hipLaunchKernelGGL(msssim_fwd_kernel<S>, dim3(a.P * T::TILES), dim3(MS_NT), T::SMEM, st, a);
+    if (a.ticket) cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();
     return 0;
 }

@@ -38,6 +38,7 @@ class _ForwardFn(torch.autograd.Function):
         if vae.training:
             vae.num_batches_tracked += 1
         ctx.vae = vae
+        ctx.ws_generation = vae._stamp_workspace()     # the saved activations live in the ONE shared workspace
         ctx.save_for_backward(x, pred, eps, theta, logvar, recon)
         ctx.mark_non_differentiable()
         return mu, logvar, recon
@@ -45,6 +46,12 @@ class _ForwardFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_mu, d_logvar, d_recon):
         vae = ctx.vae
+        if ctx.ws_generation != vae._ws_generation:
+            raise RuntimeError(
+                "critic_vae_amd: backward() of a forward whose saved activations have been overwritten — another "
+                "forward / encoder / decoder call of the same VariationalAutoencoder ran in between (activations are "
+                "kept in one shared workspace, not per autograd graph). Run backward before the next forward, or use a "
+                "second VariationalAutoencoder for evaluation.")
         x, pred, eps, theta, logvar, recon = ctx.saved_tensors
         B = x.shape[0]
         d_mu = torch.zeros_like(logvar) if d_mu is None else d_mu.contiguous()
@@ -167,9 +174,14 @@ class VariationalAutoencoder(nn.Module):
         self.decoder = Decoder(self)
         self.mssim_loss = MSSIM(self)
         self._ws = None
+        self._ws_generation = 0            # bumped by every call that writes activations into the workspace
         self.last_scalars = None
 
     # ---- plumbing ----
+    def _stamp_workspace(self):
+        self._ws_generation += 1
+        return self._ws_generation
+
     def _workspace(self, B):
         if B > self.max_batch:
             raise ValueError(f"batch {B} > max_batch {self.max_batch}")
@@ -216,6 +228,7 @@ class VariationalAutoencoder(nn.Module):
         with torch.no_grad():
             self.handle.forward(B, x, pred0, z, self.theta, self.bn_state, mu, logvar, None, self._workspace(B),
                                 train=self.training)
+            self._stamp_workspace()
             if self.training:
                 self.num_batches_tracked += 1
         return mu, logvar
@@ -225,6 +238,7 @@ class VariationalAutoencoder(nn.Module):
         recon = torch.empty(B, P.ch, self.width, self.width, device=zcat.device)
         with torch.no_grad():
             self.handle.decode(B, zcat, self.theta, recon, self._workspace(B))
+            self._stamp_workspace()
         return recon
 
     # ---- reference API ----

@@ -22,22 +22,41 @@ from . import synth
 from .nets import VariationalAutoencoder
 
 
+def _reference_batches(dset, epoch_indices, starts, batch_size, device, critic_fn):
+    """vae.py:46-50 as the reference does it: gather, fp32 copy to the device, critic — all synchronous."""
+    for b in starts:
+        images = torch.from_numpy(dset[epoch_indices[b:b + batch_size]]).to(device=device, dtype=torch.float32)
+        yield images, critic_fn(images)
+
+
 def train(autoencoder, dset, critic_fn, device, epochs=P.epochs, batch_size=P.batch_size, lr=P.lr,
           log_n=None, log=print):
-    """vae.py:33-66.  `dset`: list/array of (1,3,w,w) or (3,w,w) float frames in [0,1];
-    `critic_fn(images) -> (B,1)` stands in for critic.evaluate (vae.py:50)."""
-    dset = np.stack(dset).squeeze()
+    """vae.py:33-66.  `dset`: list/array of (1,3,w,w) or (3,w,w) float frames in [0,1] — the reference's own
+    host-side format: every batch is converted and copied synchronously, as vae.py:46-48 does — OR one uint8
+    array (N,w,w,3), the frames as the environment delivers them: batches then come through FrameFeeder
+    (pinned double buffer, H2D on a side stream, uint8 -> fp32 CHW/255 and the critic on the GPU, batch i+1
+    in flight under step i).  `critic_fn(images) -> (B,1)` stands in for critic.evaluate (vae.py:50); with
+    uint8 input it may also be a critic_vae_amd.critic.Critic."""
+    u8 = isinstance(dset, np.ndarray) and dset.dtype == np.uint8
+    if not u8:
+        dset = np.stack(dset).squeeze()
     opt = torch.optim.Adam(autoencoder.parameters(), lr=lr)
     num_samples = dset.shape[0]
     log_n = log_n if log_n is not None else batch_size * 30
     history = []
+    feeder = None
+    if u8:
+        from .feeder import FrameFeeder
+        feeder = FrameFeeder(dset, batch_size, device, autoencoder.handle, critic=critic_fn)
     for ep in range(epochs):
         epoch_indices = np.arange(num_samples)
         np.random.shuffle(epoch_indices)
-        for batch_i in range(0, num_samples, batch_size):
-            batch_indices = epoch_indices[batch_i:batch_i + batch_size]     # tail batch is kept (vae.py:44-46)
-            images = torch.from_numpy(dset[batch_indices]).to(device=device, dtype=torch.float32)
-            preds = critic_fn(images)
+        starts = range(0, num_samples, batch_size)                              # tail batch is kept (vae.py:44-46)
+        if feeder is not None:
+            stream = feeder.batches([epoch_indices[b:b + batch_size] for b in starts])
+        else:
+            stream = _reference_batches(dset, epoch_indices, starts, batch_size, device, critic_fn)
+        for batch_i, (images, preds) in zip(starts, stream):
             opt.zero_grad()
             out = autoencoder(images, preds)
             losses = autoencoder.vae_loss(out[0], out[1], out[2], out[3])
@@ -54,8 +73,10 @@ class FusedTrainer:
     """One training step = forward + loss + backward + all-reduce + Adam on flat buffers."""
 
     def __init__(self, vae, lr=P.lr, betas=P.adam_betas, eps=P.adam_eps, process_group=None, world_size=1,
-                 overlap=None, reduce_dtype=None):
-        """overlap: all-reduce the gradient in three buckets while backward still runs (default for
+                 overlap=None, reduce_dtype=None, sync=True):
+        """Construction with world_size > 1 is a COLLECTIVE (sync_replicas: five broadcasts from rank 0) unless
+        sync=False.
+        overlap: all-reduce the gradient in three buckets while backward still runs (default for
         world_size > 1; CVAE_DP_OVERLAP=0 or overlap=False = one all-reduce after backward).
         reduce_dtype: "f32" (default; the contract of SURVEY 8e: reduced gradient == mean of the shard gradients
         within 1e-4) or "bf16" (CVAE_DP_REDUCE=bf16): the wire format of the all-reduce is bf16 — half the bytes,
@@ -92,7 +113,12 @@ class FusedTrainer:
         self.exposed_ms = []              # measure_exposed: device time the compute stream spent waiting for the all-reduce
         self.measure_exposed = False
         self._ev = None
-        if world_size > 1:
+        if world_size > 1 and sync:
+            if not torch.distributed.is_initialized():
+                raise RuntimeError("FusedTrainer(world_size > 1) broadcasts rank 0's replica at construction (a COLLECTIVE: "
+                                   "every rank must construct its trainer, in the same order): call "
+                                   "torch.distributed.init_process_group / critic_vae_amd.dp.init() first, or pass "
+                                   "sync=False and call sync_replicas() yourself")
             self.sync_replicas()
 
     def sync_replicas(self, src=0):
@@ -111,6 +137,7 @@ class FusedTrainer:
         """x (B,3,w,w), pred (B,1), eps (B,32): contiguous fp32 device tensors."""
         v, h, B = self.vae, self.h, x.shape[0]
         theta = v.theta.data
+        v._stamp_workspace()               # an autograd graph of the same VAE still pending is now stale (nets.py)
         h.forward(B, x, pred, eps, theta, v.bn_state, self.mu, self.logvar, self.recon, self.ws, train=True)
         h.loss(B, x, self.mu, self.logvar, self.recon, self.ws, self.scalars, self.d_recon, self.d_mu, self.d_logvar)
         if self.world_size > 1 and self.overlap:
@@ -151,6 +178,23 @@ class FusedTrainer:
         return self.scalars
 
 
+    def fit_u8(self, frames_u8, critic, batch_size, epochs=1, generator=None, shuffle=True):
+        """The `-train` loop (vae.py:40-58) over a host uint8 dataset (N,w,w,3), fused step + overlapped feeder:
+        batch i+1 is gathered, copied (pinned, side stream) while step i computes; uint8 -> fp32 CHW/255 and the
+        critic run on the GPU.  eps ~ N(0,1) from `generator` (device).  Returns the loss scalars of the last step."""
+        from .feeder import FrameFeeder
+        dev = self.vae.theta.device
+        feeder = FrameFeeder(frames_u8, batch_size, dev, self.h, critic=critic)
+        n, scal = frames_u8.shape[0], None
+        for _ in range(epochs):
+            idx = np.arange(n)
+            if shuffle:
+                np.random.shuffle(idx)
+            for images, preds in feeder.batches([idx[b:b + batch_size] for b in range(0, n, batch_size)]):
+                eps = torch.randn(images.shape[0], P.latent_dim, device=dev, generator=generator)
+                scal = self.step(images, preds, eps)
+        return scal
+
     # time between "backward is done" and "the reduced gradient is usable" on the compute stream = the part
     # of the all-reduce that backward did not hide (bench.py: allreduce_exposed_us)
     def _exposed_begin(self):
@@ -162,6 +206,8 @@ class FusedTrainer:
         if self.measure_exposed:
             self._ev[1].record()
             self.exposed_ms.append(self._ev)
+            if len(self.exposed_ms) > 1024:          # ring: a long run without exposed_us() keeps the newest samples only
+                del self.exposed_ms[:512]
 
     def exposed_us(self):
         """Mean exposed all-reduce time per step (µs) over the steps taken with measure_exposed; syncs."""

@@ -176,8 +176,10 @@ int64_t cvae_ws_offset(cvae_handle h, int32_t batch, const char* name);
 /*
  * In-step kernel probe (measurement only): bit (kind*9 + layer) of `mask` arms a HIP event pair
  * around that conv kernel (kind 0 forward, 1 dgrad, 2 wgrad; layer 1..7) inside cvae_forward /
- * cvae_backward, recorded on the stream the kernel is launched on; bits 27..30 arm the
- * BatchNorm+pool backward apply kernel of encoder block 0..3 (the step's largest HBM-bound kernel).  cvae_probe_read returns the
+ * cvae_backward, recorded on the stream the kernel is launched on.  HBM-side kernels: bit 0 = E1 forward
+ * (in bf16 mode the BatchNorm/pool pass), bit 18 = E1 weight gradient (with block 0's fused BatchNorm backward),
+ * bit 8 = D4 forward, bit 17 = the fused D4 backward, bits 27..30 = the BatchNorm+pool backward apply kernel of
+ * encoder block 0..3, bit 31 = the MS-SSIM level-0 tile kernel (inside cvae_loss).  cvae_probe_read returns the
  * elapsed milliseconds of each recorded launch (host array) and clears the slot.
  */
 int cvae_probe_config(cvae_handle h, uint32_t mask);

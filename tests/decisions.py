@@ -20,6 +20,11 @@ TIE_TOL = 1e-5          # |difference to a tie| of a flipped unit, in units of t
 
 
 def hip_decisions(vae, B):
+    """Max-pool / ReLU decisions the HIP step actually took, read from what its kernels WROTE: the pooled output a_l
+    is matched against the four candidates of its window (the first candidate whose value the kernel stored is the
+    window's first maximum), so a kernel whose normalisation expression differed from the candidates recomputed here
+    would leave windows without any matching candidate — asserted below — instead of silently imposing decisions the
+    kernel never made."""
     ws, h, k = vae._workspace(B), vae.handle, vae.width // 64
 
     def view(name, c, s):
@@ -29,11 +34,33 @@ def hip_decisions(vae, B):
     for l, (c, s) in enumerate(ENC):
         s *= k
         y = view(f"y{l}", c, s).double()
+        a = view(f"a{l}", c, s // 2)
         coef = h.ws_view(ws, B, f"coef{l}", c * 4).view(c, 4).double()
-        # the kernels take the first maximum of fmaf(y, scale, shift): the correctly rounded fp32 value
+        # candidates: fmaf(y, scale, shift), i.e. the correctly rounded fp32 value of y*scale + shift
         n = (y * coef[:, 0].view(1, c, 1, 1) + coef[:, 1].view(1, c, 1, 1)).float()
-        dec[f"pool{l}"] = F.max_pool2d(n, 2, return_indices=True)[1].cpu()
-        dec[f"relu_enc{l}"] = (view(f"a{l}", c, s // 2) > 0).cpu()
+        cand = torch.stack([n[:, :, dy::2, dx::2] for dy in (0, 1) for dx in (0, 1)], dim=-1)       # scan order
+        host_first = cand.argmax(dim=-1)                       # torch.argmax: index of the first maximal value
+        if l < 3:                                              # ReLU blocks: a = max(max_p n_p, 0), stored exactly
+            au = a.unsqueeze(-1)
+            ulp = (torch.nextafter(au.abs(), torch.full_like(au, float("inf"))) - au.abs())
+            # exact match preferred; one ulp allowed because the candidates here are double products rounded twice
+            # (to double, then to float), which differs from the kernel's single-rounding fmaf once in ~2^30 values
+            hit = 2.0 * (cand == au).float() + ((cand - au).abs() <= ulp).float()
+            live = a > 0                                       # a == 0: the gradient is masked, the decision is moot
+            assert bool((hit.max(-1).values > 0)[live].all()), f"block {l}: a pooled output equals none of its window's candidates"
+            pos = torch.where(live, hit.argmax(dim=-1), host_first)
+            top = cand.max(-1).values
+            assert bool((cand.gather(-1, pos.unsqueeze(-1)).squeeze(-1) >= top - ulp.squeeze(-1))[live].all()), \
+                f"block {l}: the stored value is not the window maximum"
+        else:                                                  # Tanh block: a = tanh(max); tanh is monotone, compare in value
+            pos = host_first
+            err = (torch.tanh(cand.max(-1).values.double()) - a.double()).abs().max().item()
+            assert err < 2e-6, f"block 3: a3 is not tanh(max of the window candidates): {err:.2e}"
+        wo = s // 2
+        oy = torch.arange(wo, device=pos.device).view(1, 1, wo, 1)
+        ox = torch.arange(wo, device=pos.device).view(1, 1, 1, wo)
+        dec[f"pool{l}"] = ((2 * oy + pos // 2) * s + 2 * ox + pos % 2).cpu()     # flat index in the (s x s) plane, as max_pool2d returns
+        dec[f"relu_enc{l}"] = (a > 0).cpu()
     for i, (c, s) in enumerate(DEC):
         dec[f"relu_dec{i}"] = (view(f"o{i}", c, s * k) > 0).cpu()
     return dec

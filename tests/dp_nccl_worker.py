@@ -17,7 +17,9 @@ from critic_vae_amd.train import FusedTrainer             # noqa: E402
 
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
-dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29561", rank=0, world_size=1, device_id=dev)
+import tempfile                                           # noqa: E402
+_store = os.path.join(tempfile.mkdtemp(prefix="cvae_dp_"), "store")      # file rendezvous: no TCP port to collide on
+dist.init_process_group(backend="nccl", init_method="file://" + _store, rank=0, world_size=1, device_id=dev)
 B = 8
 x, pred, eps = (torch.from_numpy(a).to(dev) for a in synth.make_batch(1234, 0, B))
 
@@ -37,6 +39,13 @@ tr2.world_size, tr2.overlap = 2, True
 tr2.step(x, pred, eps)
 torch.cuda.synchronize()
 assert torch.equal(tr2.grads, ref.grads), "bucketed RCCL path changed the gradient"
+# the optional bf16 wire format over RCCL: one rank, so the reduced gradient is exactly the bf16 rounding of the fp32 one
+tr3 = FusedTrainer(VariationalAutoencoder(max_batch=B, seed=0).to(dev), reduce_dtype="bf16", sync=False)
+tr3.world_size, tr3.overlap = 2, True
+tr3.grads16 = torch.empty(tr3.grads.numel(), dtype=torch.bfloat16, device=dev)
+tr3.step(x, pred, eps)
+torch.cuda.synchronize()
+assert torch.equal(tr3.grads, ref.grads.to(torch.bfloat16).float()), "bf16 bucket all-reduce over RCCL is not RNE(g)"
 t = torch.arange(1000, device=dev, dtype=torch.float32)
 w = dist.all_reduce(t[100:600], async_op=True)
 w.wait()

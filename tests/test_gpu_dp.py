@@ -11,12 +11,45 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_two_rank_step_bucketed_overlap_and_single_allreduce():
     env = dict(os.environ, CVAE_DIST_BACKEND="gloo", CVAE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29541",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1",
+                        "--nnodes=1", "--nproc-per-node=2",            # --standalone: torchrun picks a free rendezvous port
                         os.path.join(ROOT, "tests", "dp_gpu_worker.py")], capture_output=True, text=True, timeout=600,
                        cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "DP_GPU_OK rank 0" in r.stdout and "DP_GPU_OK rank 1" in r.stdout
+
+
+def test_bf16_gradient_pack_is_rne_and_exact_back():
+    """cvae_grads_to_bf16 == torch's fp32 -> bfloat16 cast (round to nearest even) bit for bit — NaN, infinities, zeros,
+    subnormals and exact midpoints included — also on a bucket slice; cvae_grads_from_bf16 is exact."""
+    import torch
+    from critic_vae_amd.lib import Handle
+    dev = torch.device("cuda:0")
+    h = Handle(64, 4)
+    g = torch.Generator(device=dev).manual_seed(3)
+    n = 1 << 16
+    v = torch.randn(n, device=dev, generator=g) * torch.exp(torch.randn(n, device=dev, generator=g) * 8)
+    special = torch.tensor([0.0, -0.0, float("inf"), float("-inf"), float("nan"), 1e-40, -1e-40, 3.0e38, -3.0e38,
+                            1.00390625, 1.01171875, -1.00390625, 65280.0 * 2.0 ** 112, 1.0 + 2.0 ** -8 + 2.0 ** -20], device=dev)
+    v[:special.numel()] = special                      # 1.00390625 = 1 + 2^-8: an exact midpoint (ties to even -> 1.0)
+    out = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    h.grads_to_bf16(v, out)
+    want = v.to(torch.bfloat16)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16)[~torch.isnan(v)], want.view(torch.int16)[~torch.isnan(v)])
+    assert torch.isnan(out.float()[torch.isnan(v)]).all()
+    back = torch.empty(n, device=dev)
+    h.grads_from_bf16(out, back)
+    torch.cuda.synchronize()
+    ok = ~torch.isnan(v)
+    assert torch.equal(back[ok], want.float()[ok])
+    # a bucket slice (offset and length multiples of 64, as cvae_grad_bucket returns them)
+    out2 = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    h.grads_to_bf16(v[4096:12288], out2[4096:12288])
+    torch.cuda.synchronize()
+    assert torch.equal(out2[4096:12288].view(torch.int16)[ok[4096:12288]], want[4096:12288].view(torch.int16)[ok[4096:12288]])
+    assert not out2[:4096].any() and not out2[12288:].any()
+    h.grads_to_bf16(v[:0], out2[:0])                   # empty range: a no-op, not an invalid launch
 
 
 def test_phased_backward_equals_single_call():

@@ -74,8 +74,8 @@ def test_two_handles_do_not_share_state():
 def test_data_parallel_two_ranks_gloo():
     """N-rank all-reduced gradient == mean over ranks of the single-rank (oracle) gradient on that
     rank's shard, through the same flat native buffer the GPU path reduces."""
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29531",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1",
+                        "--nnodes=1", "--nproc-per-node=2",           # --standalone: torchrun picks a free rendezvous port
                         os.path.join(ROOT, "tests", "dp_worker.py")], capture_output=True, text=True, timeout=600,
                        cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

@@ -276,7 +276,10 @@ int cvae_forward(cvae_handle h, int32_t B, const float* x, const float* pred, co
             RC(launch_bn_fwd_finalize(0, W, B, ws + w.bnpart[0], P_(h->enc_g[0]), P_(h->enc_be[0]), bn_state + kBnOff[0],
                                       bn_state + 480 + kBnOff[0], ws + w.coef[0], ws + w.scratch, train, st));
             { ProbeArm pa(h, 0, 0);
-              RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], nullptr, st, true, 2, ws + w.coef[0], ws + w.a[0])); }
+              // y0 is written only for the CVAE_FUSE_E1=0 path (or, decided on the device, when a channel's gamma is tiny):
+              // the fused weight-gradient kernel recomputes it
+              RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], nullptr, st, true, 2, ws + w.coef[0], ws + w.a[0],
+                               !h->fuse_e1)); }
             continue;
         }
         if (l == 0) { ProbeArm pa(h, 0, 0); RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], ws + w.bnpart[0], st, h->cfg.precision == 1)); }
@@ -466,7 +469,8 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
                                     fuse0 ? nullptr : ws + w.d_y[l], G_(h->enc_g[l]), G_(h->enc_be[l]), nullptr, sc, st, io_bf16(h))); }
         RC(fork(7 - l));
         if (l == 0) {
-            const float* fu[5] = {ws + w.y[0], ws + w.a[0], ws + w.d_a[0], ws + w.coef[0], bn_bwd_bcoef(0, W, B, sc)};
+            const float* fu[7] = {ws + w.y[0], ws + w.a[0], ws + w.d_a[0], ws + w.coef[0], bn_bwd_bcoef(0, W, B, sc),
+                                  P_(h->enc_w[0]), P_(h->enc_b[0])};
             { ProbeArm pa(h, 2, 0); RedArm ra(h, side_red, &red_pending, st); ra.arm(&sred);
               RC(launch_e1_wgrad(W, B, x, ws + w.d_y[0], G_(h->enc_w[0]), G_(h->enc_b[0]), scw, sd, h->cfg.precision == 1, fuse0 ? fu : nullptr)); }
         } else {
@@ -567,7 +571,7 @@ int cvae_probe_read(cvae_handle h, int32_t id, float* ms_host, int32_t cap) {
 int cvae_op_conv_fwd(cvae_handle h, int32_t layer, int32_t B, const float* in, const float* wt, const float* bias,
                      float* out, float* bn_partials, void* scratch, void* stream) {
     const int W = h->cfg.width;
-    if (layer == 0) return launch_e1_fwd(W, B, in, wt, bias, out, bn_partials, (hipStream_t)stream);
+    if (layer == 0) return launch_e1_fwd(W, B, in, wt, bias, out, bn_partials, (hipStream_t)stream, io_bf16(h));   // y in the handle's storage type
     if (layer == 8) return launch_d4_fwd(W, B, in, wt, bias, out, (hipStream_t)stream);
     if (layer >= 5) {
         float* wc = (float*)scratch;

@@ -121,16 +121,19 @@ __global__ __launch_bounds__(256) void e1_fwd_kernel(const float* __restrict__ x
 // step's MFMA work, the tensor it produces is the step's largest):
 //   E1_Y     : y1 + BatchNorm partials (the stand-alone conv op).
 //   E1_STATS : BatchNorm partials only — nothing but x is read, 2 x 32 floats per strip are written.
-//   E1_POOL  : after the statistics are merged: y1 again (the backward still reads it), and on the bf16-rounded values,
-//              exactly as bn_pool_act_fwd_bf16_kernel<0> would compute from the stored tensor, scale/shift -> first
-//              maximum of each 2x2 window in scan order -> ReLU -> a1.  Replaces that kernel's read of y1
-//              (B*H*H*32*2 bytes) by a second read of x (B*H*H*3*4 bytes).
+//   E1_POOL  : after the statistics are merged: on the bf16-rounded conv values, exactly as bn_pool_act_fwd_bf16_kernel<0>
+//              would compute from a stored y1, scale/shift -> first maximum of each 2x2 window in scan order -> ReLU -> a1.
+//              y1 ITSELF IS NOT WRITTEN (round 3): the only reader left in the step, E1's weight-gradient kernel, runs the
+//              75-tap conv a third time on the tile it stages (e1_wgrad_bf16_kernel<H, true>) — B*H*H*32*2 bytes less
+//              written here and read there (1.07 GB per step at B = 2048).  Exceptions: keepY != 0 (the CVAE_FUSE_E1=0
+//              A/B path, whose separate apply pass reads y1), and steps in which a channel has |gamma| < 1e-2: the
+//              BatchNorm-backward statistics kernel then takes xhat of that channel from y1 (bn.hip).
 enum { E1_Y = 0, E1_STATS = 1, E1_POOL = 2 };
 template <int H, int PASS>
 __global__ __launch_bounds__(256) void e1_fwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           float* __restrict__ bnpart, int B,
-                                                          const float* __restrict__ coef, float* __restrict__ a1, int numStrips) {
+                                                          const float* __restrict__ coef, float* __restrict__ a1, int numStrips, int keepY) {
     constexpr int SR = 16, SW = 32, HR_ = SR + 4, HWX = 40;
     constexpr int SX = H / SW, SY = H / SR;
     __shared__ __attribute__((aligned(16))) bf16x4 lds_x[HR_ * HWX];
@@ -150,6 +153,11 @@ __global__ __launch_bounds__(256) void e1_fwd_bf16_kernel(const float* __restric
                 bw[r][kb][j] = (__bf16)((sI < 5 && c < 3) ? w[((r * 5 + sI) * 3 + c) * 32 + li] : 0.f);
             }
     const float bv = bias[li];
+    bool wr_y = PASS != E1_STATS;
+    if constexpr (PASS == E1_POOL) {
+        const float gam = coef[li * 4] / coef[li * 4 + 3];             // gamma = scale / invstd, as bn.hip's backward tests it
+        wr_y = keepY != 0 || __any(!(fabsf(gam) >= 1e-2f));           // the same answer in every wave (a wave spans all 32 channels)
+    }
     constexpr int NIT = (HR_ * HWX + 255) / 256;
     float v0[NIT], v1[NIT], v2[NIT];
     auto fetch = [&](int strip) {                // all loads first (clamped address + select), the LDS writes follow later
@@ -203,9 +211,9 @@ __global__ __launch_bounds__(256) void e1_fwd_bf16_kernel(const float* __restric
                 const float val = acc[r][v] + bv;
                 acc[r][v] = val;
                 s += val;
-                if (PASS != E1_STATS) patch[((v & 3) + 8 * (v >> 2) + 4 * lh) * 36 + li] = val;
+                if (wr_y) patch[((v & 3) + 8 * (v >> 2) + 4 * lh) * 36 + li] = val;
             }
-            if (PASS == E1_STATS) continue;
+            if (!wr_y) continue;
             const int gy = ty0 + wave * 4 + r;
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
@@ -270,7 +278,8 @@ __global__ __launch_bounds__(256) void e1_fwd_bf16_kernel(const float* __restric
 }
 
 struct ThinWgradArgs {
-    const float* a0;     // E1: x (NCHW)          D4: dOut planes (NCHW)
+    const float* a0;     // E1: x (NCHW)          D4: dOut planes (NCHW); bf16 mode: d_recon (the Tanh backward is applied while staging)
+    const float* a2;     //                       D4, bf16 mode: recon (NCHW)
     const float* a1;     // E1: dy (NHWC, 32)     D4: o3 (NHWC, 32)
     const float* w;      // D4: W4 [25][32][3]
     float* din;          // D4: d_o3 (NHWC, 32)
@@ -316,7 +325,7 @@ __device__ __forceinline__ void thin_slab_out(f32x16 (&acc)[3], float* red, floa
 // per 2x2 window and channel, dy[p] = scale*((p == argmax ? g : 0) - k1 - xhat[p]*k2) with g = da*[a > 0],
 // xhat = (y - mean)*invstd and (k1, k2) = bcoef — the arithmetic of bn_bwd_kernel<0,1>, so the result is the
 // same to the bit; the step saves one write and one read of the largest activation gradient (B x 64 x 64 x 32).
-struct E1Fuse { const float *y, *a, *da, *coef, *bcoef; };
+struct E1Fuse { const float *y, *a, *da, *coef, *bcoef, *w, *bias; };     // w, bias: E1's conv parameters (bf16 mode recomputes y)
 
 // tile mt of E1 wgrad into registers: x halo (3 planes, zero padded) and the 128x32 dy tile
 // (FUSE: thread = (channel quad, window column, window row): the window's four y quads in rd, a and da quads in rf)
@@ -455,21 +464,33 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a, E1Fuse f
 
 // precision mode 1, E1 weight gradient.  GEMM per kernel row r: dW_r[m = 4s + c][co] = sum_px P_r[px][m] * dy[px][co]
 // with P_r[px][m] = x[c][y + r - 2][px + s - 2].  The frame strip is staged as bf16 pixels of 4 channels (as in the
-// forward), so P_r is an OVERLAPPED row-major view of it (row px starts 4 elements after row px-1) and both MFMA
-// operands are transposed LDS reads (ds_read_b64_tr_b16) — no per-element gather, no conversion in the loop.
+// forward), so P_r is an OVERLAPPED row-major view of it (row px starts 4 elements after row px-1) and the A operand
+// is a transposed LDS read (ds_read_b64_tr_b16) — no per-element gather, no conversion in the loop.
 // Wave w owns tile row w (32 pixels, 2 k-steps): 10 MFMAs + 2 for the bias row (ones x dy) per tile.
 // Slab row of a workgroup: [5 kernel rows][32 m][32 co] (m >= 20 and c == 3 are padding) | bias[32] = 5152 floats.
 static constexpr int E1W_ROW = 5 * 32 * 32 + 32;
-// FUSE (see E1Fuse): thread = (channel quad, window column, window row); y / a / da arrive as 8-byte bf16 quads and
-// dy = (p == argmax ? g*scale : 0) - (A + Bc*y) with Bc = scale*k2*invstd, A = scale*k1 - Bc*mean — the apply pass's
-// formula with the per-channel constants folded (this kernel is issue-bound: ~7 VALU instructions per element).
+// FUSE (see E1Fuse), round 3: dy of block 0 is produced HERE from x, a0 and d_a0 alone — y1 is not read, it is not even
+// stored by the forward any more.  Per tile (4 rows x 32 columns):
+//   1. each wave runs the forward's 75-tap conv (10 bf16 MFMAs, the forward's operand fragments and accumulation
+//      order: the fp32 sums, hence the bf16-rounded y values and the window argmax, are the forward's to the bit) on
+//      its 2-row x 16-column quadrant: accumulator element v of lane (li, lh) is channel li of quadrant pixel
+//      m = (v&3) + 8(v>>2) + 4lh = (row m>>4, column m&15), so the four values of a 2x2 pooling window are elements
+//      v, v+1, v+8, v+9 of ONE lane;
+//   2. in the lane: yb = bf16(acc + bias); first maximum of fmaf(yb, scale, shift) in scan order;
+//      dy[p] = (p == argmax ? g*scale : 0) - (A + Bc*yb[p]) with g = d_a0*[a0 > 0], Bc = scale*k2*invstd,
+//      A = scale*k1 - Bc*mean (the apply pass's formula with the per-channel constants folded); a0 / d_a0 tiles arrive
+//      by one 16-byte load per thread, a tile ahead, and are picked up per (window, channel) from LDS;
+//   3. dy goes to LDS CHANNEL-major ([co][tile pixel], 8-byte stores of 4 consecutive pixels), so the B operand of the
+//      weight-gradient MFMA (8 consecutive pixels of one channel) is a plain 16-byte read.
+static constexpr int E1W_DT = 136;          // row stride of the channel-major dy tile in elements (68 dwords: conflict-free 16-byte reads)
 template <int H, bool FUSE>
 __global__ __launch_bounds__(256) void e1_wgrad_bf16_kernel(ThinWgradArgs a, E1Fuse fu) {
     using T = Tile<H>;
     static_assert(T::TW == 32 && T::TH == 4 && T::IMGS == 1, "one tile row per wave");
     constexpr int HWX = 40, HR_ = T::TH + 4, NPXH = HR_ * HWX;
     __shared__ __attribute__((aligned(16))) bf16x4 lds_x[NPXH + 8];
-    __shared__ __attribute__((aligned(16))) __bf16 lds_d[128 * 32];
+    __shared__ __attribute__((aligned(16))) __bf16 lds_d[FUSE ? 32 * E1W_DT : 128 * 32];     // FUSE: [co][E1W_DT]; else [px][32]
+    __shared__ __attribute__((aligned(16))) __bf16 lds_p[FUSE ? 2 * 32 * 32 : 8];             // FUSE: a0 | d_a0 tiles [pooled px][32]
     __shared__ float red[3 * 1024];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int g = lane >> 4, h = g >> 1, qrow = (lane & 15) >> 2, cb = 16 * (g & 1) + 4 * (lane & 3);
@@ -487,17 +508,25 @@ __global__ __launch_bounds__(256) void e1_wgrad_bf16_kernel(ThinWgradArgs a, E1F
     constexpr int XQ = (NPXH + 255) / 256;
     float rx[XQ][3];
     bf16x8 rd[2];
-    bf16x4 ry[4], ra, rg;                            // FUSE: the window's y quads, a and da
-    float bsc[4], bsh[4], bA[4], bB[4];
+    bf16x8 rp;                                       // FUSE: 8 channels of one pooled pixel of a0 (threads 0..127) / d_a0 (128..255)
+    // FUSE: the forward's B operand (e1_fwd_bf16_kernel): B[k = 16kb + 8lh + j][n = li] of kernel row r, k = 4*s + c
+    bf16x8 bw[FUSE ? 5 : 1][2];
+    float bv = 0.f, bsc = 0.f, bsh = 0.f, bA = 0.f, bB = 0.f;         // this lane's channel li
     if constexpr (FUSE) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = (tid & 7) * 4 + e;
-            const float sc = fu.coef[c * 4], mean = fu.coef[c * 4 + 2], invstd = fu.coef[c * 4 + 3];
-            bsc[e] = sc; bsh[e] = fu.coef[c * 4 + 1];
-            bB[e] = sc * fu.bcoef[c * 2 + 1] * invstd;
-            bA[e] = sc * fu.bcoef[c * 2] - bB[e] * mean;
-        }
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * kb + 8 * lh + j, sI = k >> 2, c = k & 3;
+                    bw[r][kb][j] = (__bf16)((sI < 5 && c < 3) ? fu.w[((r * 5 + sI) * 3 + c) * 32 + li] : 0.f);
+                }
+        bv = fu.bias[li];
+        const float sc = fu.coef[li * 4], mean = fu.coef[li * 4 + 2], invstd = fu.coef[li * 4 + 3];
+        bsc = sc; bsh = fu.coef[li * 4 + 1];
+        bB = sc * fu.bcoef[li * 2 + 1] * invstd;
+        bA = sc * fu.bcoef[li * 2] - bB * mean;
     }
     auto fetch = [&](int mt) {
         const int ib = mt / T::TILES_PER_IMG, tileInImg = mt % T::TILES_PER_IMG;
@@ -512,12 +541,9 @@ __global__ __launch_bounds__(256) void e1_wgrad_bf16_kernel(ThinWgradArgs a, E1F
             rx[i][0] = ok ? v0 : 0.f; rx[i][1] = ok ? v1 : 0.f; rx[i][2] = ok ? v2 : 0.f;
         }
         if constexpr (FUSE) {
-            const int c4 = tid & 7, gy = ty0 + 2 * (tid >> 7), gx = tx0 + 2 * ((tid >> 3) & 15);
-#pragma unroll
-            for (int p = 0; p < 4; ++p) ry[p] = Act<__bf16>::ld4raw(fu.y, ((size_t)(ib * H + gy + (p >> 1)) * H + gx + (p & 1)) * 32 + c4 * 4);
-            const size_t pe = ((size_t)(ib * (H / 2) + gy / 2) * (H / 2) + gx / 2) * 32 + c4 * 4;
-            ra = Act<__bf16>::ld4raw(fu.a, pe);
-            rg = Act<__bf16>::ld4raw(fu.da, pe);
+            const int t = tid & 127, pp = t >> 2, c8 = t & 3;            // pooled pixel pp = prow*16 + pcol of the tile's 2 x 16
+            const size_t pe = ((size_t)(ib * (H / 2) + ty0 / 2 + (pp >> 4)) * (H / 2) + tx0 / 2 + (pp & 15)) * 32 + c8 * 8;
+            rp = Act<__bf16>::ld8(tid < 128 ? fu.a : fu.da, pe);
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -537,42 +563,71 @@ __global__ __launch_bounds__(256) void e1_wgrad_bf16_kernel(ThinWgradArgs a, E1F
             if (q < NPXH) { bf16x4 u; u[0] = (__bf16)rx[i][0]; u[1] = (__bf16)rx[i][1]; u[2] = (__bf16)rx[i][2]; u[3] = (__bf16)0.f; lds_x[q] = u; }
         }
         if constexpr (FUSE) {
-            bf16x4 d[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float yv[4], m = 0.f; int pos = 0;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {                           // first maximum in scan order, like the forward
-                    yv[p] = (float)ry[p][e];
-                    const float n = fmaf(yv[p], bsc[e], bsh[e]);
-                    if (p == 0 || n > m) { m = n; pos = p; }
-                }
-                const float gs = (float)ra[e] > 0.f ? (float)rg[e] * bsc[e] : 0.f;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) d[p][e] = (__bf16)((p == pos ? gs : 0.f) - fmaf(bB[e], yv[p], bA[e]));
-            }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int mm = (2 * (tid >> 7) + (p >> 1)) * 32 + 2 * ((tid >> 3) & 15) + (p & 1);
-                *reinterpret_cast<bf16x4*>(lds_d + mm * 32 + (tid & 7) * 4) = d[p];
-            }
+            *reinterpret_cast<bf16x8*>(lds_p + (size_t)tid * 8) = rp;       // [a0 | d_a0][pp][32]: thread order IS the layout
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i) *reinterpret_cast<bf16x8*>(lds_d + (size_t)(tid + i * 256) * 8) = rd[i];
         }
         __syncthreads();
         if (mt + 1 < t1) fetch(mt + 1);
+        if constexpr (FUSE) {
+            // 1. the forward conv of this wave's quadrant: rows 2(wave>>1) + (li>>4), columns 16(wave&1) + (li&15)
+            const int qr = 2 * (wave >> 1), qc = 16 * (wave & 1);
+            f32x16 cacc;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) cacc[v] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 5; ++r)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const bf16x4* p = lds_x + (qr + (li >> 4) + r) * HWX + qc + (li & 15) + 4 * kb + 2 * lh;
+                    const bf16x4 lo = p[0], hi = p[1];
+                    const bf16x8 av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw[r][kb], cacc, 0, 0, 0);
+                }
+            // 2. BatchNorm / pool / ReLU backward of the lane's four windows (quadrant columns 4lh + {0,2,8,10}), channel li
+            bf16x4 dq[2][2];                         // [row of the quadrant][column group 0-3 / 8-11] -> 4 consecutive pixels
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int v = 2 * j, m0 = (v & 3) + 8 * (v >> 2) + 4 * lh;          // first column of the window
+                const int pp = (wave >> 1) * 16 + 8 * (wave & 1) + (m0 >> 1);
+                const float av = (float)lds_p[pp * 32 + li], gv = (float)lds_p[1024 + pp * 32 + li];
+                float yv[4], mx = 0.f; int pos = 0;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {                                       // scan order: (row 0: v, v+1), (row 1: v+8, v+9)
+                    yv[p] = (float)(__bf16)(cacc[v + (p & 1) + 8 * (p >> 1)] + bv);     // the value the forward pooled
+                    const float n = fmaf(yv[p], bsc, bsh);
+                    if (p == 0 || n > mx) { mx = n; pos = p; }
+                }
+                const float gs = av > 0.f ? gv * bsc : 0.f;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    dq[p >> 1][j >> 1][2 * (j & 1) + (p & 1)] = (__bf16)((p == pos ? gs : 0.f) - fmaf(bB, yv[p], bA));
+            }
+            // 3. channel-major dy tile: pixel index = tile row * 32 + column
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int cg = 0; cg < 2; ++cg)
+                    *reinterpret_cast<bf16x4*>(lds_d + li * E1W_DT + (qr + rr) * 32 + qc + 8 * cg + 4 * lh) = dq[rr][cg];
+            __syncthreads();
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int px = 16 * ks + 8 * h + qrow;                       // this lane's block row (pixel) for read 0; read 1: +4
-            const __bf16* dp = lds_d + (wave * 32 + px) * 32 + cb;
-            const bf16x8 bv = tr_frag(dp, dp + 4 * 32);
+            bf16x8 bvv;
+            if constexpr (FUSE) {
+                bvv = *reinterpret_cast<const bf16x8*>(lds_d + li * E1W_DT + wave * 32 + 16 * ks + 8 * lh);   // B[k = pixel][n = li]
+            } else {
+                const __bf16* dp = lds_d + (wave * 32 + px) * 32 + cb;
+                bvv = tr_frag(dp, dp + 4 * 32);
+            }
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
                 const __bf16* ap = xs + ((wave + r) * HWX + px) * 4 + cb;
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(ap, ap + 16), bv, acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(ap, ap + 16), bvv, acc[r], 0, 0, 0);
             }
-            acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bv, acc[5], 0, 0, 0);
+            acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bvv, acc[5], 0, 0, 0);
         }
     }
     // every wave contracted its own tile rows: fixed-order sum over the 4 waves, one accumulator at a time
@@ -617,6 +672,10 @@ __global__ __launch_bounds__(256) void d4_perm_kernel(const float* __restrict__ 
                                                       const float* __restrict__ part, float* __restrict__ db, int B) {
     if (blockIdx.x == gridDim.x - 1) {
         const int co = threadIdx.x >> 6, lane = threadIdx.x & 63;      // waves 0..2 = the three output channels
+        if (!part) {                        // bf16 mode: the fused backward left the sums in row 76 of the slab
+            if (threadIdx.x < 3) db[threadIdx.x] = red[76 * 32 + threadIdx.x];
+            return;
+        }
         if (co < 3) {
             float acc = 0.f;
             for (int b = lane; b < B; b += 64) acc += part[b * 3 + co];
@@ -646,17 +705,18 @@ int64_t e1_wgrad_ws_floats(int width, int B) {
 }
 
 int launch_e1_fwd(int width, int B, const float* x, const float* w, const float* bias, float* y,
-                  float* bnpart, hipStream_t st, bool bf16, int pass, const float* coef, float* a1) {
+                  float* bnpart, hipStream_t st, bool bf16, int pass, const float* coef, float* a1, bool keep_y) {
+    const int keepY = keep_y ? 1 : 0;
     if (pass != 0 && !bf16) { cvae_set_error("e1_fwd: passes 1/2 exist in bf16 mode only"); return -2; }
     const int ns64 = B * 8, ns128 = B * 32, cap = 256 * 3;        // persistent: 3 workgroups per CU (VGPR-limited), one strip each per turn
     const dim3 g64(ns64 < cap ? ns64 : cap), g128(ns128 < cap ? ns128 : cap);
     cvae_probe_begin(st);
-    if (width == 64 && bf16 && pass == 1) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_STATS>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64);
-    else if (width == 64 && bf16 && pass == 2) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_POOL>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64);
-    else if (width == 128 && bf16 && pass == 1) hipLaunchKernelGGL((e1_fwd_bf16_kernel<128, E1_STATS>), g128, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns128);
-    else if (width == 128 && bf16 && pass == 2) hipLaunchKernelGGL((e1_fwd_bf16_kernel<128, E1_POOL>), g128, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns128);
-    else if (width == 64 && bf16) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_Y>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64);
-    else if (width == 128 && bf16) hipLaunchKernelGGL((e1_fwd_bf16_kernel<128, E1_Y>), g128, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns128);
+    if (width == 64 && bf16 && pass == 1) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_STATS>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64, keepY);
+    else if (width == 64 && bf16 && pass == 2) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_POOL>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64, keepY);
+    else if (width == 128 && bf16 && pass == 1) hipLaunchKernelGGL((e1_fwd_bf16_kernel<128, E1_STATS>), g128, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns128, keepY);
+    else if (width == 128 && bf16 && pass == 2) hipLaunchKernelGGL((e1_fwd_bf16_kernel<128, E1_POOL>), g128, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns128, keepY);
+    else if (width == 64 && bf16) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_Y>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64, keepY);
+    else if (width == 128 && bf16) hipLaunchKernelGGL((e1_fwd_bf16_kernel<128, E1_Y>), g128, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns128, keepY);
     else if (width == 64) hipLaunchKernelGGL(e1_fwd_kernel<64>, dim3(B * 8), dim3(256), 0, st, x, w, bias, y, bnpart, B);
     else if (width == 128) hipLaunchKernelGGL(e1_fwd_kernel<128>, dim3(B * 32), dim3(256), 0, st, x, w, bias, y, bnpart, B);
     else { cvae_set_error("e1_fwd: width %d unsupported", width); return -2; }
@@ -670,9 +730,10 @@ int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw
     if (width != 64 && width != 128) { cvae_set_error("e1_wgrad: width %d unsupported", width); return -2; }
     int tps; const int tiles = B * (width / 4) * (width / 32);
     const int S = thin_splits(tiles, &tps);
-    ThinWgradArgs a{x, dy, nullptr, nullptr, ws, B, tiles, tps};
-    // fuse = {y0, a0, d_a0, coef0, bcoef0}: block 0's BatchNorm/pool/ReLU backward is applied while staging (no dy tensor)
-    const E1Fuse fu = fuse ? E1Fuse{fuse[0], fuse[1], fuse[2], fuse[3], fuse[4]} : E1Fuse{};
+    ThinWgradArgs a{x, nullptr, dy, nullptr, nullptr, ws, B, tiles, tps};
+    // fuse = {y0, a0, d_a0, coef0, bcoef0, w1, b1}: block 0's BatchNorm/pool/ReLU backward is applied while staging (no dy
+    // tensor); the bf16 kernel recomputes y0 from x, w1, b1 and never reads fuse[0]
+    const E1Fuse fu = fuse ? E1Fuse{fuse[0], fuse[1], fuse[2], fuse[3], fuse[4], fuse[5], fuse[6]} : E1Fuse{};
     cvae_probe_begin(st);
     if (bf16) {          // precision mode 1: transposed-read kernel, its own slab layout + a permuting finish
         if (width == 64 && fuse) hipLaunchKernelGGL((e1_wgrad_bf16_kernel<64, true>), dim3(S), dim3(256), 0, st, a, fu);
@@ -744,8 +805,18 @@ __global__ __launch_bounds__(256) void d4_fwd_kernel(const float* __restrict__ i
             ra[i] = ok ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    if ((int)blockIdx.x < numTiles) fetch(blockIdx.x);
-    for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+    // XCD-aware tile order (common.h, xcd_tile): workgroups b, b+8, ... share an XCD, so each XCD walks ONE contiguous
+    // eighth of the tiles — the 10x10 source windows of neighbouring tiles overlap by two rows / columns, and the overlap is
+    // then re-read from that XCD's L2 instead of from HBM by another XCD
+    const int G = gridDim.x;
+    auto tile_of = [&](int n) {
+        if ((G & 7) || (numTiles & 7)) return n;
+        const int b = n % G, k = n / G;
+        return (b & 7) * (numTiles >> 3) + k * (G >> 3) + (b >> 3);
+    };
+    if ((int)blockIdx.x < numTiles) fetch(tile_of(blockIdx.x));
+    for (int n = blockIdx.x; n < numTiles; n += G) {
+        const int tile = tile_of(n);
         const int ib = tile / TPI, t = tile % TPI;
         const int ty0 = (t / TX) * 16, tx0 = (t % TX) * 16, sy0 = ty0 / 2 - 1, sx0 = tx0 / 2 - 1;
         // lds_a was last read before the previous tile's second barrier: free to refill
@@ -756,7 +827,7 @@ __global__ __launch_bounds__(256) void d4_fwd_kernel(const float* __restrict__ i
             d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
         }
         __syncthreads();       // also: every thread is past the previous tile's gather, lds_q is free
-        if (tile + (int)gridDim.x < numTiles) fetch(tile + gridDim.x);
+        if (n + G < numTiles) fetch(tile_of(n + G));
         f32x16 acc[3];
 #pragma unroll
         for (int nb = 0; nb < 3; ++nb)
@@ -832,8 +903,18 @@ __global__ __launch_bounds__(256) void d4_fwd_bf16_kernel(const float* __restric
             ra[i] = ok ? l : zero8;
         }
     };
-    if ((int)blockIdx.x < numTiles) fetch(blockIdx.x);
-    for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+    // XCD-aware tile order (common.h, xcd_tile): workgroups b, b+8, ... share an XCD, so each XCD walks ONE contiguous
+    // eighth of the tiles — the 10x10 source windows of neighbouring tiles overlap by two rows / columns, and the overlap is
+    // then re-read from that XCD's L2 instead of from HBM by another XCD
+    const int G = gridDim.x;
+    auto tile_of = [&](int n) {
+        if ((G & 7) || (numTiles & 7)) return n;
+        const int b = n % G, k = n / G;
+        return (b & 7) * (numTiles >> 3) + k * (G >> 3) + (b >> 3);
+    };
+    if ((int)blockIdx.x < numTiles) fetch(tile_of(blockIdx.x));
+    for (int n = blockIdx.x; n < numTiles; n += G) {
+        const int tile = tile_of(n);
         const int ib = tile / TPI, t = tile % TPI;
         const int ty0 = (t / TX) * 16, tx0 = (t % TX) * 16, sy0 = ty0 / 2 - 1, sx0 = tx0 / 2 - 1;
 #pragma unroll
@@ -842,7 +923,7 @@ __global__ __launch_bounds__(256) void d4_fwd_bf16_kernel(const float* __restric
             if (q < 400) *reinterpret_cast<bf16x8*>(lds_a + (q >> 2) * AS + (q & 3) * 8) = ra[i];
         }
         __syncthreads();       // also: every thread is past the previous tile's gather, lds_q is free
-        if (tile + (int)gridDim.x < numTiles) fetch(tile + gridDim.x);
+        if (n + G < numTiles) fetch(tile_of(n + G));
         f32x16 acc[3];
 #pragma unroll
         for (int nb = 0; nb < 3; ++nb)
@@ -1046,19 +1127,21 @@ __global__ __launch_bounds__(256) void d4_bwd_bf16_kernel(ThinWgradArgs a) {
         for (int v = 0; v < 16; ++v) accw[mb][v] = 0.f;
     const int t0 = blockIdx.x * a.tilesPerSplit;
     int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
-    constexpr int GQ = (G0 + 255) / 256;
-    float rg[GQ];
+    constexpr int GQ = (G0 / 2 + 255) / 256;             // the halo travels as 8-byte pairs (its first column 2*sx0 - 2 is even)
+    float2 rg[GQ];
     bf16x8 ro[2];
     auto fetch = [&](int mt) {
         const int ib = mt / TPI, t = mt % TPI;
         const int sy0 = (t / (HS / 16)) * 8, sx0 = (t % (HS / 16)) * 16;
 #pragma unroll
         for (int i = 0; i < GQ; ++i) {
-            const int q = tid + i * 256, c = q / 720, rem = q % 720;
-            const int uy = 2 * sy0 - 2 + rem / 36, ux = 2 * sx0 - 2 + rem % 36;
-            const bool ok = q < G0 && (unsigned)uy < (unsigned)H && (unsigned)ux < (unsigned)H;
-            const float l = a.a0[ok ? ((size_t)(ib * 3 + c) * H + uy) * H + ux : 0];
-            rg[i] = ok ? l : 0.f;
+            const int q = tid + i * 256, c = q / 360, rem = q % 360;
+            const int uy = 2 * sy0 - 2 + rem / 18, ux = 2 * sx0 - 2 + 2 * (rem % 18);
+            const bool ok = q < G0 / 2 && (unsigned)uy < (unsigned)H && (unsigned)ux < (unsigned)H;     // ux even: ux + 1 is inside with it
+            const size_t e = ok ? ((size_t)(ib * 3 + c) * H + uy) * H + ux : 0;
+            const float2 g = *reinterpret_cast<const float2*>(a.a0 + e), r = *reinterpret_cast<const float2*>(a.a2 + e);
+            // dOut = d_recon * (1 - recon^2): Tanh backward (vae_nets.py:134), d4_actbwd_kernel's expression
+            rg[i] = ok ? make_float2(g.x * (1.f - r.x * r.x), g.y * (1.f - r.y * r.y)) : make_float2(0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1066,6 +1149,15 @@ __global__ __launch_bounds__(256) void d4_bwd_bf16_kernel(ThinWgradArgs a) {
             ro[i] = Act<__bf16>::ld8(a.a1, ((size_t)(ib * HS + sy0 + sp / 16) * HS + sx0 + sp % 16) * 32 + c8 * 8);
         }
     };
+    // bias gradient = sum of dOut over the tile's own 16 x 32 output pixels (rows / columns 2.. of the staged halo): which
+    // staged elements those are is a per-thread constant, so every thread keeps one running sum per staging slot
+    float bsum[GQ], bmask[GQ];
+#pragma unroll
+    for (int i = 0; i < GQ; ++i) {
+        const int q = tid + i * 256, rem = q % 360, hr = rem / 18, hc = 2 * (rem % 18);
+        bmask[i] = (q < G0 / 2 && hr >= 2 && hr < 18 && hc >= 2 && hc < 34) ? 1.f : 0.f;     // both columns of the pair or neither
+        bsum[i] = 0.f;
+    }
     if (t0 < t1) fetch(t0);
     const int gsp = tid & 127, ghalf = tid >> 7, gsy = gsp >> 4, gsx = gsp & 15;
     // transposed-read lane address inside a 4-row block (rows = source pixels)
@@ -1077,7 +1169,8 @@ __global__ __launch_bounds__(256) void d4_bwd_bf16_kernel(ThinWgradArgs a) {
 #pragma unroll
         for (int i = 0; i < GQ; ++i) {
             const int q = tid + i * 256;
-            if (q < G0) lds_g0[q] = rg[i];
+            if (q < G0 / 2) *reinterpret_cast<float2*>(lds_g0 + 2 * q) = rg[i];
+            bsum[i] = fmaf(bmask[i], rg[i].x + rg[i].y, bsum[i]);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1133,6 +1226,20 @@ __global__ __launch_bounds__(256) void d4_bwd_bf16_kernel(ThinWgradArgs a) {
         }
     }
     thin_slab_out(accw, smem, a.slab + (size_t)blockIdx.x * 96 * 32);
+    // row 76 of the slab (a K-pad row: zeros) carries this workgroup's three bias-gradient partials; the column
+    // reduction of the slabs sums them with the weights' (fixed order), d4_perm_kernel picks them up
+    float bc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < GQ; ++i) {
+        const int c = (tid + i * 256) / 360;
+#pragma unroll
+        for (int co = 0; co < 3; ++co) bc[co] += c == co ? bsum[i] : 0.f;
+    }
+    __shared__ float bred[4][3];
+#pragma unroll
+    for (int co = 0; co < 3; ++co) { const float v = wave_sum(bc[co]); if (lane == 0) bred[wave][co] = v; }
+    __syncthreads();                       // also: wave 0 has written the slab rows
+    if (tid < 3) a.slab[(size_t)blockIdx.x * 96 * 32 + 76 * 32 + tid] = (bred[0][tid] + bred[1][tid]) + (bred[2][tid] + bred[3][tid]);
 }
 static constexpr int D4_BWD_BF16_SMEM = 3 * 720 * 4 + 128 * 32 * 2 + (128 * 88 + 16) * 2;
 static_assert(D4_BWD_BF16_SMEM >= 3 * 3 * 1024 * 4, "thin_slab_out reuses the staging buffers");
@@ -1170,9 +1277,11 @@ int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const
     const int tiles = B * (width / 16) * (width / 32);
     const int S = d4_splits(width, B, &tps);
     float* plane_sums = ws + (size_t)S * 3072;
-    hipLaunchKernelGGL(d4_actbwd_kernel, dim3(B * 3), dim3(256), 0, st, d_recon, recon, dout, plane_sums, width * width);
-    CVAE_CHECK_LAUNCH();
-    ThinWgradArgs a{dout, o3, w, d_o3, ws, B, tiles, tps};
+    if (!bf16io) {      // fp32: Tanh backward as its own pass (writes dOut); bf16 mode applies it while the backward kernel stages
+        hipLaunchKernelGGL(d4_actbwd_kernel, dim3(B * 3), dim3(256), 0, st, d_recon, recon, dout, plane_sums, width * width);
+        CVAE_CHECK_LAUNCH();
+    }
+    ThinWgradArgs a{bf16io ? d_recon : dout, bf16io ? recon : nullptr, o3, w, d_o3, ws, B, tiles, tps};
     static DeviceOnce once[4];
     void (*kern)(ThinWgradArgs) = width == 64 ? (bf16io ? d4_bwd_bf16_kernel<64> : d4_bwd_kernel<64, float>)
                                               : (bf16io ? d4_bwd_bf16_kernel<128> : d4_bwd_kernel<128, float>);
@@ -1184,7 +1293,7 @@ int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const
     CVAE_CHECK_LAUNCH();
     float* red = plane_sums + align_up((int64_t)B * 3, 64);
     { int rc = launch_col_reduce(ws, S, 3072, 3072, red, red + 3072, st); if (rc) return rc; }
-    hipLaunchKernelGGL(d4_perm_kernel, dim3(cdiv(2400, 256) + 1), dim3(256), 0, st, red, dw, plane_sums, db, B);
+    hipLaunchKernelGGL(d4_perm_kernel, dim3(cdiv(2400, 256) + 1), dim3(256), 0, st, red, dw, bf16io ? nullptr : plane_sums, db, B);
     CVAE_CHECK_LAUNCH();
     return 0;
 }

@@ -37,7 +37,15 @@ static MsWin make_window() {
 }
 
 static constexpr int MS_NF = 32;            // finalize workgroups
-static constexpr int MS_NT = 512;           // threads of a tile workgroup (two workgroups per CU: 4 waves per SIMD)
+#ifndef CVAE_MS_NT
+#define CVAE_MS_NT 768
+#endif
+#ifndef CVAE_MS_VR
+#define CVAE_MS_VR 2
+#endif
+static constexpr int MS_NT = CVAE_MS_NT;     // threads of a tile workgroup: two workgroups per CU (80 KB of LDS each) = 6 waves per SIMD at <= 80 VGPRs;
+                                             // 768 runs the first horizontal pass (684 items at S = 64) in one round: 371 us against 392 (512) / 366 (1024) at B = 2048
+static constexpr int MS_VR = CVAE_MS_VR;     // output rows per item of the vertical passes (VR + 10 staged rows are read per item)
 
 // 1/x to ~0.5 ulp: v_rcp_f32 + one Newton step (3 instructions instead of the ~11 of an IEEE division; the
 // denominators are >= C1 / C2 minus round-off, far from the denormal range)
@@ -74,6 +82,19 @@ __device__ __forceinline__ void ms_point(float mu1, float mu2, float a11, float 
 // ------------------------------------------------------------------------------------------------
 // large levels (S = 128, 64, 32): one workgroup per (plane, RS x CS tile)
 // ------------------------------------------------------------------------------------------------
+// Round 3: the four filter passes run on PACKED fp32 (v_pk_fma_f32 / v_pk_mul_f32: two lanes of arithmetic per VALU
+// issue — the kernel is VALU-bound, one wave64 VALU instruction holds its SIMD for 4 cycles).  What is packed is chosen
+// so that every operand pair is already adjacent in registers AND in LDS, i.e. no v_mov shuffles:
+//   horizontal passes pair two PLANES of one pixel — the staged image interleaves (x, y) per pixel, so (x, y) -> (hx, hy)
+//     and (x^2, y^2) -> (hxx, hyy) are one packed chain each (xy -> hxy stays scalar); the derivative maps are kept as
+//     (d_mu, d_11) pairs + a d_12 plane in the same way;
+//   vertical passes pair the same two planes again for the pair images and two adjacent COLUMNS for the single plane;
+//   the SSIM point function runs on two adjacent columns at once.
+// Every output is still the same t = 0..10 fma chain over the same products: values are unchanged.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+
 template <int S>
 struct MsT {
     static constexpr int CS = S < 64 ? S : 64;             // tile columns
@@ -82,11 +103,16 @@ struct MsT {
     static constexpr int ER = RS + 20;                      // input rows staged (tile + 2 window radii)
     static constexpr int MR = RS + 10, MC = CS + 10;        // map region (tile + 1 window radius)
     static constexpr int MCP = ((MC + 3) / 4) * 4;          // map row stride (4 outputs per H item)
-    static constexpr int ECP = MCP + 12;                    // input row stride: the last H item reads 14 columns
-    static constexpr int LIN = 2 * ER * ECP;                // floats: x | y halo images; later the 3 derivative maps
-    static constexpr int TMP = 5 * ER * MCP;                // floats: 5 row-filtered maps; later the 3 row-filtered derivative maps
+    static constexpr int ECP = MCP + 14;                    // input row stride: the last H item reads 14 columns; ECP / 2 is ODD
+    static constexpr int DAS = MCP + 2;                     // row stride of the (d_mu, d_11) image; DAS / 2 is ODD
+    // (an item of a horizontal pass reads 16-byte units 32 bytes apart from its neighbour's: with an odd row stride in
+    //  16-byte units, lanes that alternate between two rows cover all 16 slots of the 256-byte bank row: conflict-free)
+    static constexpr int LIN = 2 * ER * ECP;                // floats: (x, y) pixels [ER][ECP]; later (d_mu, d_11) [MR][DAS] | d_12 [MR][MCP]
+    static constexpr int TMP = 5 * ER * MCP + 2 * MCP;      // floats: (hx, hy) | (hxx, hyy) | hxy, each [ER][MCP] (+2 rows: the last 4-row
+                                                            // group of the vertical pass reads past row ER-1); later (g0, g1) | g2, each [MR][CS]
     static constexpr int SMEM = (LIN + TMP) * 4;
-    static_assert(3 * MR * MCP <= LIN, "derivative maps must fit in the input halo buffer");
+    static_assert(2 * MR * DAS + MR * MCP <= LIN, "derivative maps must fit in the input halo buffer");
+    static_assert((ECP / 2) % 2 == 1 && (DAS / 2) % 2 == 1 && ER % 2 == 0 && MR % 2 == 0, "odd unit strides, even row counts");
     static_assert(3 * MR * CS <= TMP, "row-filtered derivative maps must fit in the tmp buffer");
     static_assert(MC % 2 == 0 && MR % 2 == 0, "2x2 blocking of the vertical passes");
 };
@@ -102,13 +128,35 @@ struct MsFwdArgs {
     MsWin win;
 };
 
+// ms_point on two adjacent columns at once (same operations per column as ms_point)
+__device__ __forceinline__ f32x2 ms_rcp2(f32x2 x) {
+    const f32x2 r = {__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
+    return pk_fma(pk_fma(-x, r, splat2(1.0f)), r, r);
+}
+__device__ __forceinline__ void ms_point2(f32x2 mu1, f32x2 mu2, f32x2 a11, f32x2 a22, f32x2 a12, f32x2* ssim, f32x2* cs,
+                                          f32x2* dm, f32x2* d11, f32x2* d12) {
+    const f32x2 C1 = splat2(0.0001f), C2 = splat2(0.0009f), two = splat2(2.0f);
+    const f32x2 mu1sq = mu1 * mu1, mu2sq = mu2 * mu2, mu12 = mu1 * mu2;
+    const f32x2 v1 = two * (a12 - mu12) + C2;
+    const f32x2 v2 = (a11 - mu1sq) + (a22 - mu2sq) + C2;
+    const f32x2 inv2 = ms_rcp2(v2);
+    const f32x2 c = v1 * inv2;
+    const f32x2 num = two * mu12 + C1, den = mu1sq + mu2sq + C1;
+    const f32x2 lum = num * ms_rcp2(den);
+    *cs = c;
+    *ssim = lum * c;
+    *dm = (two * mu1 * c - two * mu2) * inv2;
+    *d11 = -c * inv2;
+    *d12 = two * inv2;
+}
+
 template <int S>
-__global__ __launch_bounds__(MS_NT) void msssim_fwd_kernel(MsFwdArgs a) {
+__global__ __launch_bounds__(MS_NT, MS_NT / 128) void msssim_fwd_kernel(MsFwdArgs a) {
     using T = MsT<S>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float red[2 * (MS_NT / 64)];
-    float* lin = smem;                 // [2][ER][ECP]
-    float* tmp = smem + T::LIN;        // [5][ER][MCP]
+    float* lin = smem;                 // (x, y) pixels [ER][ECP][2]
+    float* tmp = smem + T::LIN;        // tmpA (hx, hy) [ER][MCP][2] | tmpB (hxx, hyy) [ER][MCP][2] | tmpC hxy [ER][MCP]
     const int blk = xcd_tile(blockIdx.x, gridDim.x);
     const int plane = blk / T::TILES, tile = blk % T::TILES;
     const int r0 = (tile / T::TX) * T::RS, c0 = (tile % T::TX) * T::CS;
@@ -116,8 +164,8 @@ __global__ __launch_bounds__(MS_NT) void msssim_fwd_kernel(MsFwdArgs a) {
     float w[11];
 #pragma unroll
     for (int t = 0; t < 11; ++t) w[t] = a.win.w[t];
-    // ---- stage the zero-padded input halos: image rows r0-10 .. r0+RS+9, columns c0-10 .. (8-byte units).
-    //      All global loads are issued before the first LDS write (one HBM latency per tile, not one per row) ----
+    // ---- stage the zero-padded input halos, (x, y) interleaved per pixel: image rows r0-10 .. r0+RS+9, columns c0-10 ..
+    //      (two pixels = one 16-byte LDS unit).  All global loads are issued before the first LDS write ----
     {
         constexpr int U = T::ECP / 2, NIT = (T::ER * U + MS_NT - 1) / MS_NT;
         const float* px = a.x + (size_t)plane * S * S;
@@ -141,8 +189,7 @@ __global__ __launch_bounds__(MS_NT) void msssim_fwd_kernel(MsFwdArgs a) {
             const int q = threadIdx.x + k * MS_NT;
             if (q < T::ER * U) {
                 const int er = q / U, ec = (q % U) * 2;
-                *reinterpret_cast<float2*>(lin + er * T::ECP + ec) = vx[k];
-                *reinterpret_cast<float2*>(lin + T::ER * T::ECP + er * T::ECP + ec) = vy[k];
+                *reinterpret_cast<f32x4*>(lin + (er * T::ECP + ec) * 2) = f32x4{vx[k].x, vy[k].x, vx[k].y, vy[k].y};
             }
         }
     }
@@ -152,87 +199,101 @@ __global__ __launch_bounds__(MS_NT) void msssim_fwd_kernel(MsFwdArgs a) {
         constexpr int SO = S / 2, PR = T::RS / 2, PC = T::CS / 2;
         for (int q = threadIdx.x; q < PR * PC; q += MS_NT) {
             const int pr = q / PC, pc = q % PC;
-            const float* p = lin + (10 + 2 * pr) * T::ECP + 10 + 2 * pc;
-            const float* p2 = p + T::ER * T::ECP;
+            const f32x4 u = *reinterpret_cast<const f32x4*>(lin + ((10 + 2 * pr) * T::ECP + 10 + 2 * pc) * 2);      // (x0, y0, x1, y1)
+            const f32x4 d = *reinterpret_cast<const f32x4*>(lin + ((11 + 2 * pr) * T::ECP + 10 + 2 * pc) * 2);
             const size_t o = ((size_t)plane * SO + r0 / 2 + pr) * SO + c0 / 2 + pc;
-            a.nx[o] = ((p[0] + p[1]) + (p[T::ECP] + p[T::ECP + 1])) * 0.25f;
-            a.ny[o] = ((p2[0] + p2[1]) + (p2[T::ECP] + p2[T::ECP + 1])) * 0.25f;
+            a.nx[o] = ((u[0] + u[2]) + (d[0] + d[2])) * 0.25f;
+            a.ny[o] = ((u[1] + u[3]) + (d[1] + d[3])) * 0.25f;
         }
     }
     // ---- horizontal pass of {x, y, x^2, y^2, xy}: 4 adjacent outputs per item from a 14-wide register window ----
     {
         constexpr int J = T::MCP / 4, PT = T::ER * T::MCP;
+        float* tA = tmp; float* tB = tmp + 2 * PT; float* tC = tmp + 4 * PT;
         for (int it = threadIdx.x; it < T::ER * J; it += MS_NT) {
-            const int r = it / J, c = (it % J) * 4;
-            const float* px = lin + r * T::ECP + c;
-            const float* py = px + T::ER * T::ECP;
-            float xs[16], ys[16];            // 16-byte LDS reads (the row stride leaves room for the 2 unused columns)
+            const int r = 2 * (it / (2 * J)) + (it & 1), c = ((it % (2 * J)) >> 1) * 4;      // neighbouring lanes: the two rows of a pair
+            const float* p = lin + (r * T::ECP + c) * 2;
+            f32x2 xy[14];                      // (x, y) of the 14 window pixels
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 u = *reinterpret_cast<const f32x4*>(px + 4 * i);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(py + 4 * i);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { xs[4 * i + e] = u[e]; ys[4 * i + e] = v[e]; }
+            for (int i = 0; i < 7; ++i) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(p + 4 * i);
+                xy[2 * i] = f32x2{u[0], u[1]}; xy[2 * i + 1] = f32x2{u[2], u[3]};
             }
-            f32x4 o0, o1, o2, o3, o4;
+            f32x2 hA[4], hB[4];
+            float hC[4];
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
-                float hx = 0.f, hy = 0.f, hxx = 0.f, hyy = 0.f, hxy = 0.f;
+                f32x2 sA = splat2(0.f), sB = splat2(0.f);
+                float sC = 0.f;
 #pragma unroll
                 for (int t = 0; t < 11; ++t) {
-                    const float xv = xs[o + t], yv = ys[o + t];
-                    hx = fmaf(w[t], xv, hx); hy = fmaf(w[t], yv, hy);
-                    hxx = fmaf(w[t], xv * xv, hxx); hyy = fmaf(w[t], yv * yv, hyy); hxy = fmaf(w[t], xv * yv, hxy);
+                    const f32x2 v = xy[o + t];
+                    sA = pk_fma(splat2(w[t]), v, sA);
+                    sB = pk_fma(splat2(w[t]), v * v, sB);
+                    sC = fmaf(w[t], v.x * v.y, sC);
                 }
-                o0[o] = hx; o1[o] = hy; o2[o] = hxx; o3[o] = hyy; o4[o] = hxy;
+                hA[o] = sA; hB[o] = sB; hC[o] = sC;
             }
-            float* d = tmp + r * T::MCP + c;
-            *reinterpret_cast<f32x4*>(d) = o0; *reinterpret_cast<f32x4*>(d + PT) = o1;
-            *reinterpret_cast<f32x4*>(d + 2 * PT) = o2; *reinterpret_cast<f32x4*>(d + 3 * PT) = o3;
-            *reinterpret_cast<f32x4*>(d + 4 * PT) = o4;
+            const int d = r * T::MCP + c;
+            *reinterpret_cast<f32x4*>(tA + 2 * d) = f32x4{hA[0].x, hA[0].y, hA[1].x, hA[1].y};
+            *reinterpret_cast<f32x4*>(tA + 2 * d + 4) = f32x4{hA[2].x, hA[2].y, hA[3].x, hA[3].y};
+            *reinterpret_cast<f32x4*>(tB + 2 * d) = f32x4{hB[0].x, hB[0].y, hB[1].x, hB[1].y};
+            *reinterpret_cast<f32x4*>(tB + 2 * d + 4) = f32x4{hB[2].x, hB[2].y, hB[3].x, hB[3].y};
+            *reinterpret_cast<f32x4*>(tC + d) = f32x4{hC[0], hC[1], hC[2], hC[3]};
         }
     }
     __syncthreads();
-    // ---- vertical pass on the map region + SSIM/CS maps + derivative maps (into the input buffer) ----
+    // ---- vertical pass on the map region (VR rows x 2 columns per item: VR + 10 staged rows feed VR output rows) + SSIM/CS
+    //      maps + derivative maps (into the input buffer: dA = (d_mu, d_11) pairs, dC = d_12) ----
     float s_ssim = 0.f, s_cs = 0.f;
     {
-        constexpr int PT = T::ER * T::MCP, DM = T::MR * T::MCP;
-        float* dmap = lin;
-        for (int it = threadIdx.x; it < (T::MR / 2) * (T::MC / 2); it += MS_NT) {
-            const int mr = (it / (T::MC / 2)) * 2, mc = (it % (T::MC / 2)) * 2;
-            float res[5][2][2];
+        constexpr int PT = T::ER * T::MCP, VR = MS_VR, G = (T::MR + VR - 1) / VR;
+        const float* tA = tmp; const float* tB = tmp + 2 * PT; const float* tC = tmp + 4 * PT;
+        float* dA = lin; float* dC = lin + 2 * T::MR * T::DAS;
+        for (int it = threadIdx.x; it < G * (T::MC / 2); it += MS_NT) {
+            const int mr = (it / (T::MC / 2)) * VR, mc = (it % (T::MC / 2)) * 2;
+            // staged rows mr .. mr+VR+9: the last group may read up to 2 rows past row ER-1 (the next image, or the pad rows
+            // behind the last one) for output rows >= MR, which are dropped
+            const int rb = mr * T::MCP + mc;
+            f32x2 mu[VR][2], aa[VR][2], a12[VR];       // [output row][column] (mu1, mu2) / (a11, a22); a12: [row] over the 2 columns
 #pragma unroll
-            for (int mI = 0; mI < 5; ++mI) {
-                const float* t0 = tmp + mI * PT + mr * T::MCP + mc;
-                float2 v[12];
+            for (int o = 0; o < VR; ++o) { mu[o][0] = mu[o][1] = aa[o][0] = aa[o][1] = a12[o] = splat2(0.f); }
+            // row-major over the VR + 10 staged rows: each row of the three images is read once, added into the (up to VR) output
+            // rows it belongs to and dropped; an output row is finished — SSIM point, derivative maps — as soon as its
+            // eleventh tap is in, so only the accumulators + one staged row are live.  Every output still sums its taps
+            // in the order t = 0..10.
 #pragma unroll
-                for (int i = 0; i < 12; ++i) v[i] = *reinterpret_cast<const float2*>(t0 + i * T::MCP);
+            for (int i = 0; i < VR + 10; ++i) {
+                const f32x4 vA = *reinterpret_cast<const f32x4*>(tA + (rb + i * T::MCP) * 2);
+                const f32x4 vB = *reinterpret_cast<const f32x4*>(tB + (rb + i * T::MCP) * 2);
+                const f32x2 vC = *reinterpret_cast<const f32x2*>(tC + rb + i * T::MCP);
 #pragma unroll
-                for (int o = 0; o < 2; ++o) {
-                    float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-                    for (int t = 0; t < 11; ++t) { a0 = fmaf(w[t], v[o + t].x, a0); a1 = fmaf(w[t], v[o + t].y, a1); }
-                    res[mI][o][0] = a0; res[mI][o][1] = a1;
+                for (int o = 0; o < VR; ++o) {
+                    if (i - o < 0 || i - o > 10) continue;
+                    const f32x2 wt = splat2(w[i - o]);
+                    mu[o][0] = pk_fma(wt, f32x2{vA[0], vA[1]}, mu[o][0]);
+                    mu[o][1] = pk_fma(wt, f32x2{vA[2], vA[3]}, mu[o][1]);
+                    aa[o][0] = pk_fma(wt, f32x2{vB[0], vB[1]}, aa[o][0]);
+                    aa[o][1] = pk_fma(wt, f32x2{vB[2], vB[3]}, aa[o][1]);
+                    a12[o] = pk_fma(wt, vC, a12[o]);
                 }
-            }
+                if (i < 10) continue;
+                const int o = i - 10, r = mr + o;
+                if (r < T::MR) {
+                    f32x2 ss, cs, dmv, d11v, d12v;
+                    ms_point2(f32x2{mu[o][0].x, mu[o][1].x}, f32x2{mu[o][0].y, mu[o][1].y}, f32x2{aa[o][0].x, aa[o][1].x},
+                              f32x2{aa[o][0].y, aa[o][1].y}, a12[o], &ss, &cs, &dmv, &d11v, &d12v);
 #pragma unroll
-            for (int o = 0; o < 2; ++o) {
-                float dmv[2], d11v[2], d12v[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    float ss, cs;
-                    ms_point(res[0][o][e], res[1][o][e], res[2][o][e], res[3][o][e], res[4][o][e], false, &ss, &cs,
-                             &dmv[e], &d11v[e], &d12v[e]);
-                    const int r = mr + o, c = mc + e;
-                    const bool interior = r >= 5 && r < 5 + T::RS && c >= 5 && c < 5 + T::CS;
-                    if (interior) { s_ssim += ss; s_cs += cs; }
-                    const bool inside = (unsigned)(r0 - 5 + r) < (unsigned)S && (unsigned)(c0 - 5 + c) < (unsigned)S;
-                    if (!inside) { dmv[e] = 0.f; d11v[e] = 0.f; d12v[e] = 0.f; }      // conv2d zero-pads the maps it filters
+                    for (int e = 0; e < 2; ++e) {
+                        const int c = mc + e;
+                        const bool interior = r >= 5 && r < 5 + T::RS && c >= 5 && c < 5 + T::CS;
+                        if (interior) { s_ssim += ss[e]; s_cs += cs[e]; }
+                        const bool inside = (unsigned)(r0 - 5 + r) < (unsigned)S && (unsigned)(c0 - 5 + c) < (unsigned)S;
+                        if (!inside) { dmv[e] = 0.f; d11v[e] = 0.f; d12v[e] = 0.f; }      // conv2d zero-pads the maps it filters
+                    }
+                    *reinterpret_cast<f32x4*>(dA + (r * T::DAS + mc) * 2) = f32x4{dmv.x, d11v.x, dmv.y, d11v.y};
+                    *reinterpret_cast<f32x2*>(dC + r * T::MCP + mc) = d12v;
                 }
-                float* d = dmap + (mr + o) * T::MCP + mc;
-                *reinterpret_cast<float2*>(d) = make_float2(dmv[0], dmv[1]);
-                *reinterpret_cast<float2*>(d + DM) = make_float2(d11v[0], d11v[1]);
-                *reinterpret_cast<float2*>(d + 2 * DM) = make_float2(d12v[0], d12v[1]);
             }
         }
     }
@@ -247,62 +308,96 @@ __global__ __launch_bounds__(MS_NT) void msssim_fwd_kernel(MsFwdArgs a) {
         a.part[(size_t)blk * 2 + 1] = t1;
     }
     if (!a.F) return;
-    // ---- the same separable filter over the three derivative maps: horizontal ... ----
+    // ---- the same separable filter over the three derivative maps: horizontal ((d_mu, d_11) packed, d_12 scalar) ... ----
     {
-        constexpr int J = T::CS / 4, DM = T::MR * T::MCP, PT = T::MR * T::CS;
-        const float* dmap = lin;
+        constexpr int J = T::CS / 4, PT = T::MR * T::CS;
+        const float* dA = lin; const float* dC = lin + 2 * T::MR * T::DAS;
+        float* gA = tmp; float* gC = tmp + 2 * PT;
         for (int it = threadIdx.x; it < T::MR * J; it += MS_NT) {
-            const int r = it / J, c = (it % J) * 4;
+            const int r = 2 * (it / (2 * J)) + (it & 1), c = ((it % (2 * J)) >> 1) * 4;      // neighbouring lanes: the two rows of a pair
+            f32x2 va[14];
+            float vc[16];
 #pragma unroll
-            for (int mI = 0; mI < 3; ++mI) {
-                const float* p0 = dmap + mI * DM + r * T::MCP + c;
-                float xs[16];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x4 u = *reinterpret_cast<const f32x4*>(p0 + 4 * i);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) xs[4 * i + e] = u[e];
-                }
-                f32x4 o4v;
-#pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    float h = 0.f;
-#pragma unroll
-                    for (int t = 0; t < 11; ++t) h = fmaf(w[t], xs[o + t], h);
-                    o4v[o] = h;
-                }
-                *reinterpret_cast<f32x4*>(tmp + mI * PT + r * T::CS + c) = o4v;
+            for (int i = 0; i < 7; ++i) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(dA + (r * T::DAS + c) * 2 + 4 * i);
+                va[2 * i] = f32x2{u[0], u[1]}; va[2 * i + 1] = f32x2{u[2], u[3]};
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(dC + r * T::MCP + c + 4 * i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vc[4 * i + e] = u[e];
+            }
+            f32x2 gAo[4];
+            f32x4 gCo;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                f32x2 sA = splat2(0.f);
+                float sC = 0.f;
+#pragma unroll
+                for (int t = 0; t < 11; ++t) { sA = pk_fma(splat2(w[t]), va[o + t], sA); sC = fmaf(w[t], vc[o + t], sC); }
+                gAo[o] = sA; gCo[o] = sC;
+            }
+            const int d = r * T::CS + c;
+            *reinterpret_cast<f32x4*>(gA + 2 * d) = f32x4{gAo[0].x, gAo[0].y, gAo[1].x, gAo[1].y};
+            *reinterpret_cast<f32x4*>(gA + 2 * d + 4) = f32x4{gAo[2].x, gAo[2].y, gAo[3].x, gAo[3].y};
+            *reinterpret_cast<f32x4*>(gC + d) = gCo;
         }
     }
     __syncthreads();
-    // ---- ... vertical (2 rows x 1 column per item), then F = f0 + 2 x f1 + y f2 ----
+    // ---- ... vertical (VR rows x 2 columns per item), then F = f0 + 2 x f1 + y f2 ----
     {
-        constexpr int PT = T::MR * T::CS;
+        constexpr int PT = T::MR * T::CS, VR = MS_VR;
+        static_assert(T::RS % VR == 0 && ((T::MR + VR - 1) / VR) * VR + 10 <= T::ER + 2, "whole items; over-read of the vertical pass <= 2 rows");
+        const float* gA = tmp; const float* gC = tmp + 2 * PT;
         const float* px = a.x + (size_t)plane * S * S;
         const float* py = a.y + (size_t)plane * S * S;
         float* pf = a.F + (size_t)plane * S * S;
-        for (int it = threadIdx.x; it < (T::RS / 2) * T::CS; it += MS_NT) {
-            const int r = (it / T::CS) * 2, c = it % T::CS;
+        for (int it = threadIdx.x; it < (T::RS / VR) * (T::CS / 2); it += MS_NT) {
+            const int r = (it / (T::CS / 2)) * VR, c = (it % (T::CS / 2)) * 2;
             const size_t g = (size_t)(r0 + r) * S + c0 + c;
-            const float x0 = px[g], x1 = px[g + S], y0 = py[g], y1 = py[g + S];     // L2 hits, issued ahead of the filter
-            float f[3][2];
+            float2 xv[VR], yv[VR];               // L2 hits, issued ahead of the filter
 #pragma unroll
-            for (int mI = 0; mI < 3; ++mI) {
-                const float* t0 = tmp + mI * PT + r * T::CS + c;
-                float v[12];
+            for (int o = 0; o < VR; ++o) {
+                xv[o] = *reinterpret_cast<const float2*>(px + g + (size_t)o * S);
+                yv[o] = *reinterpret_cast<const float2*>(py + g + (size_t)o * S);
+            }
+            f32x2 f01[VR][2], f2[VR];         // [row][column] (f0, f1); f2: [row] over the 2 columns
+            {
+                // row-major over the VR + 10 staged rows: each row is read, used by the (up to VR) outputs it belongs to and dropped —
+                // every output still sums its taps in the order t = 0..10
 #pragma unroll
-                for (int i = 0; i < 12; ++i) v[i] = t0[i * T::CS];
+                for (int o = 0; o < VR; ++o) { f01[o][0] = splat2(0.f); f01[o][1] = splat2(0.f); }
 #pragma unroll
-                for (int o = 0; o < 2; ++o) {
-                    float a0 = 0.f;
+                for (int i = 0; i < VR + 10; ++i) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(gA + ((r + i) * T::CS + c) * 2);
 #pragma unroll
-                    for (int t = 0; t < 11; ++t) a0 = fmaf(w[t], v[o + t], a0);
-                    f[mI][o] = a0;
+                    for (int o = 0; o < VR; ++o) {
+                        if (i - o < 0 || i - o > 10) continue;
+                        f01[o][0] = pk_fma(splat2(w[i - o]), f32x2{v[0], v[1]}, f01[o][0]);
+                        f01[o][1] = pk_fma(splat2(w[i - o]), f32x2{v[2], v[3]}, f01[o][1]);
+                    }
                 }
             }
-            pf[g] = f[0][0] + 2.0f * x0 * f[1][0] + y0 * f[2][0];
-            pf[g + S] = f[0][1] + 2.0f * x1 * f[1][1] + y1 * f[2][1];
+            __builtin_amdgcn_sched_barrier(0);
+            {
+#pragma unroll
+                for (int o = 0; o < VR; ++o) f2[o] = splat2(0.f);
+#pragma unroll
+                for (int i = 0; i < VR + 10; ++i) {
+                    const f32x2 v = *reinterpret_cast<const f32x2*>(gC + (r + i) * T::CS + c);
+#pragma unroll
+                    for (int o = 0; o < VR; ++o) {
+                        if (i - o < 0 || i - o > 10) continue;
+                        f2[o] = pk_fma(splat2(w[i - o]), v, f2[o]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < VR; ++o)
+                *reinterpret_cast<float2*>(pf + g + (size_t)o * S) =
+                    make_float2(f01[o][0].x + 2.0f * xv[o].x * f01[o][0].y + yv[o].x * f2[o].x,
+                                f01[o][1].x + 2.0f * xv[o].y * f01[o][1].y + yv[o].y * f2[o].y);
         }
     }
 }

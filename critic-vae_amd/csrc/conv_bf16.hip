@@ -605,54 +605,70 @@ struct WgradBf16Args {
 
 // WT_NW waves per workgroup (4: two workgroups per CU, 8 accumulator tiles per wave; 8: one workgroup per CU whose
 // 8 waves share every staged tile, 5 accumulator tiles per wave — better for the 32-channel layer E2)
-template <int H, int WT_NW, int W>
-__device__ __forceinline__ void wgrad_tr_body(f32x16 (&acc)[24 / WT_NW + 2], const __bf16* lds_in, const __bf16* lds_d, int ibase, int dbase,
+template <int H, int WT_NW, int W, int COB>
+__device__ __forceinline__ void wgrad_tr_body(f32x16 (&acc)[COB][24 / WT_NW + 2], const __bf16* lds_in, const __bf16* lds_d, int ibase, int dbase,
                                               bf16x8 ones) {
     using T = WtTile<H>;
     constexpr int JT = 24 / WT_NW;
     static_assert(T::KG % WT_NW == 0, "pixel groups per tile must split evenly over the waves");
 #pragma unroll
     for (int kg = 0; kg < T::KG; ++kg) {
-        const __bf16* dp = lds_d + dbase + T::pixbase(kg) * 32;
-        const bf16x8 bv = tr_frag(dp, dp + T::DT * 32);
+        bf16x8 bv[COB];
+#pragma unroll
+        for (int cb = 0; cb < COB; ++cb) {               // one [pixel][32 co] image per output-channel block
+            const __bf16* dp = lds_d + cb * T::NPX * 32 + dbase + T::pixbase(kg) * 32;
+            bv[cb] = tr_frag(dp, dp + T::DT * 32);
+        }
         const __bf16* ip = lds_in + ibase + T::halobase(kg) * 32;
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             const int tap = WT_NW * j + W, r = tap / 5, s = tap % 5;
             const __bf16* q = ip + (r * T::HTW + s) * 32;
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(q, q + T::IT * 32), bv, acc[j], 0, 0, 0);
+            const bf16x8 av = tr_frag(q, q + T::IT * 32);                    // one staged / fetched input fragment serves COB MFMAs
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb) acc[cb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[cb], acc[cb][j], 0, 0, 0);
         }
         if ((kg % WT_NW) == W) {
             const __bf16* q = ip + (4 * T::HTW + 4) * 32;
-            acc[JT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(q, q + T::IT * 32), bv, acc[JT], 0, 0, 0);
+            const bf16x8 av = tr_frag(q, q + T::IT * 32);
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb) acc[cb][JT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[cb], acc[cb][JT], 0, 0, 0);
         }
-        if ((kg % WT_NW) == ((W + 1) % WT_NW)) acc[JT + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bv, acc[JT + 1], 0, 0, 0);
+        if ((kg % WT_NW) == ((W + 1) % WT_NW)) {
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb) acc[cb][JT + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bv[cb], acc[cb][JT + 1], 0, 0, 0);
+        }
     }
 }
 
-template <int CIN, int COUT, int H, int WT_NW>
+// COB = 32-channel blocks of dy per workgroup.  2 for E2 (32 -> 64 channels, the layer with the largest tensors): the
+// staged input tile then serves both halves of the output channels instead of being fetched and staged again by a second
+// workgroup (round 2: 805 MB fetched for 403 MB of operands), and every input fragment read from LDS feeds two MFMAs.
+template <int CIN, int COUT, int H, int WT_NW, int COB>
 __global__ __launch_bounds__(WT_NW * 64, 2) void conv5x5_wgrad_tr_kernel(WgradBf16Args a) {
     using T = WtTile<H>;
     constexpr int WT_NT = WT_NW * 64, JT = 24 / WT_NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* lds_in = reinterpret_cast<__bf16*>(smem_raw);       // [halo pixel][32 ci], 64-byte rows
-    __bf16* lds_d = lds_in + T::HP * 32;                        // [pixel][32 co]
+    __bf16* lds_d = lds_in + T::HP * 32;                        // COB x [pixel][32 co]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int split = blockIdx.x, ci0 = blockIdx.y * 32, n0 = blockIdx.z * 32;
+    const int split = blockIdx.x, ci0 = blockIdx.y * 32, n0 = blockIdx.z * 32 * COB;
     // transposed-read address of this lane inside a block: row (pixel) (lane&15)>>2, columns 16*(group&1) + 4*(lane&3)
     const int g = lane >> 4, h = g >> 1, laneoff = ((lane & 15) >> 2) * 32 + 16 * (g & 1) + 4 * (lane & 3);
     const int ibase = h * T::IH * 32 + laneoff, dbase = h * T::DH * 32 + laneoff;
 
-    f32x16 acc[JT + 2];
+    f32x16 acc[COB][JT + 2];
 #pragma unroll
-    for (int j = 0; j < JT + 2; ++j)
+    for (int cb = 0; cb < COB; ++cb)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+        for (int j = 0; j < JT + 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[cb][j][v] = 0.f;
     bf16x8 zero8, ones;
 #pragma unroll
     for (int c = 0; c < 8; ++c) { zero8[c] = (__bf16)0.f; ones[c] = (__bf16)1.f; }
 
-    constexpr int IU = T::HP * 4, DU = T::NPX * 4, NI = (IU + WT_NT - 1) / WT_NT, ND = (DU + WT_NT - 1) / WT_NT;
+    constexpr int IU = T::HP * 4, DU = T::NPX * 4 * COB, NI = (IU + WT_NT - 1) / WT_NT, ND = (DU + WT_NT - 1) / WT_NT;
     bf16x8 rin[NI], rdo[ND];
     auto fetch = [&](int mt) {
         const int grp = mt / T::TPI, t = mt % T::TPI;
@@ -669,7 +685,7 @@ __global__ __launch_bounds__(WT_NW * 64, 2) void conv5x5_wgrad_tr_kernel(WgradBf
         }
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
-            const int q = tid + i * WT_NT, px = q >> 2, oc = q & 3;
+            const int q = tid + i * WT_NT, px = q / (4 * COB), oc = q % (4 * COB);      // oc: 16-byte unit of the pixel's 32*COB channels
             const int img = px / (T::TH * T::TW), rem = px % (T::TH * T::TW);
             const int gy = ty0 + rem / T::TW, gx = tx0 + rem % T::TW, ib = img0 + img;
             const bool ok = (DU % WT_NT == 0 || q < DU) && ib < a.B;
@@ -691,54 +707,62 @@ __global__ __launch_bounds__(WT_NW * 64, 2) void conv5x5_wgrad_tr_kernel(WgradBf
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const int q = tid + i * WT_NT;
-            if (DU % WT_NT == 0 || q < DU) *reinterpret_cast<bf16x8*>(lds_d + (size_t)q * 8) = rdo[i];
+            if (DU % WT_NT == 0 || q < DU) {
+                const int px = q / (4 * COB), oc = q % (4 * COB);
+                *reinterpret_cast<bf16x8*>(lds_d + ((size_t)(oc >> 2) * T::NPX + px) * 32 + (oc & 3) * 8) = rdo[i];
+            }
         }
         __syncthreads();
         if (mt + 1 < t1) fetch(mt + 1);         // in flight while this tile computes
         switch (wave) {
-            case 0: wgrad_tr_body<H, WT_NW, 0>(acc, lds_in, lds_d, ibase, dbase, ones); break;
-            case 1: wgrad_tr_body<H, WT_NW, 1>(acc, lds_in, lds_d, ibase, dbase, ones); break;
-            case 2: wgrad_tr_body<H, WT_NW, 2>(acc, lds_in, lds_d, ibase, dbase, ones); break;
-            case 3: wgrad_tr_body<H, WT_NW, 3>(acc, lds_in, lds_d, ibase, dbase, ones); break;
-            case 4: if constexpr (WT_NW == 8) wgrad_tr_body<H, WT_NW, 4>(acc, lds_in, lds_d, ibase, dbase, ones); break;
-            case 5: if constexpr (WT_NW == 8) wgrad_tr_body<H, WT_NW, 5>(acc, lds_in, lds_d, ibase, dbase, ones); break;
-            case 6: if constexpr (WT_NW == 8) wgrad_tr_body<H, WT_NW, 6>(acc, lds_in, lds_d, ibase, dbase, ones); break;
-            default: if constexpr (WT_NW == 8) wgrad_tr_body<H, WT_NW, 7>(acc, lds_in, lds_d, ibase, dbase, ones); break;
+            case 0: wgrad_tr_body<H, WT_NW, 0, COB>(acc, lds_in, lds_d, ibase, dbase, ones); break;
+            case 1: wgrad_tr_body<H, WT_NW, 1, COB>(acc, lds_in, lds_d, ibase, dbase, ones); break;
+            case 2: wgrad_tr_body<H, WT_NW, 2, COB>(acc, lds_in, lds_d, ibase, dbase, ones); break;
+            case 3: wgrad_tr_body<H, WT_NW, 3, COB>(acc, lds_in, lds_d, ibase, dbase, ones); break;
+            case 4: if constexpr (WT_NW == 8) wgrad_tr_body<H, WT_NW, 4, COB>(acc, lds_in, lds_d, ibase, dbase, ones); break;
+            case 5: if constexpr (WT_NW == 8) wgrad_tr_body<H, WT_NW, 5, COB>(acc, lds_in, lds_d, ibase, dbase, ones); break;
+            case 6: if constexpr (WT_NW == 8) wgrad_tr_body<H, WT_NW, 6, COB>(acc, lds_in, lds_d, ibase, dbase, ones); break;
+            default: if constexpr (WT_NW == 8) wgrad_tr_body<H, WT_NW, 7, COB>(acc, lds_in, lds_d, ibase, dbase, ones); break;
         }
     }
 
     float* out = a.slab + (size_t)split * (25 * CIN * COUT + COUT);     // slab row: [25][CIN][COUT] | bias[COUT]
 #pragma unroll
-    for (int j = 0; j < JT; ++j)
+    for (int cb = 0; cb < COB; ++cb)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int ci = ci0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-            out[((size_t)(WT_NW * j + wave) * CIN + ci) * COUT + n0 + li] = acc[j][v];
-        }
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int ci = ci0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+                out[((size_t)(WT_NW * j + wave) * CIN + ci) * COUT + n0 + cb * 32 + li] = acc[cb][j][v];
+            }
     // tap 24 and the bias row: every wave holds the partial of its pixel groups -> fixed-order sum through LDS
     float* red = reinterpret_cast<float*>(smem_raw);                    // [NW-1 waves][16][64]
     float* bred = red + (WT_NW - 1) * 16 * 64;                          // [NW waves][32]
-    __syncthreads();
-    if (wave > 0) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) red[((wave - 1) * 16 + v) * 64 + lane] = acc[JT][v];
-    }
-    if (lh == 0) bred[wave * 32 + li] = acc[JT + 1][0];                       // row 0 of (ones x dy) = column sums of dy
-    __syncthreads();
-    if (wave == 0) {
+    for (int cb = 0; cb < COB; ++cb) {
+        __syncthreads();
+        if (wave > 0) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            float x = acc[JT][v];
-#pragma unroll
-            for (int w2 = 0; w2 < WT_NW - 1; ++w2) x += red[(w2 * 16 + v) * 64 + lane];
-            const int ci = ci0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-            out[((size_t)24 * CIN + ci) * COUT + n0 + li] = x;
+            for (int v = 0; v < 16; ++v) red[((wave - 1) * 16 + v) * 64 + lane] = acc[cb][JT][v];
         }
-        if (blockIdx.y == 0 && lh == 0) {
-            float b = 0.f;
+        if (lh == 0) bred[wave * 32 + li] = acc[cb][JT + 1][0];                   // row 0 of (ones x dy) = column sums of dy
+        __syncthreads();
+        if (wave == 0) {
 #pragma unroll
-            for (int w2 = 0; w2 < WT_NW; ++w2) b += bred[w2 * 32 + li];
-            out[(size_t)25 * CIN * COUT + n0 + li] = b;
+            for (int v = 0; v < 16; ++v) {
+                float x = acc[cb][JT][v];
+#pragma unroll
+                for (int w2 = 0; w2 < WT_NW - 1; ++w2) x += red[(w2 * 16 + v) * 64 + lane];
+                const int ci = ci0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+                out[((size_t)24 * CIN + ci) * COUT + n0 + cb * 32 + li] = x;
+            }
+            if (blockIdx.y == 0 && lh == 0) {
+                float b = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < WT_NW; ++w2) b += bred[w2 * 32 + li];
+                out[(size_t)25 * CIN * COUT + n0 + cb * 32 + li] = b;
+            }
         }
     }
 }
@@ -761,18 +785,19 @@ static int run_wgrad_bf16(int B, const float* in, const float* dout, float* dw, 
                           int64_t* need) {
     using T = WtTile<H>;
     int tps, numTiles;
-    const int S = wgrad_bf16_splits<H>(B, (CIN / 32) * (COUT / 32), &tps, &numTiles);
+    constexpr int COB = (CIN == 32 && COUT == 64) ? 2 : 1;              // E2: both output-channel halves in one workgroup
+    const int S = wgrad_bf16_splits<H>(B, (CIN / 32) * (COUT / (32 * COB)), &tps, &numTiles);
     const int64_t n = (int64_t)25 * CIN * COUT, row = n + COUT;
     if (need) { *need = (int64_t)(S + 16) * row; return 0; }
     WgradBf16Args a{in, dout, ws, B, numTiles, tps};
     constexpr int WT_NW = CIN == 32 ? 8 : 4, WT_NT = WT_NW * 64;
-    constexpr int STAGE = (T::HP + T::NPX) * 64, RED = ((WT_NW - 1) * 16 * 64 + WT_NW * 32) * 4;
+    constexpr int STAGE = (T::HP + COB * T::NPX) * 64, RED = ((WT_NW - 1) * 16 * 64 + WT_NW * 32) * 4;
     constexpr int SMEM = STAGE > RED ? STAGE : RED;
-    auto kern = conv5x5_wgrad_tr_kernel<CIN, COUT, H, WT_NW>;
+    auto kern = conv5x5_wgrad_tr_kernel<CIN, COUT, H, WT_NW, COB>;
     static DeviceOnce once;
     { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(kern), SMEM); if (rc) return rc; }
     cvae_probe_begin(st);
-    hipLaunchKernelGGL(kern, dim3(S, CIN / 32, COUT / 32), dim3(WT_NT), SMEM, st, a);
+    hipLaunchKernelGGL(kern, dim3(S, CIN / 32, COUT / (32 * COB)), dim3(WT_NT), SMEM, st, a);
     cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();
     float* mid = ws + (size_t)S * row;

@@ -69,11 +69,30 @@ def _rel_l2(a, b):
 
 
 # Relative L2 error of the bf16-mode gradient (bf16 MFMA operands AND bf16 activation storage) against the fp32
-# oracle gradient at full size.  bf16 carries 8 significant bits and the error compounds backwards through the
-# encoder: measured (MI355X) 0.0001-0.014 on the decoder / fc tensors, 0.02-0.09 on encoder blocks 3..1, and the worst
-# tensor, the first conv's weight at the very end of the chain, 0.10 (64x64) / 0.16 (128x128).
-FULL_SIZE_REL_L2 = 0.2            # every tensor (cos >= 0.98)
-FULL_SIZE_REL_L2_DECODER = 0.03   # decoder convs, decoder_input, fc_mu / fc_var
+# oracle gradient at full size, per tensor, as MEASURED on the MI355X (the step is bit-reproducible, so these are exact
+# until a kernel changes); the test allows 1.5x each.  The error grows backwards through the encoder; the worst tensor
+# is the first conv's weight at the very end of the chain.  profiles/experiments/bf16_e1_ablation.py explains it
+# (profiles/r03_bf16_e1_ablation_*.txt): the element-wise error of d_a0 that the bf16 chain hands to block 0 is 0.23 rel
+# L2 (max-pool argmax flips + bf16 storage upstream) and averages down to 0.096 in dW1 at B = 2048 (0.18 at B = 256:
+# it is noise, ~1/sqrt(B)); block 0's own roundings (x, W1, dy0 to bf16; pooling of bf16-rounded y) add 0.033; both are
+# amplified by the cancellation BatchNorm's backward builds into the sum (|sum x dy| / sum |x dy| = 1.3e-3).
+MEASURED_REL_L2 = {
+    (2048, 64): {"e.model.0.weight": 0.1012, "e.model.1.weight": 0.0459, "e.model.1.bias": 0.0311, "e.model.4.weight": 0.0559,
+                 "e.model.5.weight": 0.0186, "e.model.5.bias": 0.0118, "e.model.8.weight": 0.0203, "e.model.9.weight": 0.0084,
+                 "e.model.9.bias": 0.0071, "e.model.12.weight": 0.0083, "e.model.13.weight": 0.0026, "e.model.13.bias": 0.0024,
+                 "e.fc_mu.weight": 0.0026, "e.fc_mu.bias": 0.0022, "e.fc_var.weight": 0.0022, "e.fc_var.bias": 0.0017,
+                 "d.model.0.weight": 0.0077, "d.model.0.bias": 0.0017, "d.model.3.weight": 0.0018, "d.model.3.bias": 0.0015,
+                 "d.model.6.weight": 0.0016, "d.model.6.bias": 0.0015, "d.model.9.weight": 0.0015, "d.model.9.bias": 0.0013,
+                 "d.model.12.weight": 0.0006, "d.model.12.bias": 0.0001, "d.decoder_input.weight": 0.0083, "d.decoder_input.bias": 0.0037},
+    (1024, 128): {"e.model.0.weight": 0.1621, "e.model.1.weight": 0.0897, "e.model.1.bias": 0.0482, "e.model.4.weight": 0.0804,
+                  "e.model.5.weight": 0.0385, "e.model.5.bias": 0.0251, "e.model.8.weight": 0.0339, "e.model.9.weight": 0.0141,
+                  "e.model.9.bias": 0.0101, "e.model.12.weight": 0.0117, "e.model.13.weight": 0.0016, "e.model.13.bias": 0.0013,
+                  "e.fc_mu.weight": 0.0014, "e.fc_mu.bias": 0.0009, "e.fc_var.weight": 0.0016, "e.fc_var.bias": 0.0012,
+                  "d.model.0.weight": 0.0128, "d.model.0.bias": 0.0017, "d.model.3.weight": 0.0019, "d.model.3.bias": 0.0017,
+                  "d.model.6.weight": 0.0016, "d.model.6.bias": 0.0014, "d.model.9.weight": 0.0017, "d.model.9.bias": 0.0015,
+                  "d.model.12.weight": 0.0008, "d.model.12.bias": 0.0003, "d.decoder_input.weight": 0.0138, "d.decoder_input.bias": 0.0061},
+}
+FULL_SIZE_MARGIN = 1.5            # x measured, + 2e-4 absolute for the tensors measured at ~1e-4
 FULL_SIZE_REL_L2_ALL = 0.02       # the whole flat gradient
 
 
@@ -81,8 +100,8 @@ FULL_SIZE_REL_L2_ALL = 0.02       # the whole flat gradient
 def test_bf16_full_size_configs(B, width):
     """BASELINE.json configs[2]/[3] (bf16, 2048 frames of 64x64 per GPU) and configs[4] (1024 frames of 128x128 per
     GPU) at FULL per-GPU size: finite, bit-reproducible across two runs, forward outputs and loss against the fp32
-    oracle run at the same size on the host, and every gradient tensor within a relative L2 error bound of the
-    oracle's (a far stronger statement than a cosine: rel L2 0.2 <=> cos >= 0.98; 0.03 <=> cos >= 0.9995)."""
+    oracle run at the same size on the host, and every gradient tensor within 1.5x its own measured relative L2 error
+    against the oracle's (MEASURED_REL_L2: 1e-4 .. 0.014 on decoder / fc tensors, 0.10 / 0.16 on the worst one)."""
     from critic_vae_amd.nets import VariationalAutoencoder
     from critic_vae_amd.train import FusedTrainer
     from critic_vae_amd import layout as L
@@ -119,10 +138,10 @@ def test_bf16_full_size_configs(B, width):
         errs[k] = e
     print(f"bf16 B={B} W={width}: loss {float(scal[0]):.6f} (oracle {float(out['total_loss'].detach()):.6f}); worst gradient rel L2 {worst}")
     print("   per tensor:", {k.replace("encoder.", "e.").replace("decoder.", "d."): round(e, 4) for k, e in errs.items()})
+    meas = MEASURED_REL_L2[(B, width)]
     for k, e in errs.items():
-        assert e < FULL_SIZE_REL_L2, (k, e)
-        if k.startswith("decoder.") or ".fc_" in k:
-            assert e < FULL_SIZE_REL_L2_DECODER, (k, e)
+        short = k.replace("encoder.", "e.").replace("decoder.", "d.")
+        assert e < FULL_SIZE_MARGIN * meas[short] + 2e-4, (k, e, meas[short])
     keys = sorted(errs)
     flat_got = torch.cat([got[k].flatten() for k in keys])
     flat_ref = torch.cat([p[k].grad.detach().flatten() for k in keys])
@@ -147,6 +166,40 @@ def test_bf16_training_trajectory_tracks_fp32():
     assert np.isfinite(curves["bf16"]).all()
     assert np.abs(curves["bf16"] - curves["f32"]).max() < 2e-2
     assert curves["bf16"][-1] < 0.6 * curves["bf16"][0]
+
+
+def test_bf16_config2_trains_like_fp32_at_full_batch():
+    """BASELINE.json configs[2] must TRAIN, not just step: 200 Adam steps (lr 5e-5, the reference's) at batch 2048 in
+    bf16 mode and in fp32 mode from the same weights on the same device-generated frames.  The loss curves must
+    stay together (max gap over the run) and end together (final-loss ratio); both must have gone down.
+    Measured on the MI355X: printed below."""
+    from critic_vae_amd.nets import VariationalAutoencoder
+    from critic_vae_amd.train import FusedTrainer
+    dev = torch.device("cuda:0")
+    B, STEPS = 2048, 200
+    curves = {}
+    for prec in ("bf16", "f32"):
+        vae = VariationalAutoencoder(max_batch=B, seed=0, precision=prec).to(dev)
+        tr = FusedTrainer(vae)
+        gen = torch.Generator(device=dev).manual_seed(77)
+        # the benchmark's synthetic frames, U[0,1) (BASELINE.json; finite MS-SSIM from the first step on): 8 batches, cycled
+        frames = torch.rand(8, B, 3, 64, 64, device=dev, generator=gen)
+        losses = torch.empty(STEPS, 3, device=dev)
+        for i in range(STEPS):
+            x = frames[i % 8]
+            pr = torch.rand(B, 1, device=dev, generator=gen)
+            ep = torch.randn(B, 32, device=dev, generator=gen)
+            losses[i] = tr.step(x, pr, ep)[:3]
+        torch.cuda.synchronize()
+        curves[prec] = losses.cpu()
+        del tr, vae
+    a, b = curves["bf16"][:, 0], curves["f32"][:, 0]
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    gap, ratio = float((a - b).abs().max()), float(a[-8:].mean() / b[-8:].mean())
+    print(f"bf16 vs f32, {STEPS} steps at B={B}: loss {float(b[0]):.4f} -> f32 {float(b[-1]):.4f} / bf16 {float(a[-1]):.4f}; "
+          f"max |gap| {gap:.2e}, final ratio {ratio:.5f}")
+    assert float(b[-8:].mean()) < 0.9 * float(b[0]) and float(a[-8:].mean()) < 0.9 * float(a[0]), "the loss must go down"
+    assert gap < 1.5e-3 and abs(ratio - 1.0) < 5e-4          # measured: max gap 4.7e-4, ratio 0.99999
 
 
 def test_unknown_precisions_are_rejected():
@@ -181,35 +234,34 @@ def test_bf16_inference_path_matches_fp32_mode():
 def test_bf16x9_emulation_meets_the_fp32_parity_bar(B, mode):
     """precision="bf16x9": operands split exactly into three bf16 parts, nine exact partial products per
     fp32 product -> only the summation order differs from fp32 ("bf16x6" keeps the six leading products and
-    drops three terms of relative size <= 2^-24 each — the size of one fp32 rounding).  Held to the fp32 bar of
-    tests/test_gpu_step.py: 1e-4 absolute everywhere; relative to each gradient tensor's max 5e-3 (the fp32
-    test allows 1e-3 for ReLU / max-pool decisions that flip within an ulp of zero; another summation
-    order flips a few other elements — measured worst case 3.9e-3 = 2.1e-6 absolute on enc2.weight)."""
+    drops three terms of relative size <= 2^-24 each — the size of one fp32 rounding).  Held to the SAME bar as the
+    fp32 mode (tests/decisions.py, as tests/test_gpu_step.py uses it): 1e-4 absolute on outputs, loss and every
+    gradient element; the max-pool / ReLU decisions that differ from the oracle's are counted and shown to be ties;
+    every gradient element within 1e-4 of its tensor's max against the oracle run with those decisions imposed.
+    (Round 2 allowed 5e-3 relative here instead; test_gpu_step.py::test_step_b256_fp32_against_oracle runs the same
+    check at the bench size.)"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from decisions import check_step_against_oracle
     from critic_vae_amd.nets import VariationalAutoencoder
-    from critic_vae_amd.train import FusedTrainer
-    from critic_vae_amd import layout as L
     dev = torch.device("cuda:0")
-    params, (x, pred, eps), p, out = _oracle_step(B)
-    xs, ps, es = (torch.from_numpy(v).to(dev) for v in (x, pred, eps))
+    x, pred, eps = (torch.from_numpy(v) for v in synth.make_batch(1234, 0, B))
     res = {}
     for prec in (mode, "f32"):
         vae = VariationalAutoencoder(max_batch=B, seed=0, precision=prec).to(dev)
-        tr = FusedTrainer(vae)
-        scal = tr.step(xs, ps, es).cpu()
-        res[prec] = (tr.mu[:B].cpu(), tr.recon[:B].cpu(), float(scal[0]), L.native_to_ref(vae.handle.layout, tr.grads.cpu()))
-    mu, recon, loss, got = res[mode]
-    assert (mu - out["mu"].detach()).abs().max() < 1e-4
-    assert (recon - out["recon"].detach()).abs().max() < 1e-4
-    assert abs(loss - float(out["total_loss"].detach())) < 1e-4
-    for k, v in p.items():
-        if v.grad is None:
-            continue
-        g, want = got[k].double(), v.grad.detach().double()
-        err = (g - want).abs().max().item()
-        assert err <= 1e-4, (k, err)
-        pre_bn_bias = k.startswith("encoder.model.") and k.endswith(".bias") and int(k.split(".")[2]) % 4 == 0
-        if not pre_bn_bias:
-            assert err <= 5e-3 * max(want.abs().max().item(), 1e-30), (k, err)
+        vae.load_reference_params(synth.make_params(0))
+        out = vae(x.to(dev), pred.to(dev), eps=eps.to(dev))
+        losses = vae.vae_loss(*out)
+        losses["total_loss"].backward()
+        torch.cuda.synchronize()
+        res[prec] = (out[1].detach().cpu(), out[3].detach().cpu(), float(losses["total_loss"].item()))
+        if prec == mode:
+            rep, o = check_step_against_oracle(vae, x, pred, eps, B)
+            assert rep is not None and rep["rel_forced"] <= 1e-4
+    mu, recon, loss = res[mode]
+    assert (mu - o["mu"].detach()).abs().max() < 1e-4
+    assert (recon - o["recon"].detach()).abs().max() < 1e-4
+    assert abs(loss - float(o["total_loss"].detach())) < 1e-4
     # and it sits as close to the fp32-MFMA mode as that mode sits to the oracle
     assert (mu - res["f32"][0]).abs().max() < 2e-5 and (recon - res["f32"][1]).abs().max() < 2e-5
 

@@ -22,9 +22,9 @@ def _inputs(dseed, step, B, first=0, width=64):
     return torch.from_numpy(x), torch.from_numpy(pred), torch.from_numpy(eps)
 
 
-def _model(B, wseed=0, width=64):
+def _model(B, wseed=0, width=64, precision="f32"):
     assert torch.cuda.is_available()
-    vae = VariationalAutoencoder(max_batch=B, seed=wseed, width=width).cuda()
+    vae = VariationalAutoencoder(max_batch=B, seed=wseed, width=width, precision=precision).cuda()
     vae.load_reference_params(synth.make_params(wseed, width))
     return vae
 
@@ -123,14 +123,17 @@ def test_fused_e1_backward_equals_the_separate_apply_pass(monkeypatch, prec, wid
             assert torch.equal(a, b), k           # nothing else may change
 
 
-def test_step_b256_fp32_against_oracle():
+@pytest.mark.parametrize("precision", ["f32", "bf16x9", "bf16x6"])
+def test_step_b256_fp32_against_oracle(precision):
     """BASELINE.json configs[1] — the bench workload — at full size: fp32, B=256, vs the CPU oracle at 1e-4
     on mu / logvar / recon / the loss scalars and on EVERY gradient element; and at 1e-4 of each gradient
     tensor's max once the handful of max-pool / ReLU decisions that sit inside fp32 round-off of a tie are
-    imposed on the oracle (tests/decisions.py: they are counted, and each is shown to be a tie)."""
+    imposed on the oracle (tests/decisions.py: they are counted, and each is shown to be a tie).
+    The fp32-emulation modes (exact 3-way bf16 operand splits on the bf16 MFMA: "bf16x9" all nine partial products,
+    "bf16x6" the six leading ones) are held to exactly the same bar — same test, same tolerances."""
     B = 256
     x, pred, eps = _inputs(1234, 0, B)
-    vae = _model(B)
+    vae = _model(B, precision=precision)
     (_, mu, logvar, recon), losses = _step(vae, x, pred, eps)
     rep, o = check_step_against_oracle(vae, x, pred, eps, B, verbose=True)
     assert rep is not None, "seed must give a finite loss"

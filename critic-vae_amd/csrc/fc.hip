@@ -133,22 +133,34 @@ __global__ __launch_bounds__(256) void fc_finish_kernel(const float* __restrict_
     if (d == 0) zcat[b * 33 + 32] = pred[b];
 }
 
-// h[b][j] = bd[j] + sum_i zcat[b][i] * Wd[i][j]
+// h[b][j] = bd[j] + sum_i zcat[b][i] * Wd[i][j].  Workgroup = 1024 columns x DI_IMGS images: every 16-byte load of Wd
+// serves DI_IMGS images (one image per workgroup re-read the 33 x K weights B times from L2: 1.1 GB at B = 2048,
+// 44 us; now 69 MB).  Per output the sum still runs i = 0..32 from the bias.
+static constexpr int DI_IMGS = 16;
 template <typename AT>
 __global__ __launch_bounds__(256) void decin_fwd_kernel(const float* __restrict__ zcat, const float* __restrict__ wd,
-                                                        const float* __restrict__ bd, float* __restrict__ h, int K) {
-    __shared__ float z[33];
-    const int b = blockIdx.x, j = (blockIdx.y * 256 + threadIdx.x) * 4;
-    if (threadIdx.x < 33) z[threadIdx.x] = zcat[b * 33 + threadIdx.x];
+                                                        const float* __restrict__ bd, float* __restrict__ h, int K, int B) {
+    __shared__ float z[DI_IMGS][33];
+    const int b0 = blockIdx.y * DI_IMGS, j = (blockIdx.x * 256 + threadIdx.x) * 4;
+    for (int q = threadIdx.x; q < DI_IMGS * 33; q += 256) z[q / 33][q % 33] = b0 + q / 33 < B ? zcat[(size_t)b0 * 33 + q] : 0.f;
     __syncthreads();
-    float4 acc = *reinterpret_cast<const float4*>(bd + j);
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(bd + j);
+    f32x4 acc[DI_IMGS];
 #pragma unroll
+    for (int m = 0; m < DI_IMGS; ++m) acc[m] = bias;
+#pragma unroll 3
     for (int i = 0; i < 33; ++i) {
-        const float4 w = *reinterpret_cast<const float4*>(wd + (size_t)i * K + j);
-        acc.x = fmaf(z[i], w.x, acc.x); acc.y = fmaf(z[i], w.y, acc.y);
-        acc.z = fmaf(z[i], w.z, acc.z); acc.w = fmaf(z[i], w.w, acc.w);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wd + (size_t)i * K + j);
+#pragma unroll
+        for (int m = 0; m < DI_IMGS; ++m) {
+            const float zv = z[m][i];                         // wave-uniform LDS broadcast
+            acc[m][0] = fmaf(zv, w[0], acc[m][0]); acc[m][1] = fmaf(zv, w[1], acc[m][1]);
+            acc[m][2] = fmaf(zv, w[2], acc[m][2]); acc[m][3] = fmaf(zv, w[3], acc[m][3]);
+        }
     }
-    Act<AT>::st4(h, (size_t)b * K + j, f32x4{acc.x, acc.y, acc.z, acc.w});
+#pragma unroll
+    for (int m = 0; m < DI_IMGS; ++m)
+        if (b0 + m < B) Act<AT>::st4(h, (size_t)(b0 + m) * K + j, acc[m]);
 }
 
 // dzcat[b][i] = sum_j dh[b][j] * Wd[i][j].  One wave = 2 images x all 33 rows of Wd: lanes split K,
@@ -220,25 +232,36 @@ __global__ __launch_bounds__(256) void fc_bwd_prep_kernel(const float* __restric
     dml[b * 64 + 32 + d] = dz * eps[idx] * 0.5f * expf(0.5f * logvar[idx]) + dlv_loss[idx];
 }
 
-// dflat[b][k] = sum_n dml[b][n] * Wfc[k][n]
+// dflat[b][k] = sum_n dml[b][n] * Wfc[k][n].  Thread = one k (its 64 weights in registers), workgroup = 256 k x DF_IMGS
+// images (8 images per workgroup re-read the 1 MB of Wfc 256 times at B = 2048 and ran at 42 us); n = 0..63 in order.
+static constexpr int DF_IMGS = 32;
 template <typename AT>
 __global__ __launch_bounds__(256) void fc_bwd_dflat_kernel(const float* __restrict__ dml, const float* __restrict__ wfc,
                                                            float* __restrict__ dflat, int B, int K) {
-    __shared__ float g[8][64];
-    const int b0 = blockIdx.x * 8, k = blockIdx.y * 256 + threadIdx.x;
-    for (int q = threadIdx.x; q < 8 * 64; q += 256) g[q >> 6][q & 63] = (b0 + (q >> 6) < B) ? dml[(size_t)(b0 + (q >> 6)) * 64 + (q & 63)] : 0.f;
+    __shared__ __attribute__((aligned(16))) float g[DF_IMGS][64];
+    const int b0 = blockIdx.x * DF_IMGS, k = blockIdx.y * 256 + threadIdx.x;
+    for (int q = threadIdx.x; q < DF_IMGS * 16; q += 256) {
+        const int r = q >> 4, c4 = q & 15;
+        *reinterpret_cast<f32x4*>(&g[r][c4 * 4]) = b0 + r < B ? *reinterpret_cast<const f32x4*>(dml + (size_t)(b0 + r) * 64 + c4 * 4)
+                                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     __syncthreads();
     float w[64];
 #pragma unroll
     for (int n4 = 0; n4 < 16; ++n4) {
-        const float4 v = *reinterpret_cast<const float4*>(wfc + (size_t)k * 64 + n4 * 4);
-        w[n4 * 4] = v.x; w[n4 * 4 + 1] = v.y; w[n4 * 4 + 2] = v.z; w[n4 * 4 + 3] = v.w;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wfc + (size_t)k * 64 + n4 * 4);
+        w[n4 * 4] = v[0]; w[n4 * 4 + 1] = v[1]; w[n4 * 4 + 2] = v[2]; w[n4 * 4 + 3] = v[3];
     }
-    for (int i = 0; i < 8; ++i) {
+#pragma unroll 4
+    for (int i = 0; i < DF_IMGS; ++i) {
         if (b0 + i >= B) break;
         float acc = 0.f;
 #pragma unroll
-        for (int n = 0; n < 64; ++n) acc = fmaf(g[i][n], w[n], acc);
+        for (int n4 = 0; n4 < 16; ++n4) {
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(&g[i][n4 * 4]);      // wave-uniform 16-byte LDS broadcast
+            acc = fmaf(gv[0], w[n4 * 4], acc); acc = fmaf(gv[1], w[n4 * 4 + 1], acc);
+            acc = fmaf(gv[2], w[n4 * 4 + 2], acc); acc = fmaf(gv[3], w[n4 * 4 + 3], acc);
+        }
         Act<AT>::st(dflat, (size_t)(b0 + i) * K + k, acc);
     }
 }
@@ -523,8 +546,8 @@ int launch_fc_fwd(int width, int B, const float* flat, const float* wfc, const f
 
 int launch_decin_fwd(int width, int B, const float* zcat, const float* wd, const float* bd, float* h, hipStream_t st, bool bf16io) {
     const int K = bott(width);
-    if (bf16io) hipLaunchKernelGGL(decin_fwd_kernel<__bf16>, dim3(B, K / 1024), dim3(256), 0, st, zcat, wd, bd, h, K);
-    else hipLaunchKernelGGL(decin_fwd_kernel<float>, dim3(B, K / 1024), dim3(256), 0, st, zcat, wd, bd, h, K);
+    if (bf16io) hipLaunchKernelGGL(decin_fwd_kernel<__bf16>, dim3(K / 1024, cdiv(B, DI_IMGS)), dim3(256), 0, st, zcat, wd, bd, h, K, B);
+    else hipLaunchKernelGGL(decin_fwd_kernel<float>, dim3(K / 1024, cdiv(B, DI_IMGS)), dim3(256), 0, st, zcat, wd, bd, h, K, B);
     CVAE_CHECK_LAUNCH();
     return 0;
 }
@@ -568,8 +591,8 @@ int launch_fc_bwd(int width, int B, const float* flat, const float* wfc, const f
     CVAE_CHECK_LAUNCH();
     int rc = launch_colsum(dml, B, 64, dbfc, csws, st);
     if (rc) return rc;
-    if (bf16io) hipLaunchKernelGGL(fc_bwd_dflat_kernel<__bf16>, dim3(cdiv(B, 8), K / 256), dim3(256), 0, st, dml, wfc, dflat, B, K);
-    else hipLaunchKernelGGL(fc_bwd_dflat_kernel<float>, dim3(cdiv(B, 8), K / 256), dim3(256), 0, st, dml, wfc, dflat, B, K);
+    if (bf16io) hipLaunchKernelGGL(fc_bwd_dflat_kernel<__bf16>, dim3(cdiv(B, DF_IMGS), K / 256), dim3(256), 0, st, dml, wfc, dflat, B, K);
+    else hipLaunchKernelGGL(fc_bwd_dflat_kernel<float>, dim3(cdiv(B, DF_IMGS), K / 256), dim3(256), 0, st, dml, wfc, dflat, B, K);
     CVAE_CHECK_LAUNCH();
     if (bf16io) {        // flat^T . dml on the bf16 MFMA
         BGemmArgs g{flat, dml, K, 64, 0, dwfc, 64, K, nullptr, B};

@@ -1,34 +1,71 @@
-"""HBM bytes per launch of the probed kernels, from the rocprofv3 PMC passes of bench.py.
+"""HBM bytes per launch of the probed kernels, from the rocprofv3 PMC passes of bench.py, per workload.
 
-    python profiles/make_traffic_json.py <pmc_fetch_dir> <pmc_write_dir> > profiles/traffic_per_launch.json
+    python profiles/make_traffic_json.py f32_b256_w64=<fetch_dir>,<write_dir> bf16_b2048_w64=<f>,<w> bf16_b1024_w128=<f>,<w> \\
+        > profiles/traffic_per_launch.json
 
-bytes = 2 * FETCH_SIZE + WRITE_SIZE (both in KiB; FETCH_SIZE under-reports wide streaming reads by
-exactly 2x on gfx950 — MI355X_MICROARCH.md, HBM section), averaged over the launches in the pass.
-bench.py reads the result for `roofline.traffic` (same workload: fp32, batch 256).
+bytes = 2 * FETCH_SIZE + WRITE_SIZE (both in KiB; FETCH_SIZE under-reports wide streaming reads by exactly 2x on gfx950 —
+MI355X_MICROARCH.md, HBM section), averaged over the launches in the pass.  The x2 is calibrated on this code's own
+access shapes by the BatchNorm apply kernels, whose byte counts are known exactly: fp32 `bn_bwd_kernel<0,1>` (16-byte
+float4 accesses) 168.1 MB counted vs 167.8 MB algorithmic, bf16 `bn_bwd_bf16_kernel<0,1>` (16-byte units of 8 bf16,
+4 lanes per 64-byte pixel row — the access shape of the bf16 conv / weight-gradient staging loads) 503.9 MB vs 503.3 MB.
+bench.py reads the result for `roofline.traffic` / `roofline_hbm.traffic` of the same workload (key = precision_bB_wW).
 """
 import collections
 import csv
 import glob
 import json
 import os
+import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from source_stamp import kernel_source_sha  # noqa: E402
 
-CONV = {  # probe name -> kernel-name prefix
-    "conv_fwd_L1": "void conv5x5_mfma_kernel<32, 64, 32, false, false", "conv_fwd_L2": "void conv5x5_mfma_kernel<64, 128, 16, false, false",
-    "conv_fwd_L3": "void conv5x5_mfma_kernel<128, 256, 8, false, false", "conv_fwd_L4": "void conv5x5_mfma_kernel<256, 128, 4, false, false",
-    "conv_dgrad_L1": "void conv5x5_mfma_kernel<64, 32, 32, false, true", "conv_dgrad_L2": "void conv5x5_mfma_kernel<128, 64, 16, false, true",
-    "conv_dgrad_L3": "void conv5x5_mfma_kernel<256, 128, 8, false, true", "conv_dgrad_L4": "void conv5x5_mfma_kernel<128, 256, 4, false, true",
-    "conv_wgrad_L1": "void conv5x5_wgrad_kernel<32, 64, 32,", "conv_wgrad_L2": "void conv5x5_wgrad_kernel<64, 128, 16,",
-    "conv_wgrad_L3": "void conv5x5_wgrad_kernel<128, 256, 8,", "conv_wgrad_L4": "void conv5x5_wgrad_kernel<256, 128, 4,",
-    "conv_fwd_L5": "void conv_up_fwd_kernel<128, 64, 4,", "conv_fwd_L6": "void conv_up_fwd_kernel<64, 32, 8,", "conv_fwd_L7": "void conv_up_fwd_kernel<32, 32, 16,",
-    "conv_dgrad_L5": "void conv_up_dgrad_kernel<128, 64, 4,", "conv_dgrad_L6": "void conv_up_dgrad_kernel<64, 32, 8,", "conv_dgrad_L7": "void conv_up_dgrad_kernel<32, 32, 16,",
-    "conv_wgrad_L5": "void conv_up_wgrad_kernel<128, 64, 4>", "conv_wgrad_L6": "void conv_up_wgrad_kernel<64, 32, 8>", "conv_wgrad_L7": "void conv_up_wgrad_kernel<32, 32, 16>",
-}
-BN_RELU_APPLY = "void bn_bwd_kernel<0, 1>"      # launched for blocks 2, 1 in that order every step (block 0: fused into E1's weight-gradient kernel)
-BN_TANH_APPLY = "void bn_bwd_kernel<1, 1>"      # block 3
+LAYERS = [(3, 32, 64), (32, 64, 32), (64, 128, 16), (128, 256, 8), (256, 128, 4), (128, 64, 8), (64, 32, 16), (32, 32, 32)]
+
+
+def patterns(prec, width):
+    """probe name -> regex on the kernel name (layer geometry scaled to `width`)."""
+    k = width // 64
+    p = {}
+    for l in range(1, 8):
+        cin, cout, h = LAYERS[l]
+        h *= k
+        if prec == "f32":
+            if l <= 4:
+                p[f"conv_fwd_L{l}"] = rf"conv5x5_mfma_kernel<{cin}, {cout}, {h}, false, false"
+                p[f"conv_dgrad_L{l}"] = rf"conv5x5_mfma_kernel<{cout}, {cin}, {h}, false, true"
+                p[f"conv_wgrad_L{l}"] = rf"conv5x5_wgrad_kernel<{cin}, {cout}, {h},"
+            else:                                      # phase-collapsed up-convs run at the stored (low) resolution
+                p[f"conv_fwd_L{l}"] = rf"conv_up_fwd_kernel<{cin}, {cout}, {h // 2},"
+                p[f"conv_dgrad_L{l}"] = rf"conv_up_dgrad_kernel<{cin}, {cout}, {h // 2},"
+                p[f"conv_wgrad_L{l}"] = rf"conv_up_wgrad_kernel<{cin}, {cout}, {h // 2}>"
+        else:
+            if l <= 4:
+                p[f"conv_fwd_L{l}"] = rf"conv5x5_bf16_kernel<{cin}, {cout}, {h}, \d+, [02], \d+, 5, 0,"
+                p[f"conv_dgrad_L{l}"] = rf"conv5x5_bf16_kernel<{cout}, {cin}, {h}, \d+, 2, \d+, 5, 0,"
+                p[f"conv_wgrad_L{l}"] = rf"conv5x5_wgrad_tr_kernel<{cin}, {cout}, {h},"
+            else:
+                p[f"conv_fwd_L{l}"] = rf"conv5x5_bf16_kernel<{cin}, {4 * cout}, {h // 2}, \d+, 2, 1, 3, 1,"
+                p[f"conv_dgrad_L{l}"] = rf"conv5x5_bf16_kernel<{4 * cout}, {cin}, {h // 2}, \d+, 2, 1, 3, 2,"
+                p[f"conv_wgrad_L{l}"] = rf"conv_up_wgrad_bf16_kernel<{cin}, {cout}, {h // 2}>"
+    if prec == "f32":
+        p["e1_fwd"] = rf"e1_fwd_kernel<{width}>"
+        p["e1_wgrad"] = rf"e1_wgrad_kernel<{width}, true>"
+        p["d4_fwd"] = rf"d4_fwd_kernel<{width}, float>"
+        p["d4_bwd"] = rf"d4_bwd_kernel<{width}, float>"
+    else:
+        p["e1_fwd"] = rf"e1_fwd_bf16_kernel<{width}, 2>"
+        p["e1_wgrad"] = rf"e1_wgrad_bf16_kernel<{width}, true>"
+        p["d4_fwd"] = rf"d4_fwd_bf16_kernel<{width}>"
+        p["d4_bwd"] = rf"d4_bwd_bf16_kernel<{width}>"
+    p["msssim_fwd_level0"] = rf"msssim_fwd_kernel<{width}>"
+    return p
+
+
+def bn_names(prec):
+    base = "bn_bwd_kernel" if prec == "f32" else "bn_bwd_bf16_kernel"
+    return f"void {base}<0, 1>", f"void {base}<1, 1>"       # ReLU blocks 2, 1 (in launch order; block 0 is fused into E1's wgrad) / Tanh block 3
 
 
 def load(d, counter):
@@ -40,28 +77,40 @@ def load(d, counter):
     return {k: [v for _, v in sorted(vs)] for k, vs in per.items()}
 
 
-def pick(table, prefix):
+def pick(table, rx):
     for k, v in table.items():
-        if k.startswith(prefix):
+        if re.search(rx, k):
             return v
     return []
 
 
-fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-out = {}
-for name, prefix in CONV.items():
-    f, w = pick(fetch, prefix), pick(write, prefix)
+def one(prec, width, fdir, wdir):
+    fetch, write = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
+    out = {}
+    for name, rx in patterns(prec, width).items():
+        f, w = pick(fetch, rx), pick(write, rx)
+        if f and w:
+            out[name] = round(2 * sum(f) / len(f) + sum(w) / len(w))
+    relu, tanh = bn_names(prec)
+    f, w = pick(fetch, re.escape(relu)), pick(write, re.escape(relu))
+    for i, layer in enumerate((2, 1)):
+        fi, wi = f[i::2], w[i::2]
+        if fi and wi:
+            out[f"bn_pool_bwd_apply_L{layer}"] = round(2 * sum(fi) / len(fi) + sum(wi) / len(wi))
+    f, w = pick(fetch, re.escape(tanh)), pick(write, re.escape(tanh))
     if f and w:
-        out[name] = round(2 * sum(f) / len(f) + sum(w) / len(w))
-f, w = pick(fetch, BN_RELU_APPLY), pick(write, BN_RELU_APPLY)
-for i, layer in enumerate((2, 1)):
-    fi, wi = f[i::2], w[i::2]
-    if fi and wi:
-        out[f"bn_pool_bwd_apply_L{layer}"] = round(2 * sum(fi) / len(fi) + sum(wi) / len(wi))
-f, w = pick(fetch, BN_TANH_APPLY), pick(write, BN_TANH_APPLY)
-if f and w:
-    out["bn_pool_bwd_apply_L3"] = round(2 * sum(f) / len(f) + sum(w) / len(w))
-json.dump({"workload": "bench.py, fp32, batch 256, one MI355X", "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (see profiles/README.md)",
+        out["bn_pool_bwd_apply_L3"] = round(2 * sum(f) / len(f) + sum(w) / len(w))
+    return out
+
+
+res = {}
+for arg in sys.argv[1:]:
+    key, dirs = arg.split("=")
+    fdir, wdir = dirs.split(",")
+    m = re.fullmatch(r"(\w+)_b(\d+)_w(\d+)", key)
+    res[key] = {"workload": f"bench.py, {m.group(1)}, batch {m.group(2)}, {m.group(3)}x{m.group(3)} frames, one MI355X",
+                "bytes_per_launch": one(m.group(1), int(m.group(3)), fdir, wdir)}
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (see profiles/README.md)",
            "formula": "2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes, mean over launches",
-           "kernel_source_sha256": kernel_source_sha(), "bytes_per_launch": out}, sys.stdout, indent=1)
+           "kernel_source_sha256": kernel_source_sha(), "workloads": res}, sys.stdout, indent=1)
 print()

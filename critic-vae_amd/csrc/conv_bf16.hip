@@ -62,6 +62,10 @@ enum { MODE_STD = 0, MODE_UP_FWD = 1, MODE_UP_DGRAD = 2 };
 #ifndef BF16_MT
 #define BF16_MT 2          // 128-pixel tiles per workgroup of the plain bf16 kernels (1 = round-1 structure)
 #endif
+#ifndef BF16_WDMA
+#define BF16_WDMA 0        // 1 (experiment, round 3): weight slabs travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) into a double
+#endif                     // buffer, one barrier per K stage.  Correct (tests green) but SLOWER on the MI355X: E2 fwd 227 -> 237 us, E2 dgrad
+                           // 223 -> 261, E4 dgrad 206 -> 227, E3 fwd 206 -> 216 at B = 2048 (0: registers -> ds_write_b128, two barriers per stage)
 
 __device__ __forceinline__ bf16x8 to_bf16x8(f32x4 lo, f32x4 hi) {
     bf16x8 r;
@@ -98,9 +102,13 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     constexpr int KB = KCB / 16, OCT = KCB / 8, NB = NT / 32;
     constexpr int PSP = Bf16Geom<H, OCT>::PSP;
     constexpr int A_UNITS = OCT * PSP, W_UNITS = KS * KB * 2 * NT;
+    // WDMA (bf16 mode): the weight slab of stage st+1 is copied HBM -> LDS by LDS-DMA while stage st computes — no staging
+    // registers, no ds_write_b128 (13 issue cycles each), and with two slab buffers ONE barrier per stage: the slab's unit
+    // order in LDS is the staging thread order (unit q <- thread q), which is exactly the DMA's "wave base + lane * 16".
+    constexpr bool WDMA = NS == 1 && BF16_WDMA != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);      // [tile][split][octet][halo pixel]
-    bf16x8* lds_w = lds_a + MT * NS * A_UNITS;                 // [split][tap][kb][half][n]
+    bf16x8* lds_w = lds_a + MT * NS * A_UNITS;                 // [buffer (WDMA: 2)][split][tap][kb][half][n]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int mt0 = xcd_tile(blockIdx.x, gridDim.x) * MT, n0 = blockIdx.y * NT;
@@ -125,7 +133,8 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
 
     // weight slab of stage (cc, r): units [s][kb][half][n] <- wp[(r*5+s)][cc*KB + kb][half][n0 + n]
     constexpr int WPT = (W_UNITS + 255) / 256;
-    bf16x8 wreg[NS * WPT];
+    static_assert(!WDMA || W_UNITS % 64 == 0, "whole wave-instructions of 64 units");
+    bf16x8 wreg[WDMA ? 1 : NS * WPT];
     // per-thread part of every staging address is fixed for the whole launch: computed once, so a stage adds one
     // wave-uniform term per load instead of redoing the div/mod chains (they were ~3 VALU instructions per MFMA)
     int wbase[WPT];
@@ -145,6 +154,16 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
 #pragma unroll
                 for (int sp = 0; sp < NS; ++sp) wreg[sp * WPT + i] = wst[wbase[i] + sp * a.splitStride];
             }
+        }
+    };
+    auto dma_w = [&](int st, int buf) {          // WDMA: stage st's slab -> lds_w buffer `buf`
+        const int cc = st / KS, r = st % KS;
+        const bf16x8* wst = a.wp + (size_t)(r * KS * (KCH / 16) + cc * KB) * 2 * NCH;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            if (W_UNITS % 256 == 0 || i * 256 + wave * 64 < W_UNITS)          // wave-uniform
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wst + wbase[i]),
+                                                 (__attribute__((address_space(3))) void*)(lds_w + buf * W_UNITS + i * 256 + wave * 64), 16, 0, 0);
         }
     };
     auto store_w = [&]() {
@@ -238,10 +257,22 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     static_assert(KCH % KCB == 0 && (KCH / KCB) % KSPLIT == 0, "channel chunking");
     constexpr int NST = (KCH / KCB) / KSPLIT * KS;
     const int st0 = blockIdx.z * NST, st1 = st0 + NST;
-    load_w(st0);
+    if constexpr (WDMA) dma_w(st0, 0); else load_w(st0);
     load_input(st0 / KS);
     for (int st = st0; st < st1; ++st) {
         const int r = st % KS;
+        int wbuf = 0;
+        if constexpr (WDMA) {
+            wbuf = (st - st0) & 1;
+            if (r == 0) {
+                __syncthreads();                   // chunk boundary: everyone finished reading the previous chunk's input tiles
+                store_input();
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of slab st has landed (and the next chunk's inputs)
+            __syncthreads();                       // slab st (and the input tiles) visible to all; everyone is done with slab st-1
+            if (r == 0 && st + KS < st1) load_input(st / KS + 1);
+            if (st + 1 < st1) dma_w(st + 1, wbuf ^ 1);            // lands in the buffer stage st-1 read, while this stage computes
+        } else {
         __syncthreads();                       // everyone finished reading the previous stage
         if (r == 0) store_input();
         store_w();
@@ -250,8 +281,9 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
         if (r == 0 && st + KS < st1) load_input(st / KS + 1);
         if (st + 1 < st1) load_w(st + 1);      // in flight while this stage computes
         __syncthreads();
+        }
         const bf16x8* ap = lds_a + lh * PSP + aPix + (r + OFF) * T::HTW + OFF;
-        const bf16x8* bp = lds_w + lh * NT + li;
+        const bf16x8* bp = lds_w + wbuf * W_UNITS + lh * NT + li;
         if (NS == 1) __builtin_amdgcn_iglp_opt(0);         // interleave the LDS fragment reads with the MFMAs
 #pragma unroll
         for (int s = 0; s < KS; ++s)
@@ -443,7 +475,8 @@ template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT = 1, int KS = 5, 
 static int run_bf16_ns(const ConvBf16Args& a, hipStream_t st) {
     using T = Tile<H>;
     constexpr int KCB = Bf16Chunk<KCH, NS, MT>::KCB;
-    constexpr int STAGE = (MT * NS * (KCB / 8) * Bf16Geom<H, KCB / 8>::PSP + NS * KS * (KCB / 16) * 2 * NT) * 16;
+    constexpr int WBUF = (NS == 1 && BF16_WDMA != 0) ? 2 : 1;          // LDS-DMA weight slabs are double-buffered
+    constexpr int STAGE = (MT * NS * (KCB / 8) * Bf16Geom<H, KCB / 8>::PSP + WBUF * NS * KS * (KCB / 16) * 2 * NT) * 16;
     constexpr int EPI_BYTES = (8 * NT > 4 * 32 * 36 ? 8 * NT : 4 * 32 * 36) * 4;
     constexpr int SMEM = STAGE > EPI_BYTES ? STAGE : EPI_BYTES;
     auto kern = conv5x5_bf16_kernel<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, NS, DMAX, MT>;

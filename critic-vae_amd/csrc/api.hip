@@ -35,6 +35,17 @@ void cvae_probe_end(hipStream_t st) {
     if (p && p->n < PROBE_CAP) { (void)hipEventRecord(p->e1[p->n], st); p->n++; }
 }
 
+int cvae_num_cus() {
+    static std::atomic<int> cached[64];                      // per device ordinal; 0 = not yet queried
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int n = cached[dev & 63].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev & 63].store(n, std::memory_order_relaxed);
+    return n;
+}
+
 struct SideRed { hipStream_t st; hipEvent_t ev; };
 static thread_local const SideRed* g_side_red = nullptr;
 hipStream_t cvae_reduce_stream(hipStream_t st) {

@@ -162,6 +162,9 @@ inline int cvae_grant_lds(DeviceOnce& once, const void* kernel, int bytes) {
     return 0;
 }
 
+// Compute units of the current device (256 on the MI355X), queried once per device: sizes the persistent grids.
+int cvae_num_cus();
+
 // ---- launchers implemented across the .hip files (all asynchronous on `st`) ----
 // conv_mfma.hip
 int launch_conv_fwd(int layer, int width, int B, const float* in, const float* w, const float* bias,

@@ -113,9 +113,9 @@ __global__ __launch_bounds__(256) void e1_fwd_kernel(const float* __restrict__ x
 }
 
 // precision mode 1, E1 forward.  The frame strip is staged ONCE as bf16 pixels of 4 channels (r, g, b, 0) — 8 bytes per
-// pixel, rows of 40 pixels — so the 5 taps x 4 channels of one kernel row are 20 CONSECUTIVE bf16 values: an A
-// fragment (8 consecutive k of one pixel) is two 8-byte LDS reads instead of 8 scalar reads + 8 conversions.
-// K per kernel row = 20 padded to 32 (zero weights): 10 MFMAs per 32 pixels, 40 weight registers per lane.
+// pixel, rows of 40 pixels — so the 4 channels of one tap are ONE 8-byte LDS unit: an A fragment (8 consecutive k) is
+// two 8-byte LDS reads instead of 8 scalar reads + 8 conversions.  K = 25 taps x 4 = 100 padded to 112 (zero weights):
+// 7 MFMAs per 32 pixels (e1_wk_* above), 28 weight registers per lane.
 // y1 leaves as bf16 (16-byte units), the BatchNorm partials come from the fp32 accumulators.
 // PASS (the bf16 training step runs the kernel TWICE instead of reading y1 back — the 75-tap conv is ~1 % of the
 // step's MFMA work, the tensor it produces is the step's largest):
@@ -128,9 +128,48 @@ __global__ __launch_bounds__(256) void e1_fwd_kernel(const float* __restrict__ x
 //              written here and read there (1.07 GB per step at B = 2048).  Exceptions: keepY != 0 (the CVAE_FUSE_E1=0
 //              A/B path, whose separate apply pass reads y1), and steps in which a channel has |gamma| < 1e-2: the
 //              BatchNorm-backward statistics kernel then takes xhat of that channel from y1 (bn.hip).
+// K-packed form of the 75-tap contraction (round 3).  The staged strip holds bf16 pixels of 4 channels (r, g, b, 0), so the
+// four channels of one tap are one 8-byte LDS unit and an MFMA's K = 16 is FOUR taps (two per lane half): 25 taps -> 7
+// MFMAs (the kernel-row form padded each row's 5 taps to 8: 10 MFMAs).  Tap assignment — chosen so that lane half 1 reads
+// at a FIXED pixel offset from lane half 0 (two extra base pointers instead of per-lane offset tables):
+//   MFMA j = 0..4 : kernel row j, columns (0, 1) | (2, 3)           half 1 = half 0 + 2 columns
+//   MFMA 5        : column 4, rows (0, 1) | (2, 3)                  half 1 = half 0 + 2 rows
+//   MFMA 6        : tap (4, 4), then zero weights                   (both halves read tap (4,4): finite values x 0)
+// The forward passes AND the weight-gradient kernel's recompute run exactly this sequence (j = 0..6 into one
+// accumulator), so they produce the same fp32 sums to the bit.
+__device__ __forceinline__ constexpr int e1_wk_tap(int j, int lh, int u) {        // -> r*5 + s, or -1 (zero weight)
+    return j < 5 ? j * 5 + 2 * lh + u : (j == 5 ? (2 * lh + u) * 5 + 4 : (lh == 0 && u == 0 ? 24 : -1));
+}
+__device__ __forceinline__ void e1_wk_load(const float* __restrict__ w, int li, int lh, bf16x8 (&bw)[7]) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int t = lh ? e1_wk_tap(j, 1, e >> 2) : e1_wk_tap(j, 0, e >> 2), c = e & 3;
+            bw[j][e] = (__bf16)((t >= 0 && c < 3) ? w[(t * 3 + c) * 32 + li] : 0.f);
+        }
+}
+// p = this lane's output pixel in the strip image (tap (0,0)), row stride HWX units
+template <int HWX>
+__device__ __forceinline__ f32x16 e1_wk_conv(const bf16x4* __restrict__ p, int lh, const bf16x8 (&bw)[7]) {
+    const bf16x4* pc = p + 2 * lh;                  // lane half 1: + 2 columns
+    const bf16x4* pr = p + 2 * HWX * lh;            // lane half 1: + 2 rows
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const bf16x4 lo = j < 5 ? pc[j * HWX] : (j == 5 ? pr[4] : p[4 * HWX + 4]);
+        const bf16x4 hi = j < 5 ? pc[j * HWX + 1] : (j == 5 ? pr[HWX + 4] : p[4 * HWX + 4]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), bw[j], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 enum { E1_Y = 0, E1_STATS = 1, E1_POOL = 2 };
 template <int H, int PASS>
-__global__ __launch_bounds__(256) void e1_fwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256, PASS == 1 ? 3 : 2) void e1_fwd_bf16_kernel(      // statistics pass: 3 workgroups per CU (<= 168 VGPRs)
+                                                         const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           float* __restrict__ bnpart, int B,
                                                           const float* __restrict__ coef, float* __restrict__ a1, int numStrips, int keepY) {
@@ -142,16 +181,8 @@ __global__ __launch_bounds__(256) void e1_fwd_bf16_kernel(const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     // persistent: the 80 weights of this lane are fetched and converted ONCE per workgroup (one workgroup per strip spent
     // more instructions on them than on the strip), and the next strip's frame values travel during this strip's MFMAs
-    bf16x8 bw[5][2];                    // B[k = 16kb + 8lh + j][n = li] of kernel row r: k = 4*s + c
-#pragma unroll
-    for (int r = 0; r < 5; ++r)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 16 * kb + 8 * lh + j, sI = k >> 2, c = k & 3;
-                bw[r][kb][j] = (__bf16)((sI < 5 && c < 3) ? w[((r * 5 + sI) * 3 + c) * 32 + li] : 0.f);
-            }
+    bf16x8 bw[7];                       // K-packed B fragments (e1_wk_load)
+    e1_wk_load(w, li, lh, bw);
     const float bv = bias[li];
     bool wr_y = PASS != E1_STATS;
     if constexpr (PASS == E1_POOL) {
@@ -187,20 +218,7 @@ __global__ __launch_bounds__(256) void e1_fwd_bf16_kernel(const float* __restric
         if (strip + (int)gridDim.x < numStrips) fetch(strip + gridDim.x);
         f32x16 acc[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[r][v] = 0.f;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-            for (int r = 0; r < 5; ++r)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    const bf16x4* p = lds_x + (wave * 4 + rr + r) * HWX + li + 4 * kb + 2 * lh;
-                    const bf16x4 lo = p[0], hi = p[1];
-                    const bf16x8 av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw[r][kb], acc[rr], 0, 0, 0);
-                }
+        for (int rr = 0; rr < 4; ++rr) acc[rr] = e1_wk_conv<HWX>(lds_x + (wave * 4 + rr) * HWX + li, lh, bw);
         // epilogue: element v of lane (li, lh) in tile r = pixel column (v&3)+8*(v>>2)+4*lh of row 4*wave+r, channel li
         float s = 0.f;
         float* patch = patch_all + wave * (32 * 36);
@@ -462,66 +480,73 @@ __global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a, E1Fuse f
     thin_slab_out(acc, smem, a.slab + (size_t)blockIdx.x * 96 * 32, bsum, true);
 }
 
-// precision mode 1, E1 weight gradient.  GEMM per kernel row r: dW_r[m = 4s + c][co] = sum_px P_r[px][m] * dy[px][co]
-// with P_r[px][m] = x[c][y + r - 2][px + s - 2].  The frame strip is staged as bf16 pixels of 4 channels (as in the
-// forward), so P_r is an OVERLAPPED row-major view of it (row px starts 4 elements after row px-1) and the A operand
-// is a transposed LDS read (ds_read_b64_tr_b16) — no per-element gather, no conversion in the loop.
-// Wave w owns tile row w (32 pixels, 2 k-steps): 10 MFMAs + 2 for the bias row (ones x dy) per tile.
-// Slab row of a workgroup: [5 kernel rows][32 m][32 co] (m >= 20 and c == 3 are padding) | bias[32] = 5152 floats.
-static constexpr int E1W_ROW = 5 * 32 * 32 + 32;
-// FUSE (see E1Fuse), round 3: dy of block 0 is produced HERE from x, a0 and d_a0 alone — y1 is not read, it is not even
-// stored by the forward any more.  Per tile (4 rows x 32 columns):
-//   1. each wave runs the forward's 75-tap conv (10 bf16 MFMAs, the forward's operand fragments and accumulation
-//      order: the fp32 sums, hence the bf16-rounded y values and the window argmax, are the forward's to the bit) on
-//      its 2-row x 16-column quadrant: accumulator element v of lane (li, lh) is channel li of quadrant pixel
-//      m = (v&3) + 8(v>>2) + 4lh = (row m>>4, column m&15), so the four values of a 2x2 pooling window are elements
-//      v, v+1, v+8, v+9 of ONE lane;
-//   2. in the lane: yb = bf16(acc + bias); first maximum of fmaf(yb, scale, shift) in scan order;
-//      dy[p] = (p == argmax ? g*scale : 0) - (A + Bc*yb[p]) with g = d_a0*[a0 > 0], Bc = scale*k2*invstd,
-//      A = scale*k1 - Bc*mean (the apply pass's formula with the per-channel constants folded); a0 / d_a0 tiles arrive
-//      by one 16-byte load per thread, a tile ahead, and are picked up per (window, channel) from LDS;
+// precision mode 1, E1 weight gradient:  dW[m'][co] = sum_px P[px][m'] * dy[px][co],  m' = 4t + c, tap t = 5r + s,
+// P[px][4t + c] = x[c][y + r - 2][px + s - 2].  The frame strip is staged as bf16 pixels of 4 channels (as in the forward), so
+// the four channels of (pixel, tap) are ONE 8-byte LDS unit and a column block of P is reached by transposed LDS reads
+// (ds_read_b64_tr_b16: every lane supplies the address of one (pixel, tap) unit) — no per-element gather, no conversion
+// in the loop.  M-packed (round 3): the 25 taps + one all-ones unit (bias row = column sums of dy) + zero units fill
+// M = 128 = 4 MFMAs per 16 pixels (the kernel-row form padded each row's 20 values to 32: 5 + 1 MFMAs, 96 accumulator
+// registers instead of 64).  Wave w owns tile row w (32 pixels, 2 k-steps): 8 MFMAs per tile.
+// Slab row of a workgroup: [128 m'][32 co]; m' = 100 is the bias row (101..103 repeat it, 104.. are zero).
+static constexpr int E1W_ROW = 128 * 32;
+// FUSE (see E1Fuse): dy of block 0 is produced HERE from x, a0 and d_a0 alone — y1 is not read, it is not even stored by
+// the forward any more.  Per tile (4 rows x 32 columns):
+//   1. each wave runs the forward's 75-tap conv (e1_wk_conv: the forward's operand fragments and accumulation order, so
+//      the fp32 sums, hence the bf16-rounded y values and the window argmax, are the forward's to the bit) on its 2-row x
+//      16-column quadrant: accumulator element v of lane (li, lh) is channel li of quadrant pixel m = (v&3) + 8(v>>2) + 4lh
+//      = (row m>>4, column m&15), so the four values of a 2x2 pooling window are elements v, v+1, v+8, v+9 of ONE lane;
+//   2. in the lane, on packed fp32 (two columns of a window per instruction): yb = bf16(acc + bias); first maximum of
+//      fmaf(yb, scale, shift) in scan order; dy[p] = (p == argmax ? g*scale : 0) - (A + Bc*yb[p]) with g = d_a0*[a0 > 0],
+//      Bc = scale*k2*invstd, A = scale*k1 - Bc*mean (the apply pass's formula with the per-channel constants folded);
+//      a0 / d_a0 tiles arrive by one 16-byte load per thread, a tile ahead, and are picked up per (window, channel) from LDS;
 //   3. dy goes to LDS CHANNEL-major ([co][tile pixel], 8-byte stores of 4 consecutive pixels), so the B operand of the
 //      weight-gradient MFMA (8 consecutive pixels of one channel) is a plain 16-byte read.
 static constexpr int E1W_DT = 136;          // row stride of the channel-major dy tile in elements (68 dwords: conflict-free 16-byte reads)
+typedef float f32x2t __attribute__((ext_vector_type(2)));
+#ifndef E1W_OCC
+#define E1W_OCC 3          // workgroups per CU of the bf16 E1 weight-gradient kernel (VGPR budget 512 / (E1W_OCC) per lane; splits = E1W_OCC * CUs)
+#endif
 template <int H, bool FUSE>
-__global__ __launch_bounds__(256) void e1_wgrad_bf16_kernel(ThinWgradArgs a, E1Fuse fu) {
+__global__ __launch_bounds__(256, E1W_OCC) void e1_wgrad_bf16_kernel(ThinWgradArgs a, E1Fuse fu) {
     using T = Tile<H>;
     static_assert(T::TW == 32 && T::TH == 4 && T::IMGS == 1, "one tile row per wave");
-    constexpr int HWX = 40, HR_ = T::TH + 4, NPXH = HR_ * HWX;
-    __shared__ __attribute__((aligned(16))) bf16x4 lds_x[NPXH + 8];
+    constexpr int HWX = 40, HR_ = T::TH + 4, NPXH = HR_ * HWX, U_ONES = NPXH + 8, U_ZERO = NPXH + 9;
+    __shared__ __attribute__((aligned(16))) bf16x4 lds_x[NPXH + 10];          // strip | 8 over-read pad units | ones | zeros
     __shared__ __attribute__((aligned(16))) __bf16 lds_d[FUSE ? 32 * E1W_DT : 128 * 32];     // FUSE: [co][E1W_DT]; else [px][32]
     __shared__ __attribute__((aligned(16))) __bf16 lds_p[FUSE ? 2 * 32 * 32 : 8];             // FUSE: a0 | d_a0 tiles [pooled px][32]
     __shared__ float red[3 * 1024];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int g = lane >> 4, h = g >> 1, qrow = (lane & 15) >> 2, cb = 16 * (g & 1) + 4 * (lane & 3);
-    f32x16 acc[6];
+    f32x16 acc[4];
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
-    bf16x8 ones;
+    if (tid < 10) {
+        const __bf16 fill = (__bf16)(tid == 8 ? 1.f : 0.f);
+        bf16x4 z; z[0] = z[1] = z[2] = z[3] = fill;
+        lds_x[NPXH + tid] = z;
+    }
+    // transposed-read unit of this lane in M block b: tap t = 8b + 4(g&1) + (lane&3) -> element offset of (row r_t, column s_t)
+    // relative to the lane's pixel; t = 25: the ones unit (bias row), t > 25: the zeros unit
+    int moff[4];
+    bool mconst[4];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) ones[c] = (__bf16)1.f;
-    if (tid < 8) { bf16x4 z; z[0] = z[1] = z[2] = z[3] = (__bf16)0.f; lds_x[NPXH + tid] = z; }      // over-read pad of the last row
+    for (int b = 0; b < 4; ++b) {
+        const int t = 8 * b + 4 * (g & 1) + (lane & 3);
+        mconst[b] = t >= 25;
+        moff[b] = t < 25 ? ((t / 5) * HWX + t % 5) * 4 : (t == 25 ? U_ONES * 4 : U_ZERO * 4);
+    }
     const int t0 = blockIdx.x * a.tilesPerSplit;
     int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
     constexpr int XQ = (NPXH + 255) / 256;
     float rx[XQ][3];
     bf16x8 rd[2];
     bf16x8 rp;                                       // FUSE: 8 channels of one pooled pixel of a0 (threads 0..127) / d_a0 (128..255)
-    // FUSE: the forward's B operand (e1_fwd_bf16_kernel): B[k = 16kb + 8lh + j][n = li] of kernel row r, k = 4*s + c
-    bf16x8 bw[FUSE ? 5 : 1][2];
+    bf16x8 bw[7];                                    // FUSE: the forward's K-packed B fragments
     float bv = 0.f, bsc = 0.f, bsh = 0.f, bA = 0.f, bB = 0.f;         // this lane's channel li
     if constexpr (FUSE) {
-#pragma unroll
-        for (int r = 0; r < 5; ++r)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = 16 * kb + 8 * lh + j, sI = k >> 2, c = k & 3;
-                    bw[r][kb][j] = (__bf16)((sI < 5 && c < 3) ? fu.w[((r * 5 + sI) * 3 + c) * 32 + li] : 0.f);
-                }
+        e1_wk_load(fu.w, li, lh, bw);
         bv = fu.bias[li];
         const float sc = fu.coef[li * 4], mean = fu.coef[li * 4 + 2], invstd = fu.coef[li * 4 + 3];
         bsc = sc; bsh = fu.coef[li * 4 + 1];
@@ -573,36 +598,31 @@ __global__ __launch_bounds__(256) void e1_wgrad_bf16_kernel(ThinWgradArgs a, E1F
         if constexpr (FUSE) {
             // 1. the forward conv of this wave's quadrant: rows 2(wave>>1) + (li>>4), columns 16(wave&1) + (li&15)
             const int qr = 2 * (wave >> 1), qc = 16 * (wave & 1);
-            f32x16 cacc;
-#pragma unroll
-            for (int v = 0; v < 16; ++v) cacc[v] = 0.f;
-#pragma unroll
-            for (int r = 0; r < 5; ++r)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    const bf16x4* p = lds_x + (qr + (li >> 4) + r) * HWX + qc + (li & 15) + 4 * kb + 2 * lh;
-                    const bf16x4 lo = p[0], hi = p[1];
-                    const bf16x8 av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw[r][kb], cacc, 0, 0, 0);
-                }
-            // 2. BatchNorm / pool / ReLU backward of the lane's four windows (quadrant columns 4lh + {0,2,8,10}), channel li
+            const f32x16 cacc = e1_wk_conv<HWX>(lds_x + (qr + (li >> 4)) * HWX + qc + (li & 15), lh, bw);
+            // 2. BatchNorm / pool / ReLU backward of the lane's four windows (quadrant columns 4lh + {0,2,8,10}), channel li;
+            //    the two columns of a window row travel as one packed pair
+            const f32x2t bv2 = {bv, bv}, sc2 = {bsc, bsc}, sh2 = {bsh, bsh}, bA2 = {bA, bA}, bB2 = {bB, bB};
             bf16x4 dq[2][2];                         // [row of the quadrant][column group 0-3 / 8-11] -> 4 consecutive pixels
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int v = 2 * j, m0 = (v & 3) + 8 * (v >> 2) + 4 * lh;          // first column of the window
                 const int pp = (wave >> 1) * 16 + 8 * (wave & 1) + (m0 >> 1);
                 const float av = (float)lds_p[pp * 32 + li], gv = (float)lds_p[1024 + pp * 32 + li];
-                float yv[4], mx = 0.f; int pos = 0;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {                                       // scan order: (row 0: v, v+1), (row 1: v+8, v+9)
-                    yv[p] = (float)(__bf16)(cacc[v + (p & 1) + 8 * (p >> 1)] + bv);     // the value the forward pooled
-                    const float n = fmaf(yv[p], bsc, bsh);
-                    if (p == 0 || n > mx) { mx = n; pos = p; }
-                }
+                // the values the forward pooled: bf16(acc + bias), rows 0 / 1 of the window
+                const f32x2t s0 = f32x2t{cacc[v], cacc[v + 1]} + bv2, s1 = f32x2t{cacc[v + 8], cacc[v + 9]} + bv2;
+                const f32x2t y0 = {(float)(__bf16)s0.x, (float)(__bf16)s0.y}, y1 = {(float)(__bf16)s1.x, (float)(__bf16)s1.y};
+                const f32x2t n0 = __builtin_elementwise_fma(y0, sc2, sh2), n1 = __builtin_elementwise_fma(y1, sc2, sh2);
+                // first maximum in scan order (0, 1 | 2, 3): tournament with strict comparisons = the forward's sequential scan
+                const bool c01 = n0.y > n0.x, c23 = n1.y > n1.x;
+                const float m01 = c01 ? n0.y : n0.x, m23 = c23 ? n1.y : n1.x;
+                const bool hi = m23 > m01;
                 const float gs = av > 0.f ? gv * bsc : 0.f;
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-                    dq[p >> 1][j >> 1][2 * (j & 1) + (p & 1)] = (__bf16)((p == pos ? gs : 0.f) - fmaf(bB, yv[p], bA));
+                const f32x2t t0v = __builtin_elementwise_fma(bB2, y0, bA2), t1v = __builtin_elementwise_fma(bB2, y1, bA2);
+                const f32x2t sel0 = {(!hi && !c01) ? gs : 0.f, (!hi && c01) ? gs : 0.f};
+                const f32x2t sel1 = {(hi && !c23) ? gs : 0.f, (hi && c23) ? gs : 0.f};
+                const f32x2t d0 = sel0 - t0v, d1 = sel1 - t1v;
+                dq[0][j >> 1][2 * (j & 1)] = (__bf16)d0.x; dq[0][j >> 1][2 * (j & 1) + 1] = (__bf16)d0.y;
+                dq[1][j >> 1][2 * (j & 1)] = (__bf16)d1.x; dq[1][j >> 1][2 * (j & 1) + 1] = (__bf16)d1.y;
             }
             // 3. channel-major dy tile: pixel index = tile row * 32 + column
 #pragma unroll
@@ -622,18 +642,18 @@ __global__ __launch_bounds__(256) void e1_wgrad_bf16_kernel(ThinWgradArgs a, E1F
                 const __bf16* dp = lds_d + (wave * 32 + px) * 32 + cb;
                 bvv = tr_frag(dp, dp + 4 * 32);
             }
+            const __bf16* pb = xs + (wave * HWX + px) * 4;               // this lane's pixel in the strip (tap (0,0))
 #pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                const __bf16* ap = xs + ((wave + r) * HWX + px) * 4 + cb;
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(ap, ap + 16), bvv, acc[r], 0, 0, 0);
+            for (int b = 0; b < 4; ++b) {
+                const __bf16* ap = mconst[b] ? xs + moff[b] : pb + moff[b];
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(ap, mconst[b] ? ap : ap + 16), bvv, acc[b], 0, 0, 0);
             }
-            acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bvv, acc[5], 0, 0, 0);
         }
     }
     // every wave contracted its own tile rows: fixed-order sum over the 4 waves, one accumulator at a time
     float* out = a.slab + (size_t)blockIdx.x * E1W_ROW;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < 4; ++j) {
         __syncthreads();
         if (wave > 0) {
 #pragma unroll
@@ -641,28 +661,24 @@ __global__ __launch_bounds__(256) void e1_wgrad_bf16_kernel(ThinWgradArgs a, E1F
         }
         __syncthreads();
         if (wave == 0) {
-            if (j < 5) {
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float x = ((acc[j][v] + red[v * 64 + lane]) + red[(16 + v) * 64 + lane]) + red[(32 + v) * 64 + lane];
-                    const int m = (v & 3) + 8 * (v >> 2) + 4 * lh;
-                    out[(j * 32 + m) * 32 + li] = x;
-                }
-            } else if (lh == 0) {
-                out[5 * 32 * 32 + li] = ((acc[5][0] + red[lane]) + red[16 * 64 + lane]) + red[32 * 64 + lane];     // row 0 = column sums of dy
+            for (int v = 0; v < 16; ++v) {
+                const float x = ((acc[j][v] + red[v * 64 + lane]) + red[(16 + v) * 64 + lane]) + red[(32 + v) * 64 + lane];
+                const int m = (v & 3) + 8 * (v >> 2) + 4 * lh;
+                out[(j * 32 + m) * 32 + li] = x;
             }
         }
     }
 }
 
-// dW1[(r*5+s)*3+c][co] <- reduced slab row [r][4s+c][co]; db1 <- its bias tail
+// dW1[(5r+s)*3+c][co] <- reduced slab row m' = 4(5r+s) + c; db1 <- row 100 (the ones unit)
 __global__ __launch_bounds__(256) void e1_perm_kernel(const float* __restrict__ red, float* __restrict__ dw, float* __restrict__ db) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < 2400) {
-        const int n = i & 31, k = i >> 5, c = k % 3, tap = k / 3, r = tap / 5, sI = tap % 5;
-        dw[i] = red[(r * 32 + 4 * sI + c) * 32 + n];
+        const int n = i & 31, k = i >> 5, c = k % 3, tap = k / 3;
+        dw[i] = red[(4 * tap + c) * 32 + n];
     } else if (i < 2432 && db) {
-        db[i - 2400] = red[5 * 32 * 32 + i - 2400];
+        db[i - 2400] = red[100 * 32 + i - 2400];
     }
 }
 
@@ -690,15 +706,15 @@ __global__ __launch_bounds__(256) void d4_perm_kernel(const float* __restrict__ 
     dst[i] = red[(tap * 3 + co) * 32 + ci];
 }
 
-static int thin_splits(int numTiles, int* tps) {
-    int S = numTiles < 512 ? numTiles : 512;
+static int thin_splits(int numTiles, int* tps, int want = 512) {
+    int S = numTiles < want ? numTiles : want;
     *tps = cdiv(numTiles, S);
     return cdiv(numTiles, *tps);
 }
 
 int64_t e1_wgrad_ws_floats(int width, int B) {
     int tps; const int tiles = B * (width / 4) * (width / 32);
-    const int64_t S = thin_splits(tiles, &tps);
+    const int64_t S = thin_splits(tiles, &tps, 1024);            // upper bound of the split counts used below
     const int64_t f32 = S * 3072 + col_reduce_ws_floats(3072);
     const int64_t b16 = S * E1W_ROW + E1W_ROW + 32 + col_reduce_ws_floats(E1W_ROW);     // slabs | reduced row | column-reduce scratch
     return f32 > b16 ? f32 : b16;
@@ -708,7 +724,7 @@ int launch_e1_fwd(int width, int B, const float* x, const float* w, const float*
                   float* bnpart, hipStream_t st, bool bf16, int pass, const float* coef, float* a1, bool keep_y) {
     const int keepY = keep_y ? 1 : 0;
     if (pass != 0 && !bf16) { cvae_set_error("e1_fwd: passes 1/2 exist in bf16 mode only"); return -2; }
-    const int ns64 = B * 8, ns128 = B * 32, cap = 256 * 3;        // persistent: 3 workgroups per CU (VGPR-limited), one strip each per turn
+    const int ns64 = B * 8, ns128 = B * 32, cap = cvae_num_cus() * 3;      // persistent: 3 workgroups per CU (<= 168 VGPRs), one strip each per turn
     const dim3 g64(ns64 < cap ? ns64 : cap), g128(ns128 < cap ? ns128 : cap);
     cvae_probe_begin(st);
     if (width == 64 && bf16 && pass == 1) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_STATS>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64, keepY);
@@ -729,7 +745,7 @@ int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw
                     const float* const* fuse) {
     if (width != 64 && width != 128) { cvae_set_error("e1_wgrad: width %d unsupported", width); return -2; }
     int tps; const int tiles = B * (width / 4) * (width / 32);
-    const int S = thin_splits(tiles, &tps);
+    const int S = thin_splits(tiles, &tps, bf16 ? E1W_OCC * cvae_num_cus() : 512);
     ThinWgradArgs a{x, nullptr, dy, nullptr, nullptr, ws, B, tiles, tps};
     // fuse = {y0, a0, d_a0, coef0, bcoef0, w1, b1}: block 0's BatchNorm/pool/ReLU backward is applied while staging (no dy
     // tensor); the bf16 kernel recomputes y0 from x, w1, b1 and never reads fuse[0]

@@ -884,11 +884,11 @@ __global__ __launch_bounds__(256) void d4_fwd_kernel(const float* __restrict__ i
 // = 2 k-steps x 3 column blocks: 6 MFMAs per 32 source pixels instead of 48 fp32 ones).  The source tile sits in LDS
 // as bf16 rows of 80 bytes (conflict-free 16-byte fragment reads); gather-sum, Tanh and the NCHW fp32 store are unchanged.
 template <int H>
-__global__ __launch_bounds__(256) void d4_fwd_bf16_kernel(const float* __restrict__ in, const float* __restrict__ w,
+__global__ __launch_bounds__(256, 3) void d4_fwd_bf16_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ recon, int B) {
     constexpr int HS = H / 2, TX = H / 16, TPI = TX * TX, AS = 40;      // AS: row stride of the source tile in elements
     __shared__ __attribute__((aligned(16))) __bf16 lds_a[128 * AS];
-    __shared__ float lds_q[128 * 97];
+    __shared__ float lds_q[100 * 97];                  // only the 10x10 window's rows are ever read: 49 KB with lds_a -> three workgroups per CU
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     bf16x8 bw[2][3];
 #pragma unroll
@@ -954,8 +954,10 @@ __global__ __launch_bounds__(256) void d4_fwd_bf16_kernel(const float* __restric
 #pragma unroll
         for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
-            for (int v = 0; v < 16; ++v)
-                lds_q[(wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh) * 97 + nb * 32 + li] = acc[nb][v];
+            for (int v = 0; v < 16; ++v) {
+                const int row = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+                if (row < 100) lds_q[row * 97 + nb * 32 + li] = acc[nb][v];
+            }
         __syncthreads();
         const int oy = tid >> 4, ox = tid & 15;
         float s0 = b0, s1 = b1, s2 = b2;
@@ -1117,8 +1119,11 @@ __global__ __launch_bounds__(256) void d4_bwd_kernel(ThinWgradArgs a) {
 // gradient is 5 MFMAs (K = 75 padded to 80, weights in registers), the weight gradient contracts each wave's 32 source
 // pixels in 2 k-steps x 3 row blocks with both operands read TRANSPOSED out of the row-major G / o3 tiles
 // (ds_read_b64_tr_b16): 11 MFMAs per 32 source pixels and wave instead of 86 fp32 ones.  o3 / d_o3 are bf16 in HBM.
+#ifndef D4B_OCC
+#define D4B_OCC 2          // workgroups per CU of the bf16 D4 backward (splits = D4B_OCC * CUs); 3 spills 41 registers: 321 us against 174
+#endif
 template <int H>
-__global__ __launch_bounds__(256) void d4_bwd_bf16_kernel(ThinWgradArgs a) {
+__global__ __launch_bounds__(256, D4B_OCC) void d4_bwd_bf16_kernel(ThinWgradArgs a) {
     constexpr int HS = H / 2, TPI = (HS / 8) * (HS / 16);
     constexpr int G0 = 3 * 720, GS = 88;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1262,18 +1267,20 @@ static_assert(D4_BWD_BF16_SMEM >= 3 * 3 * 1024 * 4, "thin_slab_out reuses the st
 
 static constexpr int D4_BWD_SMEM = (3 * 720 + 128 * 32 + 128 * 77 + 32 + 76 * 32) * 4;
 
-static int d4_splits(int width, int B, int* tps) {
-    return thin_splits(B * (width / 16) * (width / 32), tps);
+static int d4_splits(int width, int B, int* tps, bool bf16io = false) {
+    return thin_splits(B * (width / 16) * (width / 32), tps, bf16io ? D4B_OCC * cvae_num_cus() : 512);
 }
 // ws of launch_d4_bwd = [S*3072 split-K slab | B*3 plane sums of dOut]
 int64_t d4_bwd_ws_floats(int width, int B) {
     int tps;
-    return (int64_t)d4_splits(width, B, &tps) * 3072 + align_up((int64_t)B * 3, 64) + 3072 + col_reduce_ws_floats(3072);
+    const int64_t S = thin_splits(B * (width / 16) * (width / 32), &tps, 1024);        // upper bound of the split counts used
+    return S * 3072 + align_up((int64_t)B * 3, 64) + 3072 + col_reduce_ws_floats(3072);
 }
 
 int launch_d4_fwd(int width, int B, const float* in, const float* w, const float* bias, float* recon, hipStream_t st, bool bf16io) {
-    // 66 KB of LDS -> two workgroups per CU, each looping over its share of the 16x16 tiles
-    const int tiles = B * (width / 16) * (width / 16), grid = tiles < 512 ? tiles : 512;
+    // persistent: bf16 mode 49 KB of LDS -> three workgroups per CU; fp32 66 KB -> two; each loops over its share of the 16x16 tiles
+    const int want = (bf16io ? 3 : 2) * cvae_num_cus();
+    const int tiles = B * (width / 16) * (width / 16), grid = tiles < want ? tiles : want;
     cvae_probe_begin(st);
     if (width == 64 && bf16io) hipLaunchKernelGGL(d4_fwd_bf16_kernel<64>, dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
     else if (width == 128 && bf16io) hipLaunchKernelGGL(d4_fwd_bf16_kernel<128>, dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
@@ -1291,7 +1298,7 @@ int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const
     if (width != 64 && width != 128) { cvae_set_error("d4_bwd: width %d unsupported", width); return -2; }
     int tps;
     const int tiles = B * (width / 16) * (width / 32);
-    const int S = d4_splits(width, B, &tps);
+    const int S = d4_splits(width, B, &tps, bf16io);
     float* plane_sums = ws + (size_t)S * 3072;
     if (!bf16io) {      // fp32: Tanh backward as its own pass (writes dOut); bf16 mode applies it while the backward kernel stages
         hipLaunchKernelGGL(d4_actbwd_kernel, dim3(B * 3), dim3(256), 0, st, d_recon, recon, dout, plane_sums, width * width);

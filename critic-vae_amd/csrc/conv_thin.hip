@@ -13,6 +13,9 @@
 //                K=src pixels) — one fused kernel builds each G tile once in LDS for both.
 #include "common.h"
 #include "conv_epilogue.h"
+#ifndef THIN_F32_OCC
+#define THIN_F32_OCC 2      // waves per SIMD promised to the compiler for the fp32 E1 / D4 kernels (e1_fwd 160 -> 110 VGPRs; -1..2 us each)
+#endif
 
 // LDS offset of GEMM-k = tap*3 + ci inside the 3-plane x halo (k = 75 is the zero pad row)
 template <int PS, int HTW>
@@ -26,7 +29,7 @@ __device__ __forceinline__ constexpr int e1_off(int k) {
 // NHWC store, and the strip's BatchNorm partial (sum, M2 about the strip mean).
 // (precision mode 1 runs e1_fwd_bf16_kernel below instead.)
 template <int H>
-__global__ __launch_bounds__(256) void e1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256, THIN_F32_OCC) void e1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ y,
                                                      float* __restrict__ bnpart, int B) {
     constexpr int SR = 16, SW = 32, HW_ = SW + 4, HR_ = SR + 4, PS = ((3 * 0 + HW_ * HR_ + 5) / 8) * 8 + 2;
@@ -383,7 +386,7 @@ __device__ __forceinline__ void e1_wgrad_fetch(const ThinWgradArgs& a, const E1F
 
 // (precision mode 1 runs e1_wgrad_bf16_kernel below instead.)
 template <int H, bool FUSE>
-__global__ __launch_bounds__(256) void e1_wgrad_kernel(ThinWgradArgs a, E1Fuse fu) {
+__global__ __launch_bounds__(256, THIN_F32_OCC) void e1_wgrad_kernel(ThinWgradArgs a, E1Fuse fu) {
     using T = Tile<H>;
     static_assert(!FUSE || (T::TW == 32 && T::TH == 4 && T::IMGS == 1), "fused staging: 2 x 16 windows per tile");
     constexpr int X_FLOATS = ((3 * T::PS + 3) / 4) * 4;
@@ -792,7 +795,7 @@ __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f / (__ex
 // registers while the MFMAs of the current one run, and the tap gather + Tanh + NCHW store of one
 // workgroup overlaps the MFMAs of the other workgroup on the CU.
 template <int H, typename AT>   // H = output size (64); source o3 is (H/2)^2 x 32 NHWC, stored as AT
-__global__ __launch_bounds__(256) void d4_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
+__global__ __launch_bounds__(256, THIN_F32_OCC) void d4_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ recon, int B) {
     constexpr int HS = H / 2, TX = H / 16, TPI = TX * TX;
     __shared__ __attribute__((aligned(16))) float lds_a[128 * 33];
@@ -1022,7 +1025,7 @@ __device__ __forceinline__ void d4_bwd_fetch(const ThinWgradArgs& a, int mt, flo
 }
 
 template <int H, typename AT>   // H = output size (64); src tiles of 8 rows x 16 cols at HS = H/2; o3 / d_o3 stored as AT
-__global__ __launch_bounds__(256) void d4_bwd_kernel(ThinWgradArgs a) {
+__global__ __launch_bounds__(256, THIN_F32_OCC) void d4_bwd_kernel(ThinWgradArgs a) {
     constexpr int HS = H / 2, TPI = (HS / 8) * (HS / 16);
     constexpr int G0 = 3 * 720, O = 128 * 32, G = 128 * 77 + 32, WR = 76 * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];

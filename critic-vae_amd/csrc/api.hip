@@ -161,7 +161,7 @@ static void add_param(cvae_handle_s* h, int* idx, const char* name, int64_t nume
 
 extern "C" {
 
-const char* cvae_version(void) { return "critic-vae_amd 0.2 (gfx950; fp32 MFMA, bf16 MFMA with bf16 storage)"; }
+const char* cvae_version(void) { return "critic-vae_amd 0.3 (gfx950; fp32 MFMA, bf16 MFMA with bf16 storage)"; }
 const char* cvae_last_error(void) { return g_err; }
 
 int cvae_create(const cvae_config* cfg, cvae_handle* out) {

@@ -419,14 +419,21 @@ __global__ __launch_bounds__(256) void pack_w_bf16_kernel(PackJobs jobs) {
         const int n = u % N, row = u / N, half = row & 1, kb = (row >> 1) % (K / 16), tap = row / (2 * (K / 16));
         const int k0 = kb * 16 + half * 8;
         bf16x8 r0, r1, r2;
+        // the dgrad orientations contract over the source's FASTEST index (co): the unit's 8 values are 32 contiguous bytes
+        // -> two 16-byte loads (they were eight 4-byte loads a whole row apart between neighbouring lanes)
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+        if (mode == PACK_DGRAD || mode == PACK_UPDGRAD) {
+            const float* src = mode == PACK_DGRAD ? jb.w + ((size_t)(24 - tap) * cin + n) * cout + k0
+                                                  : jb.w + ((size_t)((k0 / cout) * 9 + 8 - tap) * cin + n) * cout + k0 % cout;
+            c0 = *reinterpret_cast<const f32x4*>(src); c1 = *reinterpret_cast<const f32x4*>(src + 4);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = k0 + e;
             float v;
             if (mode == PACK_FWD) v = jb.w[((size_t)tap * cin + k) * cout + n];
-            else if (mode == PACK_DGRAD) v = jb.w[((size_t)(24 - tap) * cin + n) * cout + k];
             else if (mode == PACK_UPFWD) v = jb.w[((size_t)((n / cout) * 9 + tap) * cin + k) * cout + n % cout];
-            else v = jb.w[((size_t)((k / cout) * 9 + 8 - tap) * cin + n) * cout + k % cout];
+            else v = e < 4 ? c0[e & 3] : c1[e & 3];
             if (jb.splits == 1) r0[e] = (__bf16)v;
             else { const Split3 sv = split3(v); r0[e] = sv.hi; r1[e] = sv.mid; r2[e] = sv.lo; }
         }

@@ -40,6 +40,9 @@ static constexpr int MS_NF = 32;            // finalize workgroups
 #ifndef CVAE_MS_NT
 #define CVAE_MS_NT 768
 #endif
+#ifndef CVAE_MS_RS
+#define CVAE_MS_RS 16        // tile rows of the 64- and 128-wide levels (32: one workgroup per CU, 117 KB of LDS)
+#endif
 #ifndef CVAE_MS_VR
 #define CVAE_MS_VR 2
 #endif
@@ -98,7 +101,7 @@ __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 template <int S>
 struct MsT {
     static constexpr int CS = S < 64 ? S : 64;             // tile columns
-    static constexpr int RS = S == 32 ? 32 : 16;           // tile rows
+    static constexpr int RS = S == 32 ? 32 : CVAE_MS_RS;   // tile rows
     static constexpr int TX = S / CS, TY = S / RS, TILES = TX * TY;
     static constexpr int ER = RS + 20;                      // input rows staged (tile + 2 window radii)
     static constexpr int MR = RS + 10, MC = CS + 10;        // map region (tile + 1 window radius)
@@ -107,7 +110,8 @@ struct MsT {
     static constexpr int DAS = MCP + 2;                     // row stride of the (d_mu, d_11) image; DAS / 2 is ODD
     // (an item of a horizontal pass reads 16-byte units 32 bytes apart from its neighbour's: with an odd row stride in
     //  16-byte units, lanes that alternate between two rows cover all 16 slots of the 256-byte bank row: conflict-free)
-    static constexpr int LIN = 2 * ER * ECP;                // floats: (x, y) pixels [ER][ECP]; later (d_mu, d_11) [MR][DAS] | d_12 [MR][MCP]
+    static constexpr int LIN_IN = 2 * ER * ECP, LIN_D = 2 * MR * DAS + MR * MCP;
+    static constexpr int LIN = LIN_IN > LIN_D ? LIN_IN : LIN_D;   // floats: (x, y) pixels [ER][ECP]; later (d_mu, d_11) [MR][DAS] | d_12 [MR][MCP]
     static constexpr int TMP = 5 * ER * MCP + 2 * MCP;      // floats: (hx, hy) | (hxx, hyy) | hxy, each [ER][MCP] (+2 rows: the last 4-row
                                                             // group of the vertical pass reads past row ER-1); later (g0, g1) | g2, each [MR][CS]
     static constexpr int SMEM = (LIN + TMP) * 4;
@@ -416,13 +420,16 @@ static constexpr int MS_SMALL_SMEM = (2 * 36 * 36 + 2 * 28 * 28 + 5 * 36 * 26 + 
 
 template <int NLEV>
 __global__ __launch_bounds__(256) void msssim_small_kernel(MsSmallArgs a) {
+    // Same packing as the tile kernel (round 3): the staged images interleave (x, y) per pixel, the row-filtered images are
+    // (hx, hy) / (hxx, hyy) pairs + an hxy plane, the derivative maps (d_mu, d_11) pairs + a d_12 plane: every filter tap
+    // is one 8-byte LDS read + one packed fma per pair image instead of two 4-byte reads + two fmas.
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float red[8];
-    float* linA = smem;                          // [2][36*36]
-    float* linB = linA + 2 * 36 * 36;            // [2][28*28]
-    float* tmp5 = linB + 2 * 28 * 28;            // [5][36*26]
-    float* dmap = tmp5 + 5 * 36 * 26;            // [3][26*26]
-    float* tmp3 = dmap + 3 * 26 * 26;            // [3][26*16]
+    float* linA = smem;                          // [36*36] (x, y)
+    float* linB = linA + 2 * 36 * 36;            // [28*28] (x, y)
+    float* tmp5 = linB + 2 * 28 * 28;            // (hx, hy) [36*26] | (hxx, hyy) [36*26] | hxy [36*26]
+    float* dmap = tmp5 + 5 * 36 * 26;            // (d_mu, d_11) [26*26] | d_12 [26*26]
+    float* tmp3 = dmap + 3 * 26 * 26;            // (g0, g1) [26*16] | g2 [26*16]
     const int plane = blockIdx.x;
     float w[11];
 #pragma unroll
@@ -433,8 +440,7 @@ __global__ __launch_bounds__(256) void msssim_small_kernel(MsSmallArgs a) {
         for (int q = threadIdx.x; q < 36 * 36; q += 256) {
             const int r = q / 36 - 10, c = q % 36 - 10;
             const bool ok = (unsigned)r < 16u && (unsigned)c < 16u;
-            linA[q] = ok ? px[r * 16 + c] : 0.f;
-            linA[36 * 36 + q] = ok ? py[r * 16 + c] : 0.f;
+            *reinterpret_cast<f32x2*>(linA + 2 * q) = ok ? f32x2{px[r * 16 + c], py[r * 16 + c]} : splat2(0.f);
         }
     }
     __syncthreads();
@@ -442,40 +448,43 @@ __global__ __launch_bounds__(256) void msssim_small_kernel(MsSmallArgs a) {
     float* nxt = linB;
 #pragma unroll
     for (int lev = 0; lev < NLEV; ++lev) {
-        const int S = 16 >> lev, ER = S + 20, MR = S + 10, LP = ER * ER;
+        const int S = 16 >> lev, ER = S + 20, MR = S + 10, PT = ER * MR;
         const bool last = lev == NLEV - 1;
+        float* tA = tmp5; float* tB = tmp5 + 2 * PT; float* tC = tmp5 + 4 * PT;
         // horizontal pass of the five products
         for (int q = threadIdx.x; q < ER * MR; q += 256) {
             const int r = q / MR, m = q % MR;
-            const float* px = lin + r * ER + m;
-            const float* py = px + LP;
-            float hx = 0.f, hy = 0.f, hxx = 0.f, hyy = 0.f, hxy = 0.f;
+            const float* p = lin + (r * ER + m) * 2;
+            f32x2 hA = splat2(0.f), hB = splat2(0.f);
+            float hC = 0.f;
 #pragma unroll
             for (int t = 0; t < 11; ++t) {
-                const float xv = px[t], yv = py[t];
-                hx = fmaf(w[t], xv, hx); hy = fmaf(w[t], yv, hy);
-                hxx = fmaf(w[t], xv * xv, hxx); hyy = fmaf(w[t], yv * yv, hyy); hxy = fmaf(w[t], xv * yv, hxy);
+                const f32x2 v = *reinterpret_cast<const f32x2*>(p + 2 * t);
+                hA = pk_fma(splat2(w[t]), v, hA);
+                hB = pk_fma(splat2(w[t]), v * v, hB);
+                hC = fmaf(w[t], v.x * v.y, hC);
             }
-            const int PT = ER * MR;
-            tmp5[q] = hx; tmp5[PT + q] = hy; tmp5[2 * PT + q] = hxx; tmp5[3 * PT + q] = hyy; tmp5[4 * PT + q] = hxy;
+            *reinterpret_cast<f32x2*>(tA + 2 * q) = hA; *reinterpret_cast<f32x2*>(tB + 2 * q) = hB; tC[q] = hC;
         }
         __syncthreads();
+        float* dA = dmap; float* dC = dmap + 2 * MR * MR;
         float s_ssim = 0.f, s_cs = 0.f;
         for (int q = threadIdx.x; q < MR * MR; q += 256) {
-            const int r = q / MR, m = q % MR, PT = ER * MR;
-            const float* t0 = tmp5 + r * MR + m;
-            float mu1 = 0.f, mu2 = 0.f, a11 = 0.f, a22 = 0.f, a12 = 0.f;
+            const int r = q / MR, m = q % MR;
+            f32x2 mu = splat2(0.f), aa = splat2(0.f);
+            float a12 = 0.f;
 #pragma unroll
             for (int t = 0; t < 11; ++t) {
-                mu1 = fmaf(w[t], t0[t * MR], mu1); mu2 = fmaf(w[t], t0[PT + t * MR], mu2);
-                a11 = fmaf(w[t], t0[2 * PT + t * MR], a11); a22 = fmaf(w[t], t0[3 * PT + t * MR], a22);
-                a12 = fmaf(w[t], t0[4 * PT + t * MR], a12);
+                const int o = (r + t) * MR + m;
+                mu = pk_fma(splat2(w[t]), *reinterpret_cast<const f32x2*>(tA + 2 * o), mu);
+                aa = pk_fma(splat2(w[t]), *reinterpret_cast<const f32x2*>(tB + 2 * o), aa);
+                a12 = fmaf(w[t], tC[o], a12);
             }
             float ss, cs, dm, d11, d12;
-            ms_point(mu1, mu2, a11, a22, a12, last, &ss, &cs, &dm, &d11, &d12);
+            ms_point(mu.x, mu.y, aa.x, aa.y, a12, last, &ss, &cs, &dm, &d11, &d12);
             const bool inside = r >= 5 && r < 5 + S && m >= 5 && m < 5 + S;     // the whole plane is the tile
             if (inside) { s_ssim += ss; s_cs += cs; } else { dm = 0.f; d11 = 0.f; d12 = 0.f; }
-            dmap[q] = dm; dmap[MR * MR + q] = d11; dmap[2 * MR * MR + q] = d12;
+            *reinterpret_cast<f32x2*>(dA + 2 * q) = f32x2{dm, d11}; dC[q] = d12;
         }
         s_ssim = wave_sum(s_ssim); s_cs = wave_sum(s_cs);
         if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = s_ssim; red[(threadIdx.x >> 6) * 2 + 1] = s_cs; }
@@ -485,40 +494,43 @@ __global__ __launch_bounds__(256) void msssim_small_kernel(MsSmallArgs a) {
             a.part[lev][(size_t)plane * 2 + 1] = (red[1] + red[3]) + (red[5] + red[7]);
         }
         if (a.F[lev]) {
+            float* gA = tmp3; float* gC = tmp3 + 2 * MR * S;
             for (int q = threadIdx.x; q < MR * S; q += 256) {
                 const int r = q / S, c = q % S;
-                const float* p0 = dmap + r * MR + c;
-                float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+                f32x2 h01 = splat2(0.f);
+                float h2 = 0.f;
 #pragma unroll
                 for (int t = 0; t < 11; ++t) {
-                    h0 = fmaf(w[t], p0[t], h0); h1 = fmaf(w[t], p0[MR * MR + t], h1); h2 = fmaf(w[t], p0[2 * MR * MR + t], h2);
+                    h01 = pk_fma(splat2(w[t]), *reinterpret_cast<const f32x2*>(dA + 2 * (r * MR + c + t)), h01);
+                    h2 = fmaf(w[t], dC[r * MR + c + t], h2);
                 }
-                tmp3[q] = h0; tmp3[MR * S + q] = h1; tmp3[2 * MR * S + q] = h2;
+                *reinterpret_cast<f32x2*>(gA + 2 * q) = h01; gC[q] = h2;
             }
             __syncthreads();
             for (int q = threadIdx.x; q < S * S; q += 256) {
                 const int r = q / S, c = q % S;
-                const float* t0 = tmp3 + r * S + c;
-                float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+                f32x2 f01 = splat2(0.f);
+                float f2 = 0.f;
 #pragma unroll
                 for (int t = 0; t < 11; ++t) {
-                    f0 = fmaf(w[t], t0[t * S], f0); f1 = fmaf(w[t], t0[MR * S + t * S], f1); f2 = fmaf(w[t], t0[2 * MR * S + t * S], f2);
+                    f01 = pk_fma(splat2(w[t]), *reinterpret_cast<const f32x2*>(gA + 2 * ((r + t) * S + c)), f01);
+                    f2 = fmaf(w[t], gC[(r + t) * S + c], f2);
                 }
-                const float xv = lin[(10 + r) * ER + 10 + c], yv = lin[LP + (10 + r) * ER + 10 + c];
-                a.F[lev][(size_t)plane * S * S + q] = f0 + 2.0f * xv * f1 + yv * f2;
+                const f32x2 xy = *reinterpret_cast<const f32x2*>(lin + ((10 + r) * ER + 10 + c) * 2);
+                a.F[lev][(size_t)plane * S * S + q] = f01.x + 2.0f * xy.x * f01.y + xy.y * f2;
             }
         }
         if (!last) {            // next level's zero-padded halo images from this level's interior
             const int SN = S / 2, EN = SN + 20;
             for (int q = threadIdx.x; q < EN * EN; q += 256) {
                 const int r = q / EN - 10, c = q % EN - 10;
-                float vx = 0.f, vy = 0.f;
+                f32x2 v = splat2(0.f);
                 if ((unsigned)r < (unsigned)SN && (unsigned)c < (unsigned)SN) {
-                    const float* p = lin + (10 + 2 * r) * ER + 10 + 2 * c;
-                    vx = ((p[0] + p[1]) + (p[ER] + p[ER + 1])) * 0.25f;
-                    vy = ((p[LP] + p[LP + 1]) + (p[LP + ER] + p[LP + ER + 1])) * 0.25f;
+                    const float* p = lin + ((10 + 2 * r) * ER + 10 + 2 * c) * 2;
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(p), d = *reinterpret_cast<const f32x4*>(p + 2 * ER);
+                    v = f32x2{((u[0] + u[2]) + (d[0] + d[2])) * 0.25f, ((u[1] + u[3]) + (d[1] + d[3])) * 0.25f};
                 }
-                nxt[q] = vx; nxt[EN * EN + q] = vy;
+                *reinterpret_cast<f32x2*>(nxt + 2 * q) = v;
             }
             float* sw = lin; lin = nxt; nxt = sw;
         }

@@ -113,25 +113,30 @@ static WsLayout carve(const cvae_handle_s* h, int B) {
     const int W = h->cfg.width;
     int64_t off = 0;
     auto take = [&](int64_t n) { int64_t o = off; off += align_up(n, 64); return o; };
+    // activation / activation-gradient slots hold bf16 elements in precision mode 1: half the floats
+    const bool b16 = h->cfg.precision == 1;
+    auto act = [&](int64_t elems) { return take(b16 ? (elems + 1) / 2 : elems); };
     for (int l = 0; l < 4; ++l) {
         const int64_t H = layer_h(h, l), C = kLayers[l].cout;
-        w.y[l] = take(B * H * H * C);
-        w.a[l] = take(B * (H / 2) * (H / 2) * C);
+        w.y[l] = act(B * H * H * C);
+        w.a[l] = act(B * (H / 2) * (H / 2) * C);
         w.coef[l] = take(C * 4);
         w.bnpart[l] = take((int64_t)2 * bn_num_tiles(l, W, B) * C);
-        w.d_y[l] = take(B * H * H * C);
-        w.d_a[l] = take(B * (H / 2) * (H / 2) * C);
+        // block 0's d_y exists only on the CVAE_FUSE_E1=0 path (E1's weight-gradient kernel applies the BatchNorm backward itself);
+        // the slot keeps its offset entry (-1 -> "not allocated") for cvae_ws_offset
+        w.d_y[l] = (l == 0 && h->fuse_e1) ? -1 : act(B * H * H * C);
+        w.d_a[l] = act(B * (H / 2) * (H / 2) * C);
     }
     w.zcat = take((int64_t)B * 33);
     w.d_zcat = take((int64_t)B * 33);
-    w.h = take((int64_t)B * h->K);
-    w.d_h = take((int64_t)B * h->K);
+    w.h = act((int64_t)B * h->K);
+    w.d_h = act((int64_t)B * h->K);
     for (int i = 0; i < 4; ++i) {
         const int64_t H = layer_h(h, 4 + i), C = kLayers[4 + i].cout;
-        w.o[i] = take(B * H * H * C);
-        w.d_o[i] = take(B * H * H * C);
+        w.o[i] = act(B * H * H * C);
+        w.d_o[i] = act(B * H * H * C);
     }
-    w.dout4 = take((int64_t)B * 3 * W * W);
+    w.dout4 = take(b16 ? 0 : (int64_t)B * 3 * W * W);          // bf16 mode applies the Tanh backward inside d4_bwd: no dOut tensor
     for (int i = 0; i < 3; ++i) w.wc[i] = take(conv_up_wc_floats(5 + i));
     w.wpack = take(h->cfg.precision != 0 ? conv_bf16_pack_floats(h->cfg.precision >= 2 ? 3 : 1) : 0);
     w.ms = take(msssim_ws_floats(W, B));
@@ -483,7 +488,7 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
             const float* fu[7] = {ws + w.y[0], ws + w.a[0], ws + w.d_a[0], ws + w.coef[0], bn_bwd_bcoef(0, W, B, sc),
                                   P_(h->enc_w[0]), P_(h->enc_b[0])};
             { ProbeArm pa(h, 2, 0); RedArm ra(h, side_red, &red_pending, st); ra.arm(&sred);
-              RC(launch_e1_wgrad(W, B, x, ws + w.d_y[0], G_(h->enc_w[0]), G_(h->enc_b[0]), scw, sd, h->cfg.precision == 1, fuse0 ? fu : nullptr)); }
+              RC(launch_e1_wgrad(W, B, x, fuse0 ? nullptr : ws + w.d_y[0], G_(h->enc_w[0]), G_(h->enc_b[0]), scw, sd, h->cfg.precision == 1, fuse0 ? fu : nullptr)); }
         } else {
             { ProbeArm pa(h, 2, l); RedArm ra(h, side_red, &red_pending, st); ra.arm(&sred);
               if (use_bf16_wgrad(h, l)) RC(launch_conv_wgrad_bf16(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd));

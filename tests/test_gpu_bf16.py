@@ -400,10 +400,13 @@ def test_bf16_kernels_exact_on_their_stored_operands():
     h.backward(B, x, pred, eps, theta, tr.logvar, tr.recon, tr.d_recon, tr.d_mu, tr.d_logvar, tr.ws, tr.grads)
     torch.cuda.synchronize()
     from ws_tools import recompute_d_y0
-    recompute_d_y0(h, tr.ws, B, bf16_storage=True, x=x, theta=theta)     # neither y0 nor block 0's dy is stored: both exist only inside the fused E1 weight-gradient kernel
+    # neither y0 nor block 0's dy is stored: both exist only inside the fused E1 weight-gradient kernel
+    d_y0 = recompute_d_y0(h, tr.ws, B, bf16_storage=True, x=x, theta=theta).view(torch.bfloat16)
     ws16 = tr.ws.view(torch.bfloat16)
 
     def act(name, c, s):            # stored bf16 NHWC tensor -> fp32 NCHW on the CPU
+        if name == "d_y0":
+            return d_y0[:B * s * s * c].float().view(B, s, s, c).permute(0, 3, 1, 2).contiguous().cpu()
         off = h.lib.cvae_ws_offset(h.h, B, name.encode())
         assert off >= 0, name
         return ws16[2 * off:2 * off + B * s * s * c].float().view(B, s, s, c).permute(0, 3, 1, 2).contiguous().cpu()

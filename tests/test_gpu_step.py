@@ -91,10 +91,12 @@ def test_intermediates_against_oracle_taps():
     for i, (c, s) in enumerate(dec):
         assert (view(f"o{i}", c, s) - taps[f"dec_o{i}"]).abs().max() < TOL, f"o{i}"
     from ws_tools import recompute_d_y0
-    recompute_d_y0(h, ws, B)         # the step applies block 0's BatchNorm backward inside E1's weight-gradient kernel
+    d_y0 = recompute_d_y0(h, ws, B)  # the step applies block 0's BatchNorm backward inside E1's weight-gradient kernel: no d_y0 slot
+    assert h.lib.cvae_ws_offset(h.h, B, b"d_y0") < 0
     for l, (c, s) in enumerate(enc):
         g = taps[f"enc_y{l}"].grad
-        assert (view(f"d_y{l}", c, s) - g).abs().max() <= TOL * max(1.0, 0) + 1e-4 * g.abs().max(), f"d_y{l}"
+        got = d_y0.view(B, s, s, c).permute(0, 3, 1, 2).cpu() if l == 0 else view(f"d_y{l}", c, s)
+        assert (got - g).abs().max() <= TOL * max(1.0, 0) + 1e-4 * g.abs().max(), f"d_y{l}"
 
 
 @pytest.mark.parametrize("prec,width,rel", [("f32", 64, 1e-6), ("f32", 128, 1e-6), ("bf16", 64, 2e-2)])

@@ -110,6 +110,27 @@ def test_bench_self_launches_two_ranks():
     assert res["config"]["global_batch"] == 32 and res["value"] > 0 and res["config"]["loss_finite"]
 
 
+def test_bench_multi_gpu_line_carries_config4_and_config5():
+    """The default N > 1 bench run (what the driver starts on the 8-GPU node) also times BASELINE configs[3] and configs[4]
+    per GPU, each with the three overlapped gradient buckets and with the single all-reduce after backward.  Rehearsed here
+    with two ranks on the one GPU of the test box (gloo carries the collectives)."""
+    import json
+    env = dict(os.environ, CVAE_DIST_BACKEND="gloo", CVAE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 512 and res["config"]["preset"] == "config1"
+    for key, gb in (("config4", 4096), ("config5", 2048)):
+        c = res["config"][key]
+        assert c["global_batch"] == gb and c["value"] > 0 and c["loss_finite"]
+        assert c["grad_allreduce"].startswith("3 buckets") and c["allreduce_exposed_us"] is not None
+        single = c["allreduce_modes"]["single"]
+        assert single["grad_allreduce"].startswith("single") and single["allreduce_exposed_us"] is not None and single["value"] > 0
+        assert c["distributed"]["ranks_counted_by_allreduce"] == 2
+
+
 def test_two_handles_are_independent():
     """One handle per configuration, no shared state: two handles of different frame size / precision used
     alternately give bit-identical results to each one used alone."""

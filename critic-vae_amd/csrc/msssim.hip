@@ -407,6 +407,257 @@ __global__ __launch_bounds__(MS_NT, MS_NT / 128) void msssim_fwd_kernel(MsFwdArg
 }
 
 // ------------------------------------------------------------------------------------------------
+// whole-plane levels (S = 64, 32): one workgroup per plane, S*S/4 threads, every pass exactly one item per thread
+// ------------------------------------------------------------------------------------------------
+// The tile kernel above computes its maps on the tile extended by the window radius (twice, for the fused backward):
+// 36 x 76 row-filtered and 26 x 74 map positions for a 16 x 64 tile, most of them outside the image at S = 64, where
+// conv2d's zero padding makes every one of those values a known zero.  With the whole plane in one workgroup nothing
+// outside the image is ever computed: the zero padding is literally zero rows / columns in LDS, each of the four filter
+// passes runs on S x S positions (2.7x / 1.9x / 1.6x fewer than the tiles'), no position needs an inside / interior
+// test, and every pass has exactly NT = S*S/4 items — all waves busy in every phase, which is what lets a single
+// 1024-thread workgroup per CU (152 KB of LDS at S = 64) work.  Arithmetic per output is the tile kernel's: the same
+// t = 0..10 fma chains over the same products, so F, the pyramid and the per-element SSIM / CS values are bit-identical
+// to it; only the order of the plane's partial sums differs.
+template <int S>
+struct MsP {
+    static constexpr int NT = S * S / 4;
+    static constexpr int ECP = S + 10;        // input row stride (pixels): 5 zero columns either side; ECP / 2 odd (see MsT)
+    static constexpr int DAS = S + 14;        // (d_mu, d_11) row stride: 6 zero columns left (16-byte aligned stores and
+                                              // window reads; the windows are read 16 wide), 8 right; DAS / 2 odd
+    static constexpr int DCS = S + 12;        // d_12 row stride: 6 zero columns either side
+    static constexpr int TAS = S + 2;         // row stride (pixels) of the pair images in tmp: the two rows of a lane pair
+                                              // land 16 bytes apart modulo 32 — their 16-byte stores interleave
+    static constexpr int TR = S + 10;         // rows of the tmp images: 5 zero rows above and below
+    static constexpr int LIN_IN = 2 * S * ECP, LIN_D = S * (2 * DAS + DCS);
+    static constexpr int LIN = LIN_IN > LIN_D ? LIN_IN : LIN_D;
+    static constexpr int TA = 2 * TR * TAS;   // floats of one pair image
+    static constexpr int TMP = 2 * TA + TR * S;
+    static constexpr int SMEM = (LIN + TMP) * 4;
+    static_assert((ECP / 2) % 2 == 1 && (DAS / 2) % 2 == 1 && DCS % 4 == 0 && TAS % 2 == 0, "strides");
+    static_assert(SMEM <= 160 * 1024 - 256, "LDS");
+};
+
+// sum over the 64 lanes with DPP row operations (6 VALU instructions per value; the shuffle form costs ~6 per STEP);
+// the total is returned in every lane (read from lane 63)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define MS_DPP(ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+    v += MS_DPP(0xB1, 0xf);       // quad_perm [1,0,3,2]
+    v += MS_DPP(0x4E, 0xf);       // quad_perm [2,3,0,1]
+    v += MS_DPP(0x141, 0xf);      // row_half_mirror
+    v += MS_DPP(0x140, 0xf);      // row_mirror: every lane holds its row's sum
+    v += MS_DPP(0x142, 0xa);      // row_bcast:15 into rows 1 and 3
+    v += MS_DPP(0x143, 0xc);      // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+#undef MS_DPP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+template <int S>
+__global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
+    using T = MsP<S>;
+    constexpr int NT = T::NT, J = S / 4, H = S / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float red[2 * (NT / 64)];
+    float* lin = smem;                 // (x, y) pixels [S][ECP][2]; later (d_mu, d_11) [S][DAS][2] | d_12 [S][DCS]
+    float* tmp = smem + T::LIN;        // (hx, hy) [TR][TAS][2] | (hxx, hyy) [TR][TAS][2] | hxy [TR][S]; later (g0, g1) | - | g2
+    float* tA = tmp; float* tB = tmp + T::TA; float* tC = tmp + 2 * T::TA;
+    const int tid = threadIdx.x;
+    const int plane = xcd_tile(blockIdx.x, gridDim.x);
+    if (blockIdx.x == 0 && tid == 0 && a.ticket) *a.ticket = 0u;
+    const float* px = a.x + (size_t)plane * S * S;
+    const float* py = a.y + (size_t)plane * S * S;
+    float w[11];
+#pragma unroll
+    for (int t = 0; t < 11; ++t) w[t] = a.win.w[t];
+    // ---- stage the plane, (x, y) interleaved per pixel, between 5 zero columns; zero rows of the tmp images ----
+    {
+        float vx[4], vy[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { vx[k] = px[tid + k * NT]; vy[k] = py[tid + k * NT]; }
+        const int r = tid / S, c = tid % S;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)      // rows r, r + NT/S, ...
+            *reinterpret_cast<f32x2*>(lin + ((r + k * (NT / S)) * T::ECP + 5 + c) * 2) = f32x2{vx[k], vy[k]};
+        for (int q = tid; q < S * 10; q += NT) {
+            const int zr = q / 10, j = q % 10;
+            *reinterpret_cast<f32x2*>(lin + (zr * T::ECP + (j < 5 ? j : S + j)) * 2) = splat2(0.f);
+        }
+        constexpr int ZP = 5 * T::TAS * 2 / 4, ZC = 5 * S / 4;        // 16-byte units of one block of 5 zero rows
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int q = tid; q < ZP; q += NT) {
+            reinterpret_cast<f32x4*>(tA)[q] = z; reinterpret_cast<f32x4*>(tA + (S + 5) * T::TAS * 2)[q] = z;
+            reinterpret_cast<f32x4*>(tB)[q] = z; reinterpret_cast<f32x4*>(tB + (S + 5) * T::TAS * 2)[q] = z;
+        }
+        for (int q = tid; q < ZC; q += NT) { reinterpret_cast<f32x4*>(tC)[q] = z; reinterpret_cast<f32x4*>(tC + (S + 5) * S)[q] = z; }
+    }
+    __syncthreads();
+    // ---- 2x2 average for the next level (avg_pool2d, vae_nets.py:232-233): one output per thread ----
+    {
+        const int pr = tid / H, pc = tid % H;
+        const float* p = lin + ((2 * pr) * T::ECP + 5 + 2 * pc) * 2;
+        const f32x2 u0 = *reinterpret_cast<const f32x2*>(p), u1 = *reinterpret_cast<const f32x2*>(p + 2);
+        const f32x2 d0 = *reinterpret_cast<const f32x2*>(p + 2 * T::ECP), d1 = *reinterpret_cast<const f32x2*>(p + 2 * T::ECP + 2);
+        const f32x2 o = ((u0 + u1) + (d0 + d1)) * splat2(0.25f);
+        a.nx[(size_t)plane * NT + tid] = o.x;
+        a.ny[(size_t)plane * NT + tid] = o.y;
+    }
+    // ---- horizontal pass of {x, y, x^2, y^2, xy}: 4 adjacent outputs per thread from a 14-wide register window ----
+    const int hr = 2 * (tid / (2 * J)) + (tid & 1), hc = ((tid % (2 * J)) >> 1) * 4;      // neighbouring lanes: the two rows of a pair
+    {
+        const float* p = lin + (hr * T::ECP + hc) * 2;
+        f32x2 xy[14];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(p + 4 * i);
+            xy[2 * i] = f32x2{u[0], u[1]}; xy[2 * i + 1] = f32x2{u[2], u[3]};
+        }
+        f32x2 hA[4], hB[4];
+        float hC[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            f32x2 sA = splat2(0.f), sB = splat2(0.f);
+            float sC = 0.f;
+#pragma unroll
+            for (int t = 0; t < 11; ++t) {
+                const f32x2 v = xy[o + t];
+                sA = pk_fma(splat2(w[t]), v, sA);
+                sB = pk_fma(splat2(w[t]), v * v, sB);
+                sC = fmaf(w[t], v.x * v.y, sC);
+            }
+            hA[o] = sA; hB[o] = sB; hC[o] = sC;
+        }
+        const int d = ((hr + 5) * T::TAS + hc) * 2;
+        *reinterpret_cast<f32x4*>(tA + d) = f32x4{hA[0].x, hA[0].y, hA[1].x, hA[1].y};
+        *reinterpret_cast<f32x4*>(tA + d + 4) = f32x4{hA[2].x, hA[2].y, hA[3].x, hA[3].y};
+        *reinterpret_cast<f32x4*>(tB + d) = f32x4{hB[0].x, hB[0].y, hB[1].x, hB[1].y};
+        *reinterpret_cast<f32x4*>(tB + d + 4) = f32x4{hB[2].x, hB[2].y, hB[3].x, hB[3].y};
+        *reinterpret_cast<f32x4*>(tC + (hr + 5) * S + hc) = f32x4{hC[0], hC[1], hC[2], hC[3]};
+    }
+    __syncthreads();
+    // ---- vertical pass (2 rows x 2 columns per thread) + SSIM / CS maps + derivative maps into the input buffer ----
+    const int vr = (tid / H) * 2, vc = (tid % H) * 2;
+    float* dA = lin; float* dC = lin + 2 * S * T::DAS;
+    float s_ssim = 0.f, s_cs = 0.f;
+    {
+        // zero columns of the derivative maps: per row 3 + 4 16-byte units of dA, 6 + 6 floats of dC
+        for (int q = tid; q < S * 16; q += NT) {
+            const int zr = q >> 4, k = q & 15;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            float* ra = dA + zr * T::DAS * 2; float* rc = dC + zr * T::DCS;
+            if (k < 3) *reinterpret_cast<f32x4*>(ra + 4 * k) = z;
+            else if (k < 7) *reinterpret_cast<f32x4*>(ra + (S + 6) * 2 + 4 * (k - 3)) = z;
+            else if (k == 7) *reinterpret_cast<f32x4*>(rc) = z;
+            else if (k == 8) *reinterpret_cast<f32x2*>(rc + 4) = splat2(0.f);
+            else if (k == 9) *reinterpret_cast<f32x2*>(rc + S + 6) = splat2(0.f);
+            else if (k == 10) *reinterpret_cast<f32x4*>(rc + S + 8) = z;
+        }
+        constexpr int VR = 2;
+        f32x2 mu[VR][2], aa[VR][2], a12[VR];
+#pragma unroll
+        for (int o = 0; o < VR; ++o) { mu[o][0] = mu[o][1] = aa[o][0] = aa[o][1] = a12[o] = splat2(0.f); }
+#pragma unroll
+        for (int i = 0; i < VR + 10; ++i) {               // tmp row vr + i = image row vr + i - 5
+            const f32x4 vA = *reinterpret_cast<const f32x4*>(tA + ((vr + i) * T::TAS + vc) * 2);
+            const f32x4 vB = *reinterpret_cast<const f32x4*>(tB + ((vr + i) * T::TAS + vc) * 2);
+            const f32x2 vC = *reinterpret_cast<const f32x2*>(tC + (vr + i) * S + vc);
+#pragma unroll
+            for (int o = 0; o < VR; ++o) {
+                if (i - o < 0 || i - o > 10) continue;
+                const f32x2 wt = splat2(w[i - o]);
+                mu[o][0] = pk_fma(wt, f32x2{vA[0], vA[1]}, mu[o][0]);
+                mu[o][1] = pk_fma(wt, f32x2{vA[2], vA[3]}, mu[o][1]);
+                aa[o][0] = pk_fma(wt, f32x2{vB[0], vB[1]}, aa[o][0]);
+                aa[o][1] = pk_fma(wt, f32x2{vB[2], vB[3]}, aa[o][1]);
+                a12[o] = pk_fma(wt, vC, a12[o]);
+            }
+            if (i < 10) continue;
+            const int o = i - 10, r = vr + o;
+            f32x2 ss, cs, dmv, d11v, d12v;
+            ms_point2(f32x2{mu[o][0].x, mu[o][1].x}, f32x2{mu[o][0].y, mu[o][1].y}, f32x2{aa[o][0].x, aa[o][1].x},
+                      f32x2{aa[o][0].y, aa[o][1].y}, a12[o], &ss, &cs, &dmv, &d11v, &d12v);
+            s_ssim += ss.x + ss.y; s_cs += cs.x + cs.y;
+            *reinterpret_cast<f32x4*>(dA + (r * T::DAS + 6 + vc) * 2) = f32x4{dmv.x, d11v.x, dmv.y, d11v.y};
+            *reinterpret_cast<f32x2*>(dC + r * T::DCS + 6 + vc) = d12v;
+        }
+    }
+    s_ssim = wave_sum_dpp(s_ssim); s_cs = wave_sum_dpp(s_cs);
+    if ((tid & 63) == 0) { red[(tid >> 6) * 2] = s_ssim; red[(tid >> 6) * 2 + 1] = s_cs; }
+    __syncthreads();
+    if (tid == 0) {
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NT / 64; ++k) { t0 += red[2 * k]; t1 += red[2 * k + 1]; }
+        a.part[(size_t)plane * 2] = t0;
+        a.part[(size_t)plane * 2 + 1] = t1;
+    }
+    if (!a.F) return;
+    // ---- the same separable filter over the three derivative maps: horizontal (16-wide windows from column c - 6) ... ----
+    {
+        f32x2 va[16];
+        float vc4[16];
+        const float* pa = dA + (hr * T::DAS + hc) * 2;
+        const float* pc = dC + hr * T::DCS + hc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(pa + 4 * i);
+            va[2 * i] = f32x2{u[0], u[1]}; va[2 * i + 1] = f32x2{u[2], u[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(pc + 4 * i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vc4[4 * i + e] = u[e];
+        }
+        f32x2 gAo[4];
+        f32x4 gCo;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            f32x2 sA = splat2(0.f);
+            float sC = 0.f;
+#pragma unroll
+            for (int t = 0; t < 11; ++t) { sA = pk_fma(splat2(w[t]), va[o + t + 1], sA); sC = fmaf(w[t], vc4[o + t + 1], sC); }
+            gAo[o] = sA; gCo[o] = sC;
+        }
+        const int d = ((hr + 5) * T::TAS + hc) * 2;
+        *reinterpret_cast<f32x4*>(tA + d) = f32x4{gAo[0].x, gAo[0].y, gAo[1].x, gAo[1].y};
+        *reinterpret_cast<f32x4*>(tA + d + 4) = f32x4{gAo[2].x, gAo[2].y, gAo[3].x, gAo[3].y};
+        *reinterpret_cast<f32x4*>(tC + (hr + 5) * S + hc) = gCo;
+    }
+    __syncthreads();
+    // ---- ... vertical (2 rows x 2 columns per thread), then F = f0 + 2 x f1 + y f2 ----
+    {
+        constexpr int VR = 2;
+        const size_t g = (size_t)vr * S + vc;
+        float2 xv[VR], yv[VR];               // L2 hits, issued ahead of the filter
+#pragma unroll
+        for (int o = 0; o < VR; ++o) {
+            xv[o] = *reinterpret_cast<const float2*>(px + g + (size_t)o * S);
+            yv[o] = *reinterpret_cast<const float2*>(py + g + (size_t)o * S);
+        }
+        f32x2 f01[VR][2], f2[VR];
+#pragma unroll
+        for (int o = 0; o < VR; ++o) { f01[o][0] = f01[o][1] = f2[o] = splat2(0.f); }
+#pragma unroll
+        for (int i = 0; i < VR + 10; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tA + ((vr + i) * T::TAS + vc) * 2);
+            const f32x2 u = *reinterpret_cast<const f32x2*>(tC + (vr + i) * S + vc);
+#pragma unroll
+            for (int o = 0; o < VR; ++o) {
+                if (i - o < 0 || i - o > 10) continue;
+                f01[o][0] = pk_fma(splat2(w[i - o]), f32x2{v[0], v[1]}, f01[o][0]);
+                f01[o][1] = pk_fma(splat2(w[i - o]), f32x2{v[2], v[3]}, f01[o][1]);
+                f2[o] = pk_fma(splat2(w[i - o]), u, f2[o]);
+            }
+        }
+        float* pf = a.F + (size_t)plane * S * S;
+#pragma unroll
+        for (int o = 0; o < VR; ++o)
+            *reinterpret_cast<float2*>(pf + g + (size_t)o * S) =
+                make_float2(f01[o][0].x + 2.0f * xv[o].x * f01[o][0].y + yv[o].x * f2[o].x,
+                            f01[o][1].x + 2.0f * xv[o].y * f01[o][1].y + yv[o].y * f2[o].y);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // small levels (16 -> 8 [-> 4]): one workgroup per plane, the pyramid never leaves LDS
 // ------------------------------------------------------------------------------------------------
 struct MsSmallArgs {
@@ -647,7 +898,7 @@ struct MsWs {
     int64_t pyrx[5], pyry[5], F[5], part[5], slab, coef, ticket, total;
     int nblk[5], nbig;        // nbig: levels run by the tile kernel (size >= 32)
 };
-static int ms_tiles(int S) { return S == 128 ? MsT<128>::TILES : (S == 64 ? MsT<64>::TILES : MsT<32>::TILES); }
+static int ms_tiles(int S) { return S == 128 ? MsT<128>::TILES : 1; }      // 64 / 32: msssim_plane_kernel, one workgroup per plane
 static MsWs ms_carve(int width, int B) {
     MsWs w{};
     const int P = B * 3;
@@ -672,11 +923,17 @@ int64_t msssim_ws_floats(int width, int B) { return ms_carve(width, B).total; }
 
 template <int S>
 static int ms_fwd(const MsFwdArgs& a, hipStream_t st) {
-    using T = MsT<S>;
     static DeviceOnce once;
-    { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(msssim_fwd_kernel<S>), T::SMEM); if (rc) return rc; }
     if (a.ticket) cvae_probe_begin(st);                 // level 0 only (the launch that also zeroes the ticket)
-    hipLaunchKernelGGL(msssim_fwd_kernel<S>, dim3(a.P * T::TILES), dim3(MS_NT), T::SMEM, st, a);
+    if constexpr (S == 128) {
+        using T = MsT<S>;
+        { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(msssim_fwd_kernel<S>), T::SMEM); if (rc) return rc; }
+        hipLaunchKernelGGL(msssim_fwd_kernel<S>, dim3(a.P * T::TILES), dim3(MS_NT), T::SMEM, st, a);
+    } else {
+        using T = MsP<S>;
+        { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(msssim_plane_kernel<S>), T::SMEM); if (rc) return rc; }
+        hipLaunchKernelGGL(msssim_plane_kernel<S>, dim3(a.P), dim3(T::NT), T::SMEM, st, a);
+    }
     if (a.ticket) cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();
     return 0;

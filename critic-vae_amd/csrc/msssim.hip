@@ -50,38 +50,6 @@ static constexpr int MS_NT = CVAE_MS_NT;     // threads of a tile workgroup: two
                                              // 768 runs the first horizontal pass (684 items at S = 64) in one round: 371 us against 392 (512) / 366 (1024) at B = 2048
 static constexpr int MS_VR = CVAE_MS_VR;     // output rows per item of the vertical passes (VR + 10 staged rows are read per item)
 
-// 1/x to ~0.5 ulp: v_rcp_f32 + one Newton step (3 instructions instead of the ~11 of an IEEE division; the
-// denominators are >= C1 / C2 minus round-off, far from the denormal range)
-__device__ __forceinline__ float ms_rcp(float x) {
-    const float r = __builtin_amdgcn_rcpf(x);
-    return fmaf(fmaf(-x, r, 1.0f), r, r);
-}
-
-// SSIM / CS value of one point and the derivatives of the level's contributing map (cs_map; ssim_map on the
-// last level) w.r.t. (mu1, E[x^2], E[xy]) — vae_nets.py:201-215 and its autograd
-__device__ __forceinline__ void ms_point(float mu1, float mu2, float a11, float a22, float a12, bool last,
-                                         float* ssim, float* cs, float* dm, float* d11, float* d12) {
-    const float C1 = 0.0001f, C2 = 0.0009f;
-    const float mu1sq = mu1 * mu1, mu2sq = mu2 * mu2, mu12 = mu1 * mu2;
-    const float v1 = 2.0f * (a12 - mu12) + C2;
-    const float v2 = (a11 - mu1sq) + (a22 - mu2sq) + C2;
-    const float inv2 = ms_rcp(v2);
-    const float c = v1 * inv2;
-    const float num = 2.0f * mu12 + C1, den = mu1sq + mu2sq + C1;
-    const float invden = ms_rcp(den);
-    const float lum = num * invden;
-    *cs = c;
-    *ssim = lum * c;
-    float m = (2.0f * mu1 * c - 2.0f * mu2) * inv2;
-    float e11 = -c * inv2;
-    float e12 = 2.0f * inv2;
-    if (last) {
-        const float dlum = (2.0f * mu2 - 2.0f * mu1 * lum) * invden;
-        m = dlum * c + lum * m; e11 *= lum; e12 *= lum;
-    }
-    *dm = m; *d11 = e11; *d12 = e12;
-}
-
 // ------------------------------------------------------------------------------------------------
 // large levels (S = 128, 64, 32): one workgroup per (plane, RS x CS tile)
 // ------------------------------------------------------------------------------------------------
@@ -132,11 +100,15 @@ struct MsFwdArgs {
     MsWin win;
 };
 
-// ms_point on two adjacent columns at once (same operations per column as ms_point)
+// SSIM / CS value of two adjacent points and the derivatives of the level's contributing map (cs_map; ssim_map on the
+// last level) w.r.t. (mu1, E[x^2], E[xy]) — vae_nets.py:201-215 and its autograd.
+// 1/x to ~0.5 ulp: v_rcp_f32 + one Newton step (3 instructions instead of the ~11 of an IEEE division; the
+// denominators are >= C1 / C2 minus round-off, far from the denormal range)
 __device__ __forceinline__ f32x2 ms_rcp2(f32x2 x) {
     const f32x2 r = {__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
     return pk_fma(pk_fma(-x, r, splat2(1.0f)), r, r);
 }
+template <bool LAST = false>
 __device__ __forceinline__ void ms_point2(f32x2 mu1, f32x2 mu2, f32x2 a11, f32x2 a22, f32x2 a12, f32x2* ssim, f32x2* cs,
                                           f32x2* dm, f32x2* d11, f32x2* d12) {
     const f32x2 C1 = splat2(0.0001f), C2 = splat2(0.0009f), two = splat2(2.0f);
@@ -146,12 +118,16 @@ __device__ __forceinline__ void ms_point2(f32x2 mu1, f32x2 mu2, f32x2 a11, f32x2
     const f32x2 inv2 = ms_rcp2(v2);
     const f32x2 c = v1 * inv2;
     const f32x2 num = two * mu12 + C1, den = mu1sq + mu2sq + C1;
-    const f32x2 lum = num * ms_rcp2(den);
+    const f32x2 invden = ms_rcp2(den);
+    const f32x2 lum = num * invden;
     *cs = c;
     *ssim = lum * c;
-    *dm = (two * mu1 * c - two * mu2) * inv2;
-    *d11 = -c * inv2;
-    *d12 = two * inv2;
+    f32x2 m = (two * mu1 * c - two * mu2) * inv2, e11 = -c * inv2, e12 = two * inv2;
+    if constexpr (LAST) {          // the last level contributes ssim_map = lum * cs_map (same operations as ms_point)
+        const f32x2 dlum = (two * mu2 - two * mu1 * lum) * invden;
+        m = dlum * c + lum * m; e11 *= lum; e12 *= lum;
+    }
+    *dm = m; *d11 = e11; *d12 = e12;
 }
 
 template <int S>
@@ -420,7 +396,9 @@ __global__ __launch_bounds__(MS_NT, MS_NT / 128) void msssim_fwd_kernel(MsFwdArg
 // to it; only the order of the plane's partial sums differs.
 template <int S>
 struct MsP {
-    static constexpr int NT = S * S / 4;
+    static constexpr int NTP = S * S / 4;     // threads per plane
+    static constexpr int PPW = NTP >= 256 ? 1 : 256 / NTP;      // planes per workgroup: 256 threads below S = 32
+    static constexpr int NT = NTP * PPW;
     static constexpr int ECP = S + 10;        // input row stride (pixels): 5 zero columns either side; ECP / 2 odd (see MsT)
     static constexpr int DAS = S + 14;        // (d_mu, d_11) row stride: 6 zero columns left (16-byte aligned stores and
                                               // window reads; the windows are read 16 wide), 8 right; DAS / 2 odd
@@ -432,37 +410,47 @@ struct MsP {
     static constexpr int LIN = LIN_IN > LIN_D ? LIN_IN : LIN_D;
     static constexpr int TA = 2 * TR * TAS;   // floats of one pair image
     static constexpr int TMP = 2 * TA + TR * S;
-    static constexpr int SMEM = (LIN + TMP) * 4;
-    static_assert((ECP / 2) % 2 == 1 && (DAS / 2) % 2 == 1 && DCS % 4 == 0 && TAS % 2 == 0, "strides");
+    static constexpr int PLANE = LIN + TMP;   // floats of LDS per plane
+    static constexpr int SMEM = PPW * PLANE * 4;
+    static_assert((ECP / 2) % 2 == 1 && (DAS / 2) % 2 == 1 && DCS % 4 == 0 && TAS % 2 == 0 && PLANE % 4 == 0, "strides");
     static_assert(SMEM <= 160 * 1024 - 256, "LDS");
 };
 
-// sum over the 64 lanes with DPP row operations (6 VALU instructions per value; the shuffle form costs ~6 per STEP);
-// the total is returned in every lane (read from lane 63)
-__device__ __forceinline__ float wave_sum_dpp(float v) {
+// Sum over the SEG (4, 16 or 64) lanes of a lane's aligned segment with DPP row operations (6 VALU instructions per value
+// for the whole wave; the shuffle form costs ~6 per STEP); the result is valid in the LAST lane of each segment for
+// SEG = 64 and in every lane of the segment otherwise
+template <int SEG>
+__device__ __forceinline__ float seg_sum_dpp(float v) {
 #define MS_DPP(ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
     v += MS_DPP(0xB1, 0xf);       // quad_perm [1,0,3,2]
-    v += MS_DPP(0x4E, 0xf);       // quad_perm [2,3,0,1]
-    v += MS_DPP(0x141, 0xf);      // row_half_mirror
-    v += MS_DPP(0x140, 0xf);      // row_mirror: every lane holds its row's sum
-    v += MS_DPP(0x142, 0xa);      // row_bcast:15 into rows 1 and 3
-    v += MS_DPP(0x143, 0xc);      // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    v += MS_DPP(0x4E, 0xf);       // quad_perm [2,3,0,1]: every lane holds its quad's sum
+    if constexpr (SEG >= 16) {
+        v += MS_DPP(0x141, 0xf);  // row_half_mirror
+        v += MS_DPP(0x140, 0xf);  // row_mirror: every lane holds its row's sum
+    }
+    if constexpr (SEG == 64) {
+        v += MS_DPP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+        v += MS_DPP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    }
 #undef MS_DPP
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    return v;
 }
 
-template <int S>
+template <int S, bool LAST>
 __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
     using T = MsP<S>;
-    constexpr int NT = T::NT, J = S / 4, H = S / 2;
+    constexpr int NT = T::NT, NTP = T::NTP, PPW = T::PPW, J = S / 4, H = S / 2;
+    constexpr int WPP = NTP >= 64 ? NTP / 64 : 1;        // waves per plane
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float red[2 * (NT / 64)];
-    float* lin = smem;                 // (x, y) pixels [S][ECP][2]; later (d_mu, d_11) [S][DAS][2] | d_12 [S][DCS]
-    float* tmp = smem + T::LIN;        // (hx, hy) [TR][TAS][2] | (hxx, hyy) [TR][TAS][2] | hxy [TR][S]; later (g0, g1) | - | g2
+    const int sub = PPW > 1 ? threadIdx.x / NTP : 0, tid = PPW > 1 ? threadIdx.x % NTP : threadIdx.x;
+    float* lin = smem + sub * T::PLANE;   // (x, y) pixels [S][ECP][2]; later (d_mu, d_11) [S][DAS][2] | d_12 [S][DCS]
+    float* tmp = lin + T::LIN;            // (hx, hy) [TR][TAS][2] | (hxx, hyy) [TR][TAS][2] | hxy [TR][S]; later (g0, g1) | - | g2
     float* tA = tmp; float* tB = tmp + T::TA; float* tC = tmp + 2 * T::TA;
-    const int tid = threadIdx.x;
-    const int plane = xcd_tile(blockIdx.x, gridDim.x);
-    if (blockIdx.x == 0 && tid == 0 && a.ticket) *a.ticket = 0u;
+    const int pl = xcd_tile(blockIdx.x, gridDim.x) * PPW + sub;
+    const bool valid = pl < a.P;                          // planes past the end: same work on the last plane, no stores
+    const int plane = valid ? pl : a.P - 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.ticket) *a.ticket = 0u;
     const float* px = a.x + (size_t)plane * S * S;
     const float* py = a.y + (size_t)plane * S * S;
     float w[11];
@@ -472,33 +460,33 @@ __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
     {
         float vx[4], vy[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { vx[k] = px[tid + k * NT]; vy[k] = py[tid + k * NT]; }
+        for (int k = 0; k < 4; ++k) { vx[k] = px[tid + k * NTP]; vy[k] = py[tid + k * NTP]; }
         const int r = tid / S, c = tid % S;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)      // rows r, r + NT/S, ...
-            *reinterpret_cast<f32x2*>(lin + ((r + k * (NT / S)) * T::ECP + 5 + c) * 2) = f32x2{vx[k], vy[k]};
-        for (int q = tid; q < S * 10; q += NT) {
+        for (int k = 0; k < 4; ++k)      // rows r, r + S/4, ...
+            *reinterpret_cast<f32x2*>(lin + ((r + k * (S / 4)) * T::ECP + 5 + c) * 2) = f32x2{vx[k], vy[k]};
+        for (int q = tid; q < S * 10; q += NTP) {
             const int zr = q / 10, j = q % 10;
             *reinterpret_cast<f32x2*>(lin + (zr * T::ECP + (j < 5 ? j : S + j)) * 2) = splat2(0.f);
         }
         constexpr int ZP = 5 * T::TAS * 2 / 4, ZC = 5 * S / 4;        // 16-byte units of one block of 5 zero rows
+        static_assert(ZP * 4 == 5 * T::TAS * 2 && ZC * 4 == 5 * S && ((S + 5) * T::TAS * 2) % 4 == 0 && T::TA % 4 == 0, "16-byte zero fill");
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        for (int q = tid; q < ZP; q += NT) {
+        for (int q = tid; q < ZP; q += NTP) {
             reinterpret_cast<f32x4*>(tA)[q] = z; reinterpret_cast<f32x4*>(tA + (S + 5) * T::TAS * 2)[q] = z;
             reinterpret_cast<f32x4*>(tB)[q] = z; reinterpret_cast<f32x4*>(tB + (S + 5) * T::TAS * 2)[q] = z;
         }
-        for (int q = tid; q < ZC; q += NT) { reinterpret_cast<f32x4*>(tC)[q] = z; reinterpret_cast<f32x4*>(tC + (S + 5) * S)[q] = z; }
+        for (int q = tid; q < ZC; q += NTP) { reinterpret_cast<f32x4*>(tC)[q] = z; reinterpret_cast<f32x4*>(tC + (S + 5) * S)[q] = z; }
     }
     __syncthreads();
     // ---- 2x2 average for the next level (avg_pool2d, vae_nets.py:232-233): one output per thread ----
-    {
+    if (a.nx) {
         const int pr = tid / H, pc = tid % H;
         const float* p = lin + ((2 * pr) * T::ECP + 5 + 2 * pc) * 2;
         const f32x2 u0 = *reinterpret_cast<const f32x2*>(p), u1 = *reinterpret_cast<const f32x2*>(p + 2);
         const f32x2 d0 = *reinterpret_cast<const f32x2*>(p + 2 * T::ECP), d1 = *reinterpret_cast<const f32x2*>(p + 2 * T::ECP + 2);
         const f32x2 o = ((u0 + u1) + (d0 + d1)) * splat2(0.25f);
-        a.nx[(size_t)plane * NT + tid] = o.x;
-        a.ny[(size_t)plane * NT + tid] = o.y;
+        if (valid) { a.nx[(size_t)plane * NTP + tid] = o.x; a.ny[(size_t)plane * NTP + tid] = o.y; }
     }
     // ---- horizontal pass of {x, y, x^2, y^2, xy}: 4 adjacent outputs per thread from a 14-wide register window ----
     const int hr = 2 * (tid / (2 * J)) + (tid & 1), hc = ((tid % (2 * J)) >> 1) * 4;      // neighbouring lanes: the two rows of a pair
@@ -539,7 +527,7 @@ __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
     float s_ssim = 0.f, s_cs = 0.f;
     {
         // zero columns of the derivative maps: per row 3 + 4 16-byte units of dA, 6 + 6 floats of dC
-        for (int q = tid; q < S * 16; q += NT) {
+        for (int q = tid; q < S * 16; q += NTP) {
             const int zr = q >> 4, k = q & 15;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             float* ra = dA + zr * T::DAS * 2; float* rc = dC + zr * T::DCS;
@@ -572,22 +560,30 @@ __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
             if (i < 10) continue;
             const int o = i - 10, r = vr + o;
             f32x2 ss, cs, dmv, d11v, d12v;
-            ms_point2(f32x2{mu[o][0].x, mu[o][1].x}, f32x2{mu[o][0].y, mu[o][1].y}, f32x2{aa[o][0].x, aa[o][1].x},
-                      f32x2{aa[o][0].y, aa[o][1].y}, a12[o], &ss, &cs, &dmv, &d11v, &d12v);
+            ms_point2<LAST>(f32x2{mu[o][0].x, mu[o][1].x}, f32x2{mu[o][0].y, mu[o][1].y}, f32x2{aa[o][0].x, aa[o][1].x},
+                            f32x2{aa[o][0].y, aa[o][1].y}, a12[o], &ss, &cs, &dmv, &d11v, &d12v);
             s_ssim += ss.x + ss.y; s_cs += cs.x + cs.y;
             *reinterpret_cast<f32x4*>(dA + (r * T::DAS + 6 + vc) * 2) = f32x4{dmv.x, d11v.x, dmv.y, d11v.y};
             *reinterpret_cast<f32x2*>(dC + r * T::DCS + 6 + vc) = d12v;
         }
     }
-    s_ssim = wave_sum_dpp(s_ssim); s_cs = wave_sum_dpp(s_cs);
-    if ((tid & 63) == 0) { red[(tid >> 6) * 2] = s_ssim; red[(tid >> 6) * 2 + 1] = s_cs; }
+    constexpr int SEG = NTP >= 64 ? 64 : NTP;
+    s_ssim = seg_sum_dpp<SEG>(s_ssim); s_cs = seg_sum_dpp<SEG>(s_cs);
+    if constexpr (WPP > 1) {
+        if ((threadIdx.x & 63) == 63) { red[(threadIdx.x >> 6) * 2] = s_ssim; red[(threadIdx.x >> 6) * 2 + 1] = s_cs; }
+    } else if (valid && (tid & (SEG - 1)) == SEG - 1) {
+        a.part[(size_t)plane * 2] = s_ssim;
+        a.part[(size_t)plane * 2 + 1] = s_cs;
+    }
     __syncthreads();
-    if (tid == 0) {
-        float t0 = 0.f, t1 = 0.f;
+    if constexpr (WPP > 1) {
+        if (tid == 0 && valid) {
+            float t0 = 0.f, t1 = 0.f;
 #pragma unroll
-        for (int k = 0; k < NT / 64; ++k) { t0 += red[2 * k]; t1 += red[2 * k + 1]; }
-        a.part[(size_t)plane * 2] = t0;
-        a.part[(size_t)plane * 2 + 1] = t1;
+            for (int k = 0; k < WPP; ++k) { t0 += red[2 * (sub * WPP + k)]; t1 += red[2 * (sub * WPP + k) + 1]; }
+            a.part[(size_t)plane * 2] = t0;
+            a.part[(size_t)plane * 2 + 1] = t1;
+        }
     }
     if (!a.F) return;
     // ---- the same separable filter over the three derivative maps: horizontal (16-wide windows from column c - 6) ... ----
@@ -649,143 +645,13 @@ __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
             }
         }
         float* pf = a.F + (size_t)plane * S * S;
+        if (valid) {
 #pragma unroll
-        for (int o = 0; o < VR; ++o)
-            *reinterpret_cast<float2*>(pf + g + (size_t)o * S) =
-                make_float2(f01[o][0].x + 2.0f * xv[o].x * f01[o][0].y + yv[o].x * f2[o].x,
-                            f01[o][1].x + 2.0f * xv[o].y * f01[o][1].y + yv[o].y * f2[o].y);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// small levels (16 -> 8 [-> 4]): one workgroup per plane, the pyramid never leaves LDS
-// ------------------------------------------------------------------------------------------------
-struct MsSmallArgs {
-    const float* x; const float* y;     // 16x16 planes
-    float* F[3];                         // gradient fields of the NLEV levels (null: forward only)
-    float* part[3];                      // [P][2] per level
-    int P;
-    MsWin win;
-};
-static constexpr int MS_SMALL_SMEM = (2 * 36 * 36 + 2 * 28 * 28 + 5 * 36 * 26 + 3 * 26 * 26 + 3 * 26 * 16) * 4;
-
-template <int NLEV>
-__global__ __launch_bounds__(256) void msssim_small_kernel(MsSmallArgs a) {
-    // Same packing as the tile kernel (round 3): the staged images interleave (x, y) per pixel, the row-filtered images are
-    // (hx, hy) / (hxx, hyy) pairs + an hxy plane, the derivative maps (d_mu, d_11) pairs + a d_12 plane: every filter tap
-    // is one 8-byte LDS read + one packed fma per pair image instead of two 4-byte reads + two fmas.
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ float red[8];
-    float* linA = smem;                          // [36*36] (x, y)
-    float* linB = linA + 2 * 36 * 36;            // [28*28] (x, y)
-    float* tmp5 = linB + 2 * 28 * 28;            // (hx, hy) [36*26] | (hxx, hyy) [36*26] | hxy [36*26]
-    float* dmap = tmp5 + 5 * 36 * 26;            // (d_mu, d_11) [26*26] | d_12 [26*26]
-    float* tmp3 = dmap + 3 * 26 * 26;            // (g0, g1) [26*16] | g2 [26*16]
-    const int plane = blockIdx.x;
-    float w[11];
-#pragma unroll
-    for (int t = 0; t < 11; ++t) w[t] = a.win.w[t];
-    {
-        const float* px = a.x + (size_t)plane * 256;
-        const float* py = a.y + (size_t)plane * 256;
-        for (int q = threadIdx.x; q < 36 * 36; q += 256) {
-            const int r = q / 36 - 10, c = q % 36 - 10;
-            const bool ok = (unsigned)r < 16u && (unsigned)c < 16u;
-            *reinterpret_cast<f32x2*>(linA + 2 * q) = ok ? f32x2{px[r * 16 + c], py[r * 16 + c]} : splat2(0.f);
+            for (int o = 0; o < VR; ++o)
+                *reinterpret_cast<float2*>(pf + g + (size_t)o * S) =
+                    make_float2(f01[o][0].x + 2.0f * xv[o].x * f01[o][0].y + yv[o].x * f2[o].x,
+                                f01[o][1].x + 2.0f * xv[o].y * f01[o][1].y + yv[o].y * f2[o].y);
         }
-    }
-    __syncthreads();
-    float* lin = linA;
-    float* nxt = linB;
-#pragma unroll
-    for (int lev = 0; lev < NLEV; ++lev) {
-        const int S = 16 >> lev, ER = S + 20, MR = S + 10, PT = ER * MR;
-        const bool last = lev == NLEV - 1;
-        float* tA = tmp5; float* tB = tmp5 + 2 * PT; float* tC = tmp5 + 4 * PT;
-        // horizontal pass of the five products
-        for (int q = threadIdx.x; q < ER * MR; q += 256) {
-            const int r = q / MR, m = q % MR;
-            const float* p = lin + (r * ER + m) * 2;
-            f32x2 hA = splat2(0.f), hB = splat2(0.f);
-            float hC = 0.f;
-#pragma unroll
-            for (int t = 0; t < 11; ++t) {
-                const f32x2 v = *reinterpret_cast<const f32x2*>(p + 2 * t);
-                hA = pk_fma(splat2(w[t]), v, hA);
-                hB = pk_fma(splat2(w[t]), v * v, hB);
-                hC = fmaf(w[t], v.x * v.y, hC);
-            }
-            *reinterpret_cast<f32x2*>(tA + 2 * q) = hA; *reinterpret_cast<f32x2*>(tB + 2 * q) = hB; tC[q] = hC;
-        }
-        __syncthreads();
-        float* dA = dmap; float* dC = dmap + 2 * MR * MR;
-        float s_ssim = 0.f, s_cs = 0.f;
-        for (int q = threadIdx.x; q < MR * MR; q += 256) {
-            const int r = q / MR, m = q % MR;
-            f32x2 mu = splat2(0.f), aa = splat2(0.f);
-            float a12 = 0.f;
-#pragma unroll
-            for (int t = 0; t < 11; ++t) {
-                const int o = (r + t) * MR + m;
-                mu = pk_fma(splat2(w[t]), *reinterpret_cast<const f32x2*>(tA + 2 * o), mu);
-                aa = pk_fma(splat2(w[t]), *reinterpret_cast<const f32x2*>(tB + 2 * o), aa);
-                a12 = fmaf(w[t], tC[o], a12);
-            }
-            float ss, cs, dm, d11, d12;
-            ms_point(mu.x, mu.y, aa.x, aa.y, a12, last, &ss, &cs, &dm, &d11, &d12);
-            const bool inside = r >= 5 && r < 5 + S && m >= 5 && m < 5 + S;     // the whole plane is the tile
-            if (inside) { s_ssim += ss; s_cs += cs; } else { dm = 0.f; d11 = 0.f; d12 = 0.f; }
-            *reinterpret_cast<f32x2*>(dA + 2 * q) = f32x2{dm, d11}; dC[q] = d12;
-        }
-        s_ssim = wave_sum(s_ssim); s_cs = wave_sum(s_cs);
-        if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = s_ssim; red[(threadIdx.x >> 6) * 2 + 1] = s_cs; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            a.part[lev][(size_t)plane * 2] = (red[0] + red[2]) + (red[4] + red[6]);
-            a.part[lev][(size_t)plane * 2 + 1] = (red[1] + red[3]) + (red[5] + red[7]);
-        }
-        if (a.F[lev]) {
-            float* gA = tmp3; float* gC = tmp3 + 2 * MR * S;
-            for (int q = threadIdx.x; q < MR * S; q += 256) {
-                const int r = q / S, c = q % S;
-                f32x2 h01 = splat2(0.f);
-                float h2 = 0.f;
-#pragma unroll
-                for (int t = 0; t < 11; ++t) {
-                    h01 = pk_fma(splat2(w[t]), *reinterpret_cast<const f32x2*>(dA + 2 * (r * MR + c + t)), h01);
-                    h2 = fmaf(w[t], dC[r * MR + c + t], h2);
-                }
-                *reinterpret_cast<f32x2*>(gA + 2 * q) = h01; gC[q] = h2;
-            }
-            __syncthreads();
-            for (int q = threadIdx.x; q < S * S; q += 256) {
-                const int r = q / S, c = q % S;
-                f32x2 f01 = splat2(0.f);
-                float f2 = 0.f;
-#pragma unroll
-                for (int t = 0; t < 11; ++t) {
-                    f01 = pk_fma(splat2(w[t]), *reinterpret_cast<const f32x2*>(gA + 2 * ((r + t) * S + c)), f01);
-                    f2 = fmaf(w[t], gC[(r + t) * S + c], f2);
-                }
-                const f32x2 xy = *reinterpret_cast<const f32x2*>(lin + ((10 + r) * ER + 10 + c) * 2);
-                a.F[lev][(size_t)plane * S * S + q] = f01.x + 2.0f * xy.x * f01.y + xy.y * f2;
-            }
-        }
-        if (!last) {            // next level's zero-padded halo images from this level's interior
-            const int SN = S / 2, EN = SN + 20;
-            for (int q = threadIdx.x; q < EN * EN; q += 256) {
-                const int r = q / EN - 10, c = q % EN - 10;
-                f32x2 v = splat2(0.f);
-                if ((unsigned)r < (unsigned)SN && (unsigned)c < (unsigned)SN) {
-                    const float* p = lin + ((10 + 2 * r) * ER + 10 + 2 * c) * 2;
-                    const f32x4 u = *reinterpret_cast<const f32x4*>(p), d = *reinterpret_cast<const f32x4*>(p + 2 * ER);
-                    v = f32x2{((u[0] + u[2]) + (d[0] + d[2])) * 0.25f, ((u[1] + u[3]) + (d[1] + d[3])) * 0.25f};
-                }
-                *reinterpret_cast<f32x2*>(nxt + 2 * q) = v;
-            }
-            float* sw = lin; lin = nxt; nxt = sw;
-        }
-        __syncthreads();
     }
 }
 
@@ -896,21 +762,20 @@ __global__ __launch_bounds__(256) void msssim_bwd_kernel(MsBwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 struct MsWs {
     int64_t pyrx[5], pyry[5], F[5], part[5], slab, coef, ticket, total;
-    int nblk[5], nbig;        // nbig: levels run by the tile kernel (size >= 32)
+    int nblk[5];
 };
-static int ms_tiles(int S) { return S == 128 ? MsT<128>::TILES : 1; }      // 64 / 32: msssim_plane_kernel, one workgroup per plane
+static int ms_tiles(int S) { return S == 128 ? MsT<128>::TILES : 1; }      // <= 64: msssim_plane_kernel, one partial pair per plane
 static MsWs ms_carve(int width, int B) {
     MsWs w{};
     const int P = B * 3;
     int64_t off = 0;
     auto take = [&](int64_t n) { int64_t o = off; off += align_up(n, 64); return o; };
-    w.nbig = width == 128 ? 3 : 2;
     for (int l = 0; l < 5; ++l) {
         const int S = width >> l;
         const int64_t n = (int64_t)P * S * S;
-        if (l > 0 && l <= w.nbig) { w.pyrx[l] = take(n); w.pyry[l] = take(n); }     // levels below 16 stay in LDS
+        if (l > 0) { w.pyrx[l] = take(n); w.pyry[l] = take(n); }
         w.F[l] = take(n);
-        w.nblk[l] = l < w.nbig ? P * ms_tiles(S) : P;
+        w.nblk[l] = P * ms_tiles(S);
     }
     for (int l = 0; l < 5; ++l) w.part[l] = take((int64_t)w.nblk[l] * 2);
     w.slab = take(MS_NF * 11 * 2);
@@ -921,7 +786,7 @@ static MsWs ms_carve(int width, int B) {
 }
 int64_t msssim_ws_floats(int width, int B) { return ms_carve(width, B).total; }
 
-template <int S>
+template <int S, bool LAST>
 static int ms_fwd(const MsFwdArgs& a, hipStream_t st) {
     static DeviceOnce once;
     if (a.ticket) cvae_probe_begin(st);                 // level 0 only (the launch that also zeroes the ticket)
@@ -931,8 +796,8 @@ static int ms_fwd(const MsFwdArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(msssim_fwd_kernel<S>, dim3(a.P * T::TILES), dim3(MS_NT), T::SMEM, st, a);
     } else {
         using T = MsP<S>;
-        { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(msssim_plane_kernel<S>), T::SMEM); if (rc) return rc; }
-        hipLaunchKernelGGL(msssim_plane_kernel<S>, dim3(a.P), dim3(T::NT), T::SMEM, st, a);
+        { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(msssim_plane_kernel<S, LAST>), T::SMEM); if (rc) return rc; }
+        hipLaunchKernelGGL((msssim_plane_kernel<S, LAST>), dim3((a.P + T::PPW - 1) / T::PPW), dim3(T::NT), T::SMEM, st, a);
     }
     if (a.ticket) cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();
@@ -950,25 +815,20 @@ int launch_msssim(int width, int B, const float* img1, const float* img2, const 
     unsigned* ticket = reinterpret_cast<unsigned*>(ws + w.ticket);
     const float* lx[5]; const float* ly[5];
     lx[0] = img1; ly[0] = img2;
-    for (int l = 1; l <= w.nbig; ++l) { lx[l] = ws + w.pyrx[l]; ly[l] = ws + w.pyry[l]; }
-    for (int l = 0; l < w.nbig; ++l) {
-        MsFwdArgs a{lx[l], ly[l], ws + w.pyrx[l + 1], ws + w.pyry[l + 1], grad ? ws + w.F[l] : nullptr, ws + w.part[l],
-                    l == 0 ? ticket : nullptr, P, win};
+    for (int l = 1; l < 5; ++l) { lx[l] = ws + w.pyrx[l]; ly[l] = ws + w.pyry[l]; }
+    for (int l = 0; l < 5; ++l) {
+        const bool last = l == 4;
+        MsFwdArgs a{lx[l], ly[l], last ? nullptr : ws + w.pyrx[l + 1], last ? nullptr : ws + w.pyry[l + 1],
+                    grad ? ws + w.F[l] : nullptr, ws + w.part[l], l == 0 ? ticket : nullptr, P, win};
         switch (width >> l) {
-            case 128: rc = ms_fwd<128>(a, st); break;
-            case 64: rc = ms_fwd<64>(a, st); break;
-            default: rc = ms_fwd<32>(a, st); break;
+            case 128: rc = ms_fwd<128, false>(a, st); break;
+            case 64: rc = ms_fwd<64, false>(a, st); break;
+            case 32: rc = ms_fwd<32, false>(a, st); break;
+            case 16: rc = ms_fwd<16, false>(a, st); break;
+            case 8: rc = last ? ms_fwd<8, true>(a, st) : ms_fwd<8, false>(a, st); break;
+            default: rc = ms_fwd<4, true>(a, st); break;
         }
         if (rc) return rc;
-    }
-    {
-        MsSmallArgs s{};
-        s.x = lx[w.nbig]; s.y = ly[w.nbig]; s.P = P; s.win = win;
-        const int nsmall = 5 - w.nbig;
-        for (int k = 0; k < nsmall; ++k) { s.F[k] = grad ? ws + w.F[w.nbig + k] : nullptr; s.part[k] = ws + w.part[w.nbig + k]; }
-        if (nsmall == 3) hipLaunchKernelGGL(msssim_small_kernel<3>, dim3(P), dim3(256), MS_SMALL_SMEM, st, s);
-        else hipLaunchKernelGGL(msssim_small_kernel<2>, dim3(P), dim3(256), MS_SMALL_SMEM, st, s);
-        CVAE_CHECK_LAUNCH();
     }
     MsFinArgs f{};
     for (int l = 0; l < 5; ++l) {

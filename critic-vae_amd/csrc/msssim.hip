@@ -399,20 +399,20 @@ struct MsP {
     static constexpr int NTP = S * S / 4;     // threads per plane
     static constexpr int PPW = NTP >= 256 ? 1 : 256 / NTP;      // planes per workgroup: 256 threads below S = 32
     static constexpr int NT = NTP * PPW;
-    static constexpr int ECP = S + 10;        // input row stride (pixels): 5 zero columns either side; ECP / 2 odd (see MsT)
-    static constexpr int DAS = S + 14;        // (d_mu, d_11) row stride: 6 zero columns left (16-byte aligned stores and
-                                              // window reads; the windows are read 16 wide), 8 right; DAS / 2 odd
-    static constexpr int DCS = S + 12;        // d_12 row stride: 6 zero columns either side
+    static constexpr int DAS = S + 14;        // row stride (pixels) of the (x, y) input image AND of the (d_mu, d_11) image that later
+                                              // overlays it: 6 zero columns left (16-byte aligned stores and window reads; the
+                                              // windows are read 16 wide), 8 right — the same columns in both uses, zeroed once
+                                              // per workgroup; DAS / 2 odd (see MsT)
+    static constexpr int DCS = S + 12;        // d_12 row stride: 6 zero columns either side (behind the input image: zeroed once)
     static constexpr int TAS = S + 2;         // row stride (pixels) of the pair images in tmp: the two rows of a lane pair
                                               // land 16 bytes apart modulo 32 — their 16-byte stores interleave
     static constexpr int TR = S + 10;         // rows of the tmp images: 5 zero rows above and below
-    static constexpr int LIN_IN = 2 * S * ECP, LIN_D = S * (2 * DAS + DCS);
-    static constexpr int LIN = LIN_IN > LIN_D ? LIN_IN : LIN_D;
+    static constexpr int LIN = S * (2 * DAS + DCS);
     static constexpr int TA = 2 * TR * TAS;   // floats of one pair image
     static constexpr int TMP = 2 * TA + TR * S;
     static constexpr int PLANE = LIN + TMP;   // floats of LDS per plane
     static constexpr int SMEM = PPW * PLANE * 4;
-    static_assert((ECP / 2) % 2 == 1 && (DAS / 2) % 2 == 1 && DCS % 4 == 0 && TAS % 2 == 0 && PLANE % 4 == 0, "strides");
+    static_assert((DAS / 2) % 2 == 1 && DCS % 4 == 0 && TAS % 2 == 0 && PLANE % 4 == 0, "strides");
     static_assert(SMEM <= 160 * 1024 - 256, "LDS");
 };
 
@@ -436,6 +436,15 @@ __device__ __forceinline__ float seg_sum_dpp(float v) {
     return v;
 }
 
+#ifdef MS_TIMING      // experiment builds only (profiles/experiments/variant.sh ... -DMS_TIMING): phase timestamps of a few waves
+__device__ long long ms_dbg[4 * 2 * 16];
+extern "C" int cvae_ms_dbg_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ms_dbg), sizeof(long long) * 4 * 2 * 16); }
+#define MS_T(k) do { if (S == 64 && (threadIdx.x == 0 || threadIdx.x == NT - 64) && (blockIdx.x & 63) == 0 && blockIdx.x < 256) \
+        ms_dbg[((blockIdx.x >> 6) * 2 + (threadIdx.x != 0)) * 16 + (k)] = clock64(); } while (0)
+#else
+#define MS_T(k)
+#endif
+
 template <int S, bool LAST>
 __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
     using T = MsP<S>;
@@ -444,31 +453,14 @@ __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float red[2 * (NT / 64)];
     const int sub = PPW > 1 ? threadIdx.x / NTP : 0, tid = PPW > 1 ? threadIdx.x % NTP : threadIdx.x;
-    float* lin = smem + sub * T::PLANE;   // (x, y) pixels [S][ECP][2]; later (d_mu, d_11) [S][DAS][2] | d_12 [S][DCS]
+    float* lin = smem + sub * T::PLANE;   // (x, y) pixels [S][DAS][2], later (d_mu, d_11) in the same layout | d_12 [S][DCS]
     float* tmp = lin + T::LIN;            // (hx, hy) [TR][TAS][2] | (hxx, hyy) [TR][TAS][2] | hxy [TR][S]; later (g0, g1) | - | g2
     float* tA = tmp; float* tB = tmp + T::TA; float* tC = tmp + 2 * T::TA;
-    const int pl = xcd_tile(blockIdx.x, gridDim.x) * PPW + sub;
-    const bool valid = pl < a.P;                          // planes past the end: same work on the last plane, no stores
-    const int plane = valid ? pl : a.P - 1;
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.ticket) *a.ticket = 0u;
-    const float* px = a.x + (size_t)plane * S * S;
-    const float* py = a.y + (size_t)plane * S * S;
     float w[11];
 #pragma unroll
     for (int t = 0; t < 11; ++t) w[t] = a.win.w[t];
-    // ---- stage the plane, (x, y) interleaved per pixel, between 5 zero columns; zero rows of the tmp images ----
-    {
-        float vx[4], vy[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { vx[k] = px[tid + k * NTP]; vy[k] = py[tid + k * NTP]; }
-        const int r = tid / S, c = tid % S;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)      // rows r, r + S/4, ...
-            *reinterpret_cast<f32x2*>(lin + ((r + k * (S / 4)) * T::ECP + 5 + c) * 2) = f32x2{vx[k], vy[k]};
-        for (int q = tid; q < S * 10; q += NTP) {
-            const int zr = q / 10, j = q % 10;
-            *reinterpret_cast<f32x2*>(lin + (zr * T::ECP + (j < 5 ? j : S + j)) * 2) = splat2(0.f);
-        }
+    {   // the 5 zero rows above and below the tmp images: written once, no pass ever stores there
         constexpr int ZP = 5 * T::TAS * 2 / 4, ZC = 5 * S / 4;        // 16-byte units of one block of 5 zero rows
         static_assert(ZP * 4 == 5 * T::TAS * 2 && ZC * 4 == 5 * S && ((S + 5) * T::TAS * 2) % 4 == 0 && T::TA % 4 == 0, "16-byte zero fill");
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -477,24 +469,73 @@ __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
             reinterpret_cast<f32x4*>(tB)[q] = z; reinterpret_cast<f32x4*>(tB + (S + 5) * T::TAS * 2)[q] = z;
         }
         for (int q = tid; q < ZC; q += NTP) { reinterpret_cast<f32x4*>(tC)[q] = z; reinterpret_cast<f32x4*>(tC + (S + 5) * S)[q] = z; }
+        // ... and the zero columns of the input / derivative images: per row 3 + 4 16-byte units of the pair image, 6 + 6 floats of d_12
+        float* dA0 = lin; float* dC0 = lin + 2 * S * T::DAS;
+        for (int q = tid; q < S * 16; q += NTP) {
+            const int zr = q >> 4, k = q & 15;
+            float* ra = dA0 + zr * T::DAS * 2; float* rc = dC0 + zr * T::DCS;
+            if (k < 3) *reinterpret_cast<f32x4*>(ra + 4 * k) = z;
+            else if (k < 7) *reinterpret_cast<f32x4*>(ra + (S + 6) * 2 + 4 * (k - 3)) = z;
+            else if (k == 7) *reinterpret_cast<f32x4*>(rc) = z;
+            else if (k == 8) *reinterpret_cast<f32x2*>(rc + 4) = splat2(0.f);
+            else if (k == 9) *reinterpret_cast<f32x2*>(rc + S + 6) = splat2(0.f);
+            else if (k == 10) *reinterpret_cast<f32x4*>(rc + S + 8) = z;
+        }
     }
+    // Persistent: the grid is one residency of the chip (LDS-limited, 1 workgroup per CU at S = 64) and every workgroup walks
+    // its share of the planes; the next plane's pixels are fetched into registers while this one is filtered, so the HBM
+    // latency of the staging loads (2-5 k cycles with nothing else resident on the CU) is paid once per workgroup.
+    const int ngroups = (a.P + PPW - 1) / PPW;
+    float2 vx[2], vy[2];                  // pixels (r, 2c), (r, 2c + 1) of rows r = tid / H and r + H
+    {
+        const int p0 = min((int)blockIdx.x * PPW + sub, a.P - 1);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            vx[k] = *reinterpret_cast<const float2*>(a.x + (size_t)p0 * S * S + 2 * (tid + k * NTP));
+            vy[k] = *reinterpret_cast<const float2*>(a.y + (size_t)p0 * S * S + 2 * (tid + k * NTP));
+        }
+    }
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int pl = grp * PPW + sub;
+    const bool valid = pl < a.P;                          // planes past the end: same work on the last plane, no stores
+    const int plane = valid ? pl : a.P - 1;
+    const float* px = a.x + (size_t)plane * S * S;
+    const float* py = a.y + (size_t)plane * S * S;
+    MS_T(0);
+    // ---- stage the plane, (x, y) interleaved per pixel (the zero columns either side are already there) ----
+    {
+        const int r = tid / H, c = (tid % H) * 2;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            *reinterpret_cast<f32x4*>(lin + ((r + k * H) * T::DAS + 6 + c) * 2) = f32x4{vx[k].x, vy[k].x, vx[k].y, vy[k].y};
+        if (grp + (int)gridDim.x < ngroups) {             // next plane of this workgroup: in flight during the four passes
+            const int pn = min((grp + (int)gridDim.x) * PPW + sub, a.P - 1);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                vx[k] = *reinterpret_cast<const float2*>(a.x + (size_t)pn * S * S + 2 * (tid + k * NTP));
+                vy[k] = *reinterpret_cast<const float2*>(a.y + (size_t)pn * S * S + 2 * (tid + k * NTP));
+            }
+        }
+    }
+    MS_T(1);
     __syncthreads();
+    MS_T(2);
     // ---- 2x2 average for the next level (avg_pool2d, vae_nets.py:232-233): one output per thread ----
     if (a.nx) {
         const int pr = tid / H, pc = tid % H;
-        const float* p = lin + ((2 * pr) * T::ECP + 5 + 2 * pc) * 2;
-        const f32x2 u0 = *reinterpret_cast<const f32x2*>(p), u1 = *reinterpret_cast<const f32x2*>(p + 2);
-        const f32x2 d0 = *reinterpret_cast<const f32x2*>(p + 2 * T::ECP), d1 = *reinterpret_cast<const f32x2*>(p + 2 * T::ECP + 2);
-        const f32x2 o = ((u0 + u1) + (d0 + d1)) * splat2(0.25f);
+        const float* p = lin + ((2 * pr) * T::DAS + 6 + 2 * pc) * 2;
+        const f32x4 u = *reinterpret_cast<const f32x4*>(p), d = *reinterpret_cast<const f32x4*>(p + 2 * T::DAS);      // (x0, y0, x1, y1)
+        const f32x2 o = ((f32x2{u[0], u[1]} + f32x2{u[2], u[3]}) + (f32x2{d[0], d[1]} + f32x2{d[2], d[3]})) * splat2(0.25f);
         if (valid) { a.nx[(size_t)plane * NTP + tid] = o.x; a.ny[(size_t)plane * NTP + tid] = o.y; }
     }
-    // ---- horizontal pass of {x, y, x^2, y^2, xy}: 4 adjacent outputs per thread from a 14-wide register window ----
+    // ---- horizontal pass of {x, y, x^2, y^2, xy}: 4 adjacent outputs per thread from a register window (16 pixels from
+    //      column c - 6, 16-byte aligned; taps at window positions o + 1 .. o + 11) ----
     const int hr = 2 * (tid / (2 * J)) + (tid & 1), hc = ((tid % (2 * J)) >> 1) * 4;      // neighbouring lanes: the two rows of a pair
     {
-        const float* p = lin + (hr * T::ECP + hc) * 2;
-        f32x2 xy[14];
+        const float* p = lin + (hr * T::DAS + hc) * 2;
+        f32x2 xy[16];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
+        for (int i = 0; i < 8; ++i) {
             const f32x4 u = *reinterpret_cast<const f32x4*>(p + 4 * i);
             xy[2 * i] = f32x2{u[0], u[1]}; xy[2 * i + 1] = f32x2{u[2], u[3]};
         }
@@ -506,7 +547,7 @@ __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
             float sC = 0.f;
 #pragma unroll
             for (int t = 0; t < 11; ++t) {
-                const f32x2 v = xy[o + t];
+                const f32x2 v = xy[o + t + 1];
                 sA = pk_fma(splat2(w[t]), v, sA);
                 sB = pk_fma(splat2(w[t]), v * v, sB);
                 sC = fmaf(w[t], v.x * v.y, sC);
@@ -520,33 +561,26 @@ __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
         *reinterpret_cast<f32x4*>(tB + d + 4) = f32x4{hB[2].x, hB[2].y, hB[3].x, hB[3].y};
         *reinterpret_cast<f32x4*>(tC + (hr + 5) * S + hc) = f32x4{hC[0], hC[1], hC[2], hC[3]};
     }
+    MS_T(3);
     __syncthreads();
+    MS_T(4);
     // ---- vertical pass (2 rows x 2 columns per thread) + SSIM / CS maps + derivative maps into the input buffer ----
     const int vr = (tid / H) * 2, vc = (tid % H) * 2;
     float* dA = lin; float* dC = lin + 2 * S * T::DAS;
     float s_ssim = 0.f, s_cs = 0.f;
     {
-        // zero columns of the derivative maps: per row 3 + 4 16-byte units of dA, 6 + 6 floats of dC
-        for (int q = tid; q < S * 16; q += NTP) {
-            const int zr = q >> 4, k = q & 15;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            float* ra = dA + zr * T::DAS * 2; float* rc = dC + zr * T::DCS;
-            if (k < 3) *reinterpret_cast<f32x4*>(ra + 4 * k) = z;
-            else if (k < 7) *reinterpret_cast<f32x4*>(ra + (S + 6) * 2 + 4 * (k - 3)) = z;
-            else if (k == 7) *reinterpret_cast<f32x4*>(rc) = z;
-            else if (k == 8) *reinterpret_cast<f32x2*>(rc + 4) = splat2(0.f);
-            else if (k == 9) *reinterpret_cast<f32x2*>(rc + S + 6) = splat2(0.f);
-            else if (k == 10) *reinterpret_cast<f32x4*>(rc + S + 8) = z;
-        }
         constexpr int VR = 2;
         f32x2 mu[VR][2], aa[VR][2], a12[VR];
 #pragma unroll
         for (int o = 0; o < VR; ++o) { mu[o][0] = mu[o][1] = aa[o][0] = aa[o][1] = a12[o] = splat2(0.f); }
+        // one base address per image, rows at compile-time offsets (ds_read immediates, no per-row address arithmetic)
+        const float* pA = tA + (vr * T::TAS + vc) * 2;
+        const float* pC = tC + vr * S + vc;
 #pragma unroll
         for (int i = 0; i < VR + 10; ++i) {               // tmp row vr + i = image row vr + i - 5
-            const f32x4 vA = *reinterpret_cast<const f32x4*>(tA + ((vr + i) * T::TAS + vc) * 2);
-            const f32x4 vB = *reinterpret_cast<const f32x4*>(tB + ((vr + i) * T::TAS + vc) * 2);
-            const f32x2 vC = *reinterpret_cast<const f32x2*>(tC + (vr + i) * S + vc);
+            const f32x4 vA = *reinterpret_cast<const f32x4*>(pA + i * (T::TAS * 2));
+            const f32x4 vB = *reinterpret_cast<const f32x4*>(pA + T::TA + i * (T::TAS * 2));
+            const f32x2 vC = *reinterpret_cast<const f32x2*>(pC + i * S);
 #pragma unroll
             for (int o = 0; o < VR; ++o) {
                 if (i - o < 0 || i - o > 10) continue;
@@ -575,7 +609,9 @@ __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
         a.part[(size_t)plane * 2] = s_ssim;
         a.part[(size_t)plane * 2 + 1] = s_cs;
     }
+    MS_T(5);
     __syncthreads();
+    MS_T(6);
     if constexpr (WPP > 1) {
         if (tid == 0 && valid) {
             float t0 = 0.f, t1 = 0.f;
@@ -585,7 +621,7 @@ __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
             a.part[(size_t)plane * 2 + 1] = t1;
         }
     }
-    if (!a.F) return;
+    if (!a.F) continue;         // (all waves are past the barrier above: the next plane may be staged over the derivative maps)
     // ---- the same separable filter over the three derivative maps: horizontal (16-wide windows from column c - 6) ... ----
     {
         f32x2 va[16];
@@ -618,7 +654,9 @@ __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
         *reinterpret_cast<f32x4*>(tA + d + 4) = f32x4{gAo[2].x, gAo[2].y, gAo[3].x, gAo[3].y};
         *reinterpret_cast<f32x4*>(tC + (hr + 5) * S + hc) = gCo;
     }
+    MS_T(7);
     __syncthreads();
+    MS_T(8);
     // ---- ... vertical (2 rows x 2 columns per thread), then F = f0 + 2 x f1 + y f2 ----
     {
         constexpr int VR = 2;
@@ -632,10 +670,12 @@ __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
         f32x2 f01[VR][2], f2[VR];
 #pragma unroll
         for (int o = 0; o < VR; ++o) { f01[o][0] = f01[o][1] = f2[o] = splat2(0.f); }
+        const float* pA = tA + (vr * T::TAS + vc) * 2;
+        const float* pC = tC + vr * S + vc;
 #pragma unroll
         for (int i = 0; i < VR + 10; ++i) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(tA + ((vr + i) * T::TAS + vc) * 2);
-            const f32x2 u = *reinterpret_cast<const f32x2*>(tC + (vr + i) * S + vc);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(pA + i * (T::TAS * 2));
+            const f32x2 u = *reinterpret_cast<const f32x2*>(pC + i * S);
 #pragma unroll
             for (int o = 0; o < VR; ++o) {
                 if (i - o < 0 || i - o > 10) continue;
@@ -653,6 +693,8 @@ __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
                                 f01[o][1].x + 2.0f * xv[o].y * f01[o][1].y + yv[o].y * f2[o].y);
         }
     }
+    MS_T(9);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -797,7 +839,9 @@ static int ms_fwd(const MsFwdArgs& a, hipStream_t st) {
     } else {
         using T = MsP<S>;
         { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(msssim_plane_kernel<S, LAST>), T::SMEM); if (rc) return rc; }
-        hipLaunchKernelGGL((msssim_plane_kernel<S, LAST>), dim3((a.P + T::PPW - 1) / T::PPW), dim3(T::NT), T::SMEM, st, a);
+        constexpr int byLds = (160 * 1024) / (T::SMEM + 256), byThreads = 2048 / T::NT;
+        const int resident = cvae_num_cus() * (byLds < byThreads ? byLds : byThreads), ngroups = (a.P + T::PPW - 1) / T::PPW;
+        hipLaunchKernelGGL((msssim_plane_kernel<S, LAST>), dim3(ngroups < resident ? ngroups : resident), dim3(T::NT), T::SMEM, st, a);
     }
     if (a.ticket) cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();

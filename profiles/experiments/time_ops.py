@@ -37,6 +37,15 @@ def main():
         scal = torch.empty(16, device=dev)
         d = torch.empty_like(a)
         t_all = timeit(lambda: H.op_msssim(B, a, b, ws, scal, d))
+        if hasattr(H.lib, "cvae_ms_dbg_read"):        # -DMS_TIMING build: phase timestamps (clock64) of waves 0 / 15 of four workgroups
+            import ctypes
+            buf = (ctypes.c_longlong * 128)()
+            torch.cuda.synchronize()
+            H.lib.cvae_ms_dbg_read(buf)
+            names = ["stage", "B0", "pool+H1", "B1", "V1", "B2", "part+H2", "B3", "V2"]
+            for g in range(8):
+                t = list(buf[g * 16:g * 16 + 10])
+                print(f"wg {1024 * (g // 2)} wave {'0' if g % 2 == 0 else 'last'}: " + "  ".join(f"{n} {t[i + 1] - t[i]}" for i, n in enumerate(names)) + f"  total {t[9] - t[0]}")
         t_fwd = timeit(lambda: H.op_msssim(B, a, b, ws, scal, None))
         print(f"msssim B={B} W={W}: fwd+bwd {t_all:.1f} us, fwd only {t_fwd:.1f} us, loss {float(scal[1]):.6f}")
 

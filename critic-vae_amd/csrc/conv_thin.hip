@@ -691,8 +691,8 @@ __global__ __launch_bounds__(256) void d4_perm_kernel(const float* __restrict__ 
                                                       const float* __restrict__ part, float* __restrict__ db, int B) {
     if (blockIdx.x == gridDim.x - 1) {
         const int co = threadIdx.x >> 6, lane = threadIdx.x & 63;      // waves 0..2 = the three output channels
-        if (!part) {                        // bf16 mode: the fused backward left the sums in row 76 of the slab
-            if (threadIdx.x < 3) db[threadIdx.x] = red[76 * 32 + threadIdx.x];
+        if (!part) {                        // bf16 mode: the fused backward left the sums in row 3 of the slab
+            if (threadIdx.x < 3) db[threadIdx.x] = red[3 * 32 + threadIdx.x];
             return;
         }
         if (co < 3) {
@@ -706,6 +706,16 @@ __global__ __launch_bounds__(256) void d4_perm_kernel(const float* __restrict__ 
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= 2400) return;
     const int co = i % 3, ci = (i / 3) % 32, tap = i / 96;
+    if (!part) {                            // bf16 mode: red = dV[i][j][co][ci] of the phase-collapsed form; tap (r, s) is reached from
+        const int r = tap / 5, s5 = tap % 5;        // the window positions i in {4-r, 5-r}, j in {4-s, 5-s} (d4_bwd_bf16_kernel)
+        float acc = 0.f;
+#pragma unroll
+        for (int di = 0; di < 2; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) acc += red[(((4 - r + di) * 8 + (4 - s5 + dj)) * 4 + co) * 32 + ci];
+        dst[i] = acc;
+        return;
+    }
     dst[i] = red[(tap * 3 + co) * 32 + ci];
 }
 
@@ -883,47 +893,71 @@ __global__ __launch_bounds__(256, THIN_F32_OCC) void d4_fwd_kernel(const float* 
     }
 }
 
-// precision mode 1: the same forward with o3 read as bf16 and Q = o3 . W on v_mfma_f32_32x32x16_bf16 (K = 32 channels
-// = 2 k-steps x 3 column blocks: 6 MFMAs per 32 source pixels instead of 48 fp32 ones).  The source tile sits in LDS
-// as bf16 rows of 80 bytes (conflict-free 16-byte fragment reads); gather-sum, Tanh and the NCHW fp32 store are unchanged.
+// precision mode 1 (round 3): Upsample(2) -> Conv5x5 -> Tanh as the PHASE-COLLAPSED 3x3 conv of conv_up.hip over the stored
+// low-resolution o3, straight on the MFMA.  Output pixel (2y+py, 2x+px) reads source pixel (y+a-1, x+b-1) through the 5x5
+// taps r with floor((py+r-2)/2) = a-1 (and s likewise), so with wc[p][a][b] = the sum of those taps' weights
+//     out[2y+py][2x+px][co] = bias[co] + sum_{a,b < 3} sum_ci o3[y+a-1][x+b-1][ci] * wc[p][a][b][ci][co]
+// = a GEMM with M = source pixels, N = 4 phases x 3 channels = 12 (one 16-column v_mfma_f32_16x16x32_bf16 block: 75 % of
+// the accumulator lanes carry an output, against 37 % for a 32-column block) and K = 9 taps x 32 channels: 9 MFMAs per
+// 16 source pixels, their A fragments read in place from the staged halo tile (a tap is an address offset), the collapsed
+// weights in registers for the whole launch.  The round-2 kernel computed Q[source][tap, co] for the 10x10 window and had
+// every output pixel gather its 25 taps from LDS: 48 ds_write_b32 + 75 ds_read_b32 per thread and tile, which bound it
+// (134 us at B = 2048 for 235 MB); here a wave issues 18 ds_read_b128 + 8 ds_write_b32 per 32 source pixels.
+// Workgroup = 8 x 16 source pixels (16 x 32 outputs), wave w = source rows 2w, 2w+1; Tanh in the accumulator layout, the
+// NCHW fp32 rows leave through an LDS transpose as 8-byte stores.
 template <int H>
-__global__ __launch_bounds__(256, 3) void d4_fwd_bf16_kernel(const float* __restrict__ in, const float* __restrict__ w,
+__global__ __launch_bounds__(256, 4) void d4_fwd_bf16_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ recon, int B) {
-    constexpr int HS = H / 2, TX = H / 16, TPI = TX * TX, AS = 40;      // AS: row stride of the source tile in elements
-    __shared__ __attribute__((aligned(16))) __bf16 lds_a[128 * AS];
-    __shared__ float lds_q[100 * 97];                  // only the 10x10 window's rows are ever read: 49 KB with lds_a -> three workgroups per CU
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    bf16x8 bw[2][3];
+    constexpr int HS = H / 2, TXN = HS / 16, TPI = (HS / 8) * TXN;
+    constexpr int HW = 18, HP = 10 * HW, PSP = 180;            // halo tile 10 x 18 source pixels; plane stride == 4 (mod 16) units:
+    static_assert(PSP >= HP && PSP % 16 == 4, "plane stride");  // the 4 octets x 4 pixels of a store phase hit 16 different 16-byte slots
+    constexpr int OS = 34;                                       // row stride (floats) of the output tile [3][16][OS]
+    __shared__ __attribute__((aligned(16))) bf16x8 lds_a[4 * PSP];      // [channel octet][halo pixel]
+    __shared__ __attribute__((aligned(16))) float lds_o[3 * 16 * OS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lg = lane >> 4;
+    // collapsed weights as B fragments: column n = p*3 + co (n >= 12: zero), k = ci; built once per workgroup in LDS (the
+    // halo buffer, before the first tile), then this lane's 9 fragments (tap t = a*3 + b, k = 8*lg + j) stay in registers
+    bf16x8 bw[9];
+    {
+        __bf16* wl = reinterpret_cast<__bf16*>(lds_a);           // [t][n][lg][8]
+        static_assert(9 * 16 * 4 <= 4 * PSP, "weight fragments fit in the halo buffer");
+        for (int q = tid; q < 9 * 16 * 32; q += 256) {
+            const int ci = q & 31, n = (q >> 5) & 15, t = q >> 9;
+            const int pz = n / 3, co = n % 3, py = pz >> 1, px = pz & 1, ta = t / 3, tb = t % 3;
+            // 5x5 taps that reach source row offset ta-1 from output phase py: py = 0: {0,1},{2,3},{4}; py = 1: {0},{1,2},{3,4}
+            const int r0 = py ? (ta == 0 ? 0 : 2 * ta - 1) : 2 * ta, r1 = py ? 2 * ta : (ta == 2 ? 4 : 2 * ta + 1);
+            const int s0 = px ? (tb == 0 ? 0 : 2 * tb - 1) : 2 * tb, s1 = px ? 2 * tb : (tb == 2 ? 4 : 2 * tb + 1);
+            float acc = 0.f;
+            if (n < 12)
+                for (int r = r0; r <= r1; ++r)
+                    for (int s5 = s0; s5 <= s1; ++s5) acc += w[((r * 5 + s5) * 32 + ci) * 3 + co];
+            wl[((t * 16 + n) * 4 + (ci >> 3)) * 8 + (ci & 7)] = (__bf16)acc;
+        }
+        __syncthreads();
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int nb = 0; nb < 3; ++nb)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int n = nb * 32 + li, ci = 16 * ks + 8 * lh + j;
-                bw[ks][nb][j] = (__bf16)(n < 75 ? w[((n / 3) * 32 + ci) * 3 + n % 3] : 0.f);
-            }
-    const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
+        for (int t = 0; t < 9; ++t) bw[t] = lds_a[(t * 16 + lc) * 4 + lg];
+        __syncthreads();
+    }
+    const float bv = lc < 12 ? bias[lc % 3] : 0.f;
     const int numTiles = B * TPI;
     bf16x8 zero8;
 #pragma unroll
     for (int c = 0; c < 8; ++c) zero8[c] = (__bf16)0.f;
-    for (int q = tid; q < 28 * 4; q += 256) *reinterpret_cast<bf16x8*>(lds_a + (100 + (q >> 2)) * AS + (q & 3) * 8) = zero8;   // rows 100..127 stay 0
-    bf16x8 ra[2];
+    bf16x8 ra[3];
     auto fetch = [&](int tile) {
         const int ib = tile / TPI, t = tile % TPI;
-        const int sy0 = (t / TX) * 8 - 1, sx0 = (t % TX) * 8 - 1;           // 10x10 source window
+        const int sy0 = (t / TXN) * 8 - 1, sx0 = (t % TXN) * 16 - 1;           // 10 x 18 source window
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 3; ++i) {
             const int q = tid + i * 256, c8 = q & 3, sp = q >> 2;
-            const int sy = sy0 + sp / 10, sx = sx0 + sp % 10;
-            const bool ok = sp < 100 && (unsigned)sy < (unsigned)HS && (unsigned)sx < (unsigned)HS;
+            const int sy = sy0 + sp / HW, sx = sx0 + sp % HW;
+            const bool ok = sp < HP && (unsigned)sy < (unsigned)HS && (unsigned)sx < (unsigned)HS;
             const bf16x8 l = Act<__bf16>::ld8(in, ok ? ((size_t)(ib * HS + sy) * HS + sx) * 32 + c8 * 8 : 0);
             ra[i] = ok ? l : zero8;
         }
     };
     // XCD-aware tile order (common.h, xcd_tile): workgroups b, b+8, ... share an XCD, so each XCD walks ONE contiguous
-    // eighth of the tiles — the 10x10 source windows of neighbouring tiles overlap by two rows / columns, and the overlap is
+    // eighth of the tiles — the source windows of neighbouring tiles overlap by two rows / columns, and the overlap is
     // then re-read from that XCD's L2 instead of from HBM by another XCD
     const int G = gridDim.x;
     auto tile_of = [&](int n) {
@@ -935,49 +969,39 @@ __global__ __launch_bounds__(256, 3) void d4_fwd_bf16_kernel(const float* __rest
     for (int n = blockIdx.x; n < numTiles; n += G) {
         const int tile = tile_of(n);
         const int ib = tile / TPI, t = tile % TPI;
-        const int ty0 = (t / TX) * 16, tx0 = (t % TX) * 16, sy0 = ty0 / 2 - 1, sx0 = tx0 / 2 - 1;
+        const int ty0 = (t / TXN) * 16, tx0 = (t % TXN) * 32;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 3; ++i) {
             const int q = tid + i * 256;
-            if (q < 400) *reinterpret_cast<bf16x8*>(lds_a + (q >> 2) * AS + (q & 3) * 8) = ra[i];
+            if (q < HP * 4) lds_a[(q & 3) * PSP + (q >> 2)] = ra[i];
         }
-        __syncthreads();       // also: every thread is past the previous tile's gather, lds_q is free
+        __syncthreads();       // also: every thread is past the previous tile's output rows, lds_o is free
         if (n + G < numTiles) fetch(tile_of(n + G));
-        f32x16 acc[3];
+        f32x4 acc[2];
 #pragma unroll
-        for (int nb = 0; nb < 3; ++nb)
+        for (int g = 0; g < 2; ++g) {
+            acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bf16x8* ap = lds_a + lg * PSP + (2 * wave + g) * HW + lc;      // source row 2w+g, column lc of the tile: halo (row, col) + tap
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[nb][v] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 av = *reinterpret_cast<const bf16x8*>(lds_a + (wave * 32 + li) * AS + (2 * ks + lh) * 8);
-#pragma unroll
-            for (int nb = 0; nb < 3; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw[ks][nb], acc[nb], 0, 0, 0);
+            for (int t = 0; t < 9; ++t)
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[(t / 3) * HW + t % 3], bw[t], acc[g], 0, 0, 0);
         }
+        if (lc < 12) {
+            const int pz = lc / 3, co = lc % 3;
 #pragma unroll
-        for (int nb = 0; nb < 3; ++nb)
+            for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int row = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-                if (row < 100) lds_q[row * 97 + nb * 32 + li] = acc[nb][v];
-            }
+                for (int i = 0; i < 4; ++i)       // accumulator row 4*lg + i = source column of row 2w+g
+                    lds_o[(co * 16 + 2 * (2 * wave + g) + (pz >> 1)) * OS + 2 * (4 * lg + i) + (pz & 1)] = fast_tanh(acc[g][i] + bv);
+        }
         __syncthreads();
-        const int oy = tid >> 4, ox = tid & 15;
-        float s0 = b0, s1 = b1, s2 = b2;
+        {
+            const int oy = tid >> 4, ox = (tid & 15) * 2;
 #pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            const int sr = ((ty0 + oy + r - 2) >> 1) - sy0;
-#pragma unroll
-            for (int s5 = 0; s5 < 5; ++s5) {
-                const int sc = ((tx0 + ox + s5 - 2) >> 1) - sx0;
-                const float* qv = lds_q + (sr * 10 + sc) * 97 + (r * 5 + s5) * 3;
-                s0 += qv[0]; s1 += qv[1]; s2 += qv[2];
-            }
+            for (int co = 0; co < 3; ++co)
+                *reinterpret_cast<float2*>(recon + ((size_t)(ib * 3 + co) * H + ty0 + oy) * H + tx0 + ox) =
+                    *reinterpret_cast<const float2*>(lds_o + (co * 16 + oy) * OS + ox);
         }
-        const size_t o = ((size_t)(ib * 3) * H + ty0 + oy) * H + tx0 + ox;
-        recon[o] = fast_tanh(s0);
-        recon[o + (size_t)H * H] = fast_tanh(s1);
-        recon[o + 2 * (size_t)H * H] = fast_tanh(s2);
     }
 }
 
@@ -1118,32 +1142,54 @@ __global__ __launch_bounds__(256, THIN_F32_OCC) void d4_bwd_kernel(ThinWgradArgs
     thin_slab_out(accw, smem, a.slab + (size_t)blockIdx.x * 96 * 32);
 }
 
-// precision mode 1: the fused D4 backward on the bf16 MFMA.  G is built in LDS as bf16 rows of 88 elements; the input
-// gradient is 5 MFMAs (K = 75 padded to 80, weights in registers), the weight gradient contracts each wave's 32 source
-// pixels in 2 k-steps x 3 row blocks with both operands read TRANSPOSED out of the row-major G / o3 tiles
-// (ds_read_b64_tr_b16): 11 MFMAs per 32 source pixels and wave instead of 86 fp32 ones.  o3 / d_o3 are bf16 in HBM.
+// precision mode 1 (round 3): the fused D4 backward on the bf16 MFMA in the phase-collapsed form of the forward.  Source pixel
+// (y, x) is read by the 6 x 6 output pixels (2y-2+i, 2x-2+j), i, j < 6, output (i, j) reaching it through the 5x5 taps
+// r in {4-i, 5-i}, s in {4-j, 5-j} (those inside 0..4), so with V[i][j] = the sum of those taps' weights
+//     d_o3[y][x][ci]   = relu'(o3) * sum_{i,j,co} dOut[2y-2+i][2x-2+j][co] * V[i][j][ci][co]
+//     dV[i][j][ci][co] = sum_{y,x} dOut[2y-2+i][2x-2+j][co] * o3[y][x][ci],   dW[r][s] = sum_{i in {4-r,5-r}, j in {4-s,5-s}} dV[i][j]
+// The A-side operand of BOTH contractions is dOut itself: staged once per tile as a bf16 image [row][column][4] (channel 3 =
+// 0), a source pixel's 6 x 6 window is 6 runs of 8 columns x 4 channels = 32 contiguous elements (columns 6, 7 of a run meet
+// zero weights), i.e. K = 6 x 32 = 192 read in place — 16-byte reads for the input gradient, transposed 8-byte reads
+// (ds_read_b64_tr_b16, every lane supplies its own source pixel's address) for the weight gradient.  The round-2 kernel built
+// G[source][tap, co] (sums of up to 2 x 2 outputs) in LDS first: ~100 LDS operations per thread and tile, which bound it
+// (175 us at B = 2048 for 485 MB); here the tile costs a wave 12 + 12 MFMAs, 12 ds_read_b128 and 32 transposed reads.
+//   input gradient : C[ci][source pixel] = V^T . dOut^T, 12 k-steps (weights in registers as A fragments, the wave's 32
+//                    source pixels as columns): lane = pixel, registers = 4 consecutive channels x 4 -> 8-byte bf16 stores;
+//   weight gradient: dV[k][ci] over K = source pixels; wave w takes k-blocks {w>>1, (w>>1)+2, (w>>1)+4} over the tile half w&1
+//                    (3 accumulators per wave instead of 6); halves are added through LDS at the end.
+// Slab row of a workgroup: [192 k][32 ci], k = i*32 + j*4 + co; row 3 (a zero row: co = 3) carries the bias-gradient partials.
 #ifndef D4B_OCC
-#define D4B_OCC 2          // workgroups per CU of the bf16 D4 backward (splits = D4B_OCC * CUs); 3 spills 41 registers: 321 us against 174
+#define D4B_OCC 2          // workgroups per CU of the bf16 D4 backward (splits = D4B_OCC * CUs)
 #endif
+static constexpr int D4P_ROW = 192 * 32;
+static constexpr int D4P_IW = 40;                 // image row stride in pixels (36 staged + 4 zero columns for the 8-wide runs)
 template <int H>
 __global__ __launch_bounds__(256, D4B_OCC) void d4_bwd_bf16_kernel(ThinWgradArgs a) {
     constexpr int HS = H / 2, TPI = (HS / 8) * (HS / 16);
-    constexpr int G0 = 3 * 720, GS = 88;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* lds_g0 = smem;                                              // dOut halo planes [3][20][36] fp32
-    __bf16* lds_o = reinterpret_cast<__bf16*>(smem + G0);              // o3 tile [128][32]
-    __bf16* lds_G = lds_o + 128 * 32;                                  // [128][88] (+16 pad)
+    constexpr int IMG = 20 * D4P_IW * 4;                                        // elements of the dOut image
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* img = reinterpret_cast<__bf16*>(smem_raw);                          // [20 rows][40 columns][4]
+    __bf16* lds_o = img + IMG;                                                  // o3 tile [128][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    bf16x8 bwd[5];                                                     // W4r[k = tap*3+co][ci = li], k = 16kb + 8lh + j
-#pragma unroll
-    for (int kb = 0; kb < 5; ++kb)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = 16 * kb + 8 * lh + j;
-            bwd[kb][j] = (__bf16)(k < 75 ? a.w[((k / 3) * 32 + li) * 3 + k % 3] : 0.f);
+    // collapsed weights as A fragments of the input gradient: row ci = li, k-step m covers k = 16m + 8lh + jj
+    bf16x8 vw[12];
+    {
+        static_assert(12 * 32 * 2 * 8 <= IMG + 128 * 32, "weight fragments fit in the staging buffers");
+        for (int q = tid; q < 192 * 32; q += 256) {
+            const int ci = q & 31, k = q >> 5, co = k & 3, j = (k >> 2) & 7, i = k >> 5;
+            float acc = 0.f;
+            if (co < 3 && j < 6)
+                for (int r = (4 - i < 0 ? 0 : 4 - i); r <= (5 - i > 4 ? 4 : 5 - i); ++r)
+                    for (int s5 = (4 - j < 0 ? 0 : 4 - j); s5 <= (5 - j > 4 ? 4 : 5 - j); ++s5) acc += a.w[((r * 5 + s5) * 32 + ci) * 3 + co];
+            img[(((k >> 4) * 32 + ci) * 2 + ((k >> 3) & 1)) * 8 + (k & 7)] = (__bf16)acc;
         }
-    for (int q = tid; q < 128 * 13; q += 256) lds_G[(q / 13) * GS + 75 + q % 13] = (__bf16)0.f;     // K pad columns stay zero
-    if (tid < 16) lds_G[128 * GS + tid] = (__bf16)0.f;
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 12; ++m) vw[m] = *reinterpret_cast<const bf16x8*>(img + ((m * 32 + li) * 2 + lh) * 8);
+        __syncthreads();
+    }
+    for (int q = tid; q < 20 * 2; q += 256)       // columns 36..39 of every image row stay zero (16 elements = two 16-byte units per row)
+        *reinterpret_cast<f32x4*>(img + ((q >> 1) * D4P_IW + 36) * 4 + (q & 1) * 8) = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x16 accw[3];
 #pragma unroll
     for (int mb = 0; mb < 3; ++mb)
@@ -1151,21 +1197,24 @@ __global__ __launch_bounds__(256, D4B_OCC) void d4_bwd_bf16_kernel(ThinWgradArgs
         for (int v = 0; v < 16; ++v) accw[mb][v] = 0.f;
     const int t0 = blockIdx.x * a.tilesPerSplit;
     int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
-    constexpr int GQ = (G0 / 2 + 255) / 256;             // the halo travels as 8-byte pairs (its first column 2*sx0 - 2 is even)
-    float2 rg[GQ];
+    // staging: item q = (image row, column pair) carries both pixels x 3 channels: 6 + 6 8-byte loads, one 16-byte LDS unit
+    float2 rg[2][3], rr[2][3];
     bf16x8 ro[2];
     auto fetch = [&](int mt) {
         const int ib = mt / TPI, t = mt % TPI;
         const int sy0 = (t / (HS / 16)) * 8, sx0 = (t % (HS / 16)) * 16;
 #pragma unroll
-        for (int i = 0; i < GQ; ++i) {
-            const int q = tid + i * 256, c = q / 360, rem = q % 360;
-            const int uy = 2 * sy0 - 2 + rem / 18, ux = 2 * sx0 - 2 + 2 * (rem % 18);
-            const bool ok = q < G0 / 2 && (unsigned)uy < (unsigned)H && (unsigned)ux < (unsigned)H;     // ux even: ux + 1 is inside with it
-            const size_t e = ok ? ((size_t)(ib * 3 + c) * H + uy) * H + ux : 0;
-            const float2 g = *reinterpret_cast<const float2*>(a.a0 + e), r = *reinterpret_cast<const float2*>(a.a2 + e);
-            // dOut = d_recon * (1 - recon^2): Tanh backward (vae_nets.py:134), d4_actbwd_kernel's expression
-            rg[i] = ok ? make_float2(g.x * (1.f - r.x * r.x), g.y * (1.f - r.y * r.y)) : make_float2(0.f, 0.f);
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + i * 256, row = q / 18, cp = q % 18;
+            const int uy = 2 * sy0 - 2 + row, ux = 2 * sx0 - 2 + 2 * cp;
+            const bool ok = q < 360 && (unsigned)uy < (unsigned)H && (unsigned)ux < (unsigned)H;     // ux even: ux + 1 is inside with it
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const size_t e = ok ? ((size_t)(ib * 3 + c) * H + uy) * H + ux : 0;
+                const float2 g = *reinterpret_cast<const float2*>(a.a0 + e), r = *reinterpret_cast<const float2*>(a.a2 + e);
+                rg[i][c] = ok ? g : make_float2(0.f, 0.f);
+                rr[i][c] = r;
+            }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1174,99 +1223,109 @@ __global__ __launch_bounds__(256, D4B_OCC) void d4_bwd_bf16_kernel(ThinWgradArgs
         }
     };
     // bias gradient = sum of dOut over the tile's own 16 x 32 output pixels (rows / columns 2.. of the staged halo): which
-    // staged elements those are is a per-thread constant, so every thread keeps one running sum per staging slot
-    float bsum[GQ], bmask[GQ];
+    // staged items those are is a per-thread constant
+    float bsum[3] = {0.f, 0.f, 0.f}, bmask[2];
 #pragma unroll
-    for (int i = 0; i < GQ; ++i) {
-        const int q = tid + i * 256, rem = q % 360, hr = rem / 18, hc = 2 * (rem % 18);
-        bmask[i] = (q < G0 / 2 && hr >= 2 && hr < 18 && hc >= 2 && hc < 34) ? 1.f : 0.f;     // both columns of the pair or neither
-        bsum[i] = 0.f;
+    for (int i = 0; i < 2; ++i) {
+        const int q = tid + i * 256, row = q / 18, cp = q % 18;
+        bmask[i] = (q < 360 && row >= 2 && row < 18 && cp >= 1 && cp < 17) ? 1.f : 0.f;
     }
     if (t0 < t1) fetch(t0);
-    const int gsp = tid & 127, ghalf = tid >> 7, gsy = gsp >> 4, gsx = gsp & 15;
-    // transposed-read lane address inside a 4-row block (rows = source pixels)
-    const int g = lane >> 4, h = g >> 1, qrow = (lane & 15) >> 2, cb = 16 * (g & 1) + 4 * (lane & 3);
+    // this lane's source pixel in the two contractions
+    const int dy = 2 * wave + (li >> 4), dx = li & 15;                          // input gradient: wave w = tile rows 2w, 2w+1
+    const __bf16* dsrc = img + ((2 * dy) * D4P_IW + 2 * dx + 2 * lh) * 4;       // + (i*IW + 4*(m&1)) * 4 for k-step m = 2i + (m&1)
+    const int g = lane >> 4, h = g >> 1, qrow = (lane & 15) >> 2, cb = 16 * (g & 1) + 4 * (lane & 3);      // transposed-read lane address
+    const int whalf = wave & 1, wblk = wave >> 1;
     for (int mt = t0; mt < t1; ++mt) {
         const int ib = mt / TPI, t = mt % TPI;
         const int sy0 = (t / (HS / 16)) * 8, sx0 = (t % (HS / 16)) * 16;
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < GQ; ++i) {
-            const int q = tid + i * 256;
-            if (q < G0 / 2) *reinterpret_cast<float2*>(lds_g0 + 2 * q) = rg[i];
-            bsum[i] = fmaf(bmask[i], rg[i].x + rg[i].y, bsum[i]);
-        }
-#pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int q = tid + i * 256;
-            *reinterpret_cast<bf16x8*>(lds_o + (size_t)q * 8) = ro[i];
+            // dOut = d_recon * (1 - recon^2): Tanh backward (vae_nets.py:134), d4_actbwd_kernel's expression
+            float d[3][2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                d[c][0] = rg[i][c].x * (1.f - rr[i][c].x * rr[i][c].x);
+                d[c][1] = rg[i][c].y * (1.f - rr[i][c].y * rr[i][c].y);
+                bsum[c] = fmaf(bmask[i], d[c][0] + d[c][1], bsum[c]);
+            }
+            bf16x8 u;
+            u[0] = (__bf16)d[0][0]; u[1] = (__bf16)d[1][0]; u[2] = (__bf16)d[2][0]; u[3] = (__bf16)0.f;
+            u[4] = (__bf16)d[0][1]; u[5] = (__bf16)d[1][1]; u[6] = (__bf16)d[2][1]; u[7] = (__bf16)0.f;
+            if (q < 360) *reinterpret_cast<bf16x8*>(img + ((q / 18) * D4P_IW + 2 * (q % 18)) * 4) = u;
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<bf16x8*>(lds_o + (size_t)(tid + i * 256) * 8) = ro[i];
         __syncthreads();
         if (mt + 1 < t1) fetch(mt + 1);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int pr = ghalf * 8 + i;                     // wave-uniform
-            if (pr < 15) {
-                const int co = pr / 5, r = pr % 5;
-                const float* p = lds_g0 + co * 720 + (2 * gsy - r + 4) * 36 + 2 * gsx;
-                float cs[6];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float2 u = *reinterpret_cast<const float2*>(p + 2 * j);
-                    const float2 d = *reinterpret_cast<const float2*>(p + 36 + 2 * j);
-                    cs[2 * j] = u.x + d.x; cs[2 * j + 1] = u.y + d.y;
-                }
-                __bf16* gp = lds_G + gsp * GS + r * 15 + co;
-#pragma unroll
-                for (int sI = 0; sI < 5; ++sI) gp[sI * 3] = (__bf16)(cs[4 - sI] + cs[5 - sI]);
-            }
-        }
-        __syncthreads();
-        // dgrad: d_o3[src][ci] = relu'(o3) * sum_k G[src][k] * W4r[k][ci]
+        // input gradient
         f32x16 accd;
 #pragma unroll
         for (int v = 0; v < 16; ++v) accd[v] = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 5; ++kb) {
-            const bf16x8 av = *reinterpret_cast<const bf16x8*>(lds_G + (wave * 32 + li) * GS + 16 * kb + 8 * lh);
-            accd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bwd[kb], accd, 0, 0, 0);
+        for (int m = 0; m < 12; ++m) {
+            const bf16x8 bv = *reinterpret_cast<const bf16x8*>(dsrc + ((m >> 1) * D4P_IW + 4 * (m & 1)) * 4);
+            accd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vw[m], bv, accd, 0, 0, 0);
         }
+        {
+            const int sp = dy * 16 + dx;                     // accumulator column = this lane's source pixel; rows = channels
+            const size_t o = ((size_t)(ib * HS + sy0 + dy) * HS + sx0 + dx) * 32;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int sp = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-            const float x = (float)lds_o[sp * 32 + li] > 0.f ? accd[v] : 0.f;
-            Act<__bf16>::st(a.din, ((size_t)(ib * HS + sy0 + sp / 16) * HS + sx0 + sp % 16) * 32 + li, x);
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int c0 = 8 * q4 + 4 * lh;
+                const bf16x4 ov = *reinterpret_cast<const bf16x4*>(lds_o + sp * 32 + c0);
+                bf16x4 out;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[e] = (float)ov[e] > 0.f ? (__bf16)accd[4 * q4 + e] : (__bf16)0.f;
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.din) + o + c0) = out;
+            }
         }
-        // wgrad: dW[k][ci] += sum over this wave's 32 source pixels of G[src][k] * o3[src][ci]
+        // weight gradient: this wave's three k-blocks over its half of the tile's source pixels
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int row = wave * 32 + 16 * ks + 8 * h + qrow;
+        for (int ks = 0; ks < 4; ++ks) {
+            const int row = 64 * whalf + 16 * ks + 8 * h + qrow;                 // source pixel (tile row row>>4, column row&15); row + 4: same tile row
             const bf16x8 bv = tr_frag(lds_o + row * 32 + cb, lds_o + (row + 4) * 32 + cb);
+            const __bf16* ip = img + ((2 * (row >> 4)) * D4P_IW + 2 * (row & 15)) * 4 + cb;
 #pragma unroll
             for (int mb = 0; mb < 3; ++mb) {
-                const bf16x8 av = tr_frag(lds_G + row * GS + mb * 32 + cb, lds_G + (row + 4) * GS + mb * 32 + cb);
+                const __bf16* rp = ip + (wblk + 2 * mb) * D4P_IW * 4;
+                const bf16x8 av = tr_frag(rp, rp + 8 * 4);                       // source pixel + 4 = 8 image columns on
                 accw[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, accw[mb], 0, 0, 0);
             }
         }
     }
-    thin_slab_out(accw, smem, a.slab + (size_t)blockIdx.x * 96 * 32);
-    // row 76 of the slab (a K-pad row: zeros) carries this workgroup's three bias-gradient partials; the column
-    // reduction of the slabs sums them with the weights' (fixed order), d4_perm_kernel picks them up
-    float bc[3] = {0.f, 0.f, 0.f};
+    // add the two tile halves (waves w, w^1 hold the same k-blocks) and write the slab rows
+    float* red = reinterpret_cast<float*>(smem_raw);
+    __syncthreads();
+    if (whalf == 1) {
 #pragma unroll
-    for (int i = 0; i < GQ; ++i) {
-        const int c = (tid + i * 256) / 360;
+        for (int mb = 0; mb < 3; ++mb)
 #pragma unroll
-        for (int co = 0; co < 3; ++co) bc[co] += c == co ? bsum[i] : 0.f;
+            for (int v = 0; v < 16; ++v) red[((wblk * 3 + mb) * 16 + v) * 64 + lane] = accw[mb][v];
     }
+    __syncthreads();
+    float* slab = a.slab + (size_t)blockIdx.x * D4P_ROW;
+    if (whalf == 0) {
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int k = (wblk + 2 * mb) * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+                if (k != 3) slab[k * 32 + li] = accw[mb][v] + red[((wblk * 3 + mb) * 16 + v) * 64 + lane];
+            }
+    }
+    // row 3 of the slab (k = (0, 0, co = 3): a zero row) carries this workgroup's three bias-gradient partials; the column
+    // reduction of the slabs sums them with the weights' (fixed order), d4_perm_kernel picks them up
     __shared__ float bred[4][3];
 #pragma unroll
-    for (int co = 0; co < 3; ++co) { const float v = wave_sum(bc[co]); if (lane == 0) bred[wave][co] = v; }
-    __syncthreads();                       // also: wave 0 has written the slab rows
-    if (tid < 3) a.slab[(size_t)blockIdx.x * 96 * 32 + 76 * 32 + tid] = (bred[0][tid] + bred[1][tid]) + (bred[2][tid] + bred[3][tid]);
+    for (int co = 0; co < 3; ++co) { const float v = wave_sum(bsum[co]); if (lane == 0) bred[wave][co] = v; }
+    __syncthreads();
+    if (tid < 32) slab[3 * 32 + tid] = tid < 3 ? (bred[0][tid] + bred[1][tid]) + (bred[2][tid] + bred[3][tid]) : 0.f;
 }
-static constexpr int D4_BWD_BF16_SMEM = 3 * 720 * 4 + 128 * 32 * 2 + (128 * 88 + 16) * 2;
-static_assert(D4_BWD_BF16_SMEM >= 3 * 3 * 1024 * 4, "thin_slab_out reuses the staging buffers");
+static constexpr int D4_BWD_BF16_SMEM = 2 * 3 * 16 * 64 * 4;          // the final half-add of the accumulators (24 KB) exceeds the staging buffers (14.6 KB)
+static_assert(D4_BWD_BF16_SMEM >= (20 * D4P_IW * 4 + 128 * 32) * 2, "staging buffers");
 
 static constexpr int D4_BWD_SMEM = (3 * 720 + 128 * 32 + 128 * 77 + 32 + 76 * 32) * 4;
 
@@ -1277,13 +1336,14 @@ static int d4_splits(int width, int B, int* tps, bool bf16io = false) {
 int64_t d4_bwd_ws_floats(int width, int B) {
     int tps;
     const int64_t S = thin_splits(B * (width / 16) * (width / 32), &tps, 1024);        // upper bound of the split counts used
-    return S * 3072 + align_up((int64_t)B * 3, 64) + 3072 + col_reduce_ws_floats(3072);
+    const int64_t row = D4P_ROW;                                                        // bf16 mode's slab row (fp32: 3072)
+    return S * row + align_up((int64_t)B * 3, 64) + row + col_reduce_ws_floats((int)row);
 }
 
 int launch_d4_fwd(int width, int B, const float* in, const float* w, const float* bias, float* recon, hipStream_t st, bool bf16io) {
-    // persistent: bf16 mode 49 KB of LDS -> three workgroups per CU; fp32 66 KB -> two; each loops over its share of the 16x16 tiles
-    const int want = (bf16io ? 3 : 2) * cvae_num_cus();
-    const int tiles = B * (width / 16) * (width / 16), grid = tiles < want ? tiles : want;
+    // persistent: bf16 mode 4 workgroups per CU (18 KB of LDS, 16 x 32-output tiles); fp32 66 KB -> two (16 x 16 tiles); each loops over its share
+    const int want = (bf16io ? 4 : 2) * cvae_num_cus();
+    const int tiles = bf16io ? B * (width / 16) * (width / 32) : B * (width / 16) * (width / 16), grid = tiles < want ? tiles : want;
     cvae_probe_begin(st);
     if (width == 64 && bf16io) hipLaunchKernelGGL(d4_fwd_bf16_kernel<64>, dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
     else if (width == 128 && bf16io) hipLaunchKernelGGL(d4_fwd_bf16_kernel<128>, dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
@@ -1302,7 +1362,8 @@ int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const
     int tps;
     const int tiles = B * (width / 16) * (width / 32);
     const int S = d4_splits(width, B, &tps, bf16io);
-    float* plane_sums = ws + (size_t)S * 3072;
+    const int row = bf16io ? D4P_ROW : 3072;                  // floats of one workgroup's slab
+    float* plane_sums = ws + (size_t)S * row;
     if (!bf16io) {      // fp32: Tanh backward as its own pass (writes dOut); bf16 mode applies it while the backward kernel stages
         hipLaunchKernelGGL(d4_actbwd_kernel, dim3(B * 3), dim3(256), 0, st, d_recon, recon, dout, plane_sums, width * width);
         CVAE_CHECK_LAUNCH();
@@ -1318,7 +1379,7 @@ int launch_d4_bwd(int width, int B, const float* o3, const float* d_recon, const
     cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();
     float* red = plane_sums + align_up((int64_t)B * 3, 64);
-    { int rc = launch_col_reduce(ws, S, 3072, 3072, red, red + 3072, st); if (rc) return rc; }
+    { int rc = launch_col_reduce(ws, S, row, row, red, red + row, st); if (rc) return rc; }
     hipLaunchKernelGGL(d4_perm_kernel, dim3(cdiv(2400, 256) + 1), dim3(256), 0, st, red, dw, bf16io ? nullptr : plane_sums, db, B);
     CVAE_CHECK_LAUNCH();
     return 0;

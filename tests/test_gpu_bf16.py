@@ -462,8 +462,21 @@ def test_bf16_kernels_exact_on_their_stored_operands():
     o3 = act("o3", 32, 32)
     up3 = F.interpolate(o3, scale_factor=2, mode="nearest")
     w4, b4 = ref["decoder.model.12.weight"], ref["decoder.model.12.bias"]
-    recon = torch.tanh(F.conv2d(up3, bf(w4), b4, padding=2))
-    close(tr.recon[:B].cpu(), recon, "recon", 1e-4)
+    # the forward kernel contracts the PHASE-COLLAPSED 3x3 weights (sums of the 5x5 taps that reach one source pixel from
+    # one output phase), summed in fp32 and rounded to bf16 once: reproduce exactly that
+    taps = {0: [[0, 1], [2, 3], [4]], 1: [[0], [1, 2], [3, 4]]}
+    pre = torch.empty(B, 3, 64, 64)
+    for py in (0, 1):
+        for px in (0, 1):
+            wc = torch.zeros(3, 32, 3, 3)
+            for ta in range(3):
+                for tb in range(3):
+                    for r in taps[py][ta]:
+                        for s5 in taps[px][tb]:
+                            wc[:, :, ta, tb] += w4[:, :, r, s5]
+            pre[:, :, py::2, px::2] = F.conv2d(o3, bf(wc), b4, padding=1)
+    close(tr.recon[:B].cpu(), torch.tanh(pre), "recon", 1e-4)
+    close(tr.recon[:B].cpu(), torch.tanh(F.conv2d(up3, bf(w4), b4, padding=2)), "recon vs 5x5 weights", 2.0 ** -6)
     dout = (tr.d_recon[:B] * (1.0 - tr.recon[:B] ** 2)).cpu()
     dw4, db4 = wgrad(up3, dout)
     close(grd["decoder.model.12.weight"], dw4, "dW dec4", 1e-2)         # the 2x2-block sums G are rounded to bf16

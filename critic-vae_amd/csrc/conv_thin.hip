@@ -1161,6 +1161,12 @@ __global__ __launch_bounds__(256, THIN_F32_OCC) void d4_bwd_kernel(ThinWgradArgs
 #ifndef D4B_OCC
 #define D4B_OCC 2          // workgroups per CU of the bf16 D4 backward (splits = D4B_OCC * CUs)
 #endif
+#ifndef D4B_VWLDS
+#define D4B_VWLDS 0
+#endif
+#ifndef D4B_ACC2
+#define D4B_ACC2 1          // input gradient as two chains of 6 MFMAs (119 -> 116 us); D4B_VWLDS=1 (weights re-read from LDS, 3 workgroups per CU): 134-142 us
+#endif
 static constexpr int D4P_ROW = 192 * 32;
 static constexpr int D4P_IW = 40;                 // image row stride in pixels (36 staged + 4 zero columns for the 8-wide runs)
 template <int H>
@@ -1170,9 +1176,12 @@ __global__ __launch_bounds__(256, D4B_OCC) void d4_bwd_bf16_kernel(ThinWgradArgs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* img = reinterpret_cast<__bf16*>(smem_raw);                          // [20 rows][40 columns][4]
     __bf16* lds_o = img + IMG;                                                  // o3 tile [128][32]
+#if D4B_VWLDS
+    __shared__ __attribute__((aligned(16))) __bf16 lds_v[12 * 64 * 8];          // the input gradient's weight fragments [k-step][lane]
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     // collapsed weights as A fragments of the input gradient: row ci = li, k-step m covers k = 16m + 8lh + jj
-    bf16x8 vw[12];
+    bf16x8 vw[D4B_VWLDS ? 1 : 12];
     {
         static_assert(12 * 32 * 2 * 8 <= IMG + 128 * 32, "weight fragments fit in the staging buffers");
         for (int q = tid; q < 192 * 32; q += 256) {
@@ -1184,8 +1193,12 @@ __global__ __launch_bounds__(256, D4B_OCC) void d4_bwd_bf16_kernel(ThinWgradArgs
             img[(((k >> 4) * 32 + ci) * 2 + ((k >> 3) & 1)) * 8 + (k & 7)] = (__bf16)acc;
         }
         __syncthreads();
+#if D4B_VWLDS
+        for (int q = tid; q < 12 * 64; q += 256) reinterpret_cast<bf16x8*>(lds_v)[q] = reinterpret_cast<const bf16x8*>(img)[q];
+#else
 #pragma unroll
         for (int m = 0; m < 12; ++m) vw[m] = *reinterpret_cast<const bf16x8*>(img + ((m * 32 + li) * 2 + lh) * 8);
+#endif
         __syncthreads();
     }
     for (int q = tid; q < 20 * 2; q += 256)       // columns 36..39 of every image row stay zero (16 elements = two 16-byte units per row)
@@ -1261,13 +1274,23 @@ __global__ __launch_bounds__(256, D4B_OCC) void d4_bwd_bf16_kernel(ThinWgradArgs
         __syncthreads();
         if (mt + 1 < t1) fetch(mt + 1);
         // input gradient
-        f32x16 accd;
+        f32x16 accd, accd2;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) accd[v] = 0.f;
+        for (int v = 0; v < 16; ++v) { accd[v] = 0.f; accd2[v] = 0.f; }
 #pragma unroll
         for (int m = 0; m < 12; ++m) {
             const bf16x8 bv = *reinterpret_cast<const bf16x8*>(dsrc + ((m >> 1) * D4P_IW + 4 * (m & 1)) * 4);
-            accd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vw[m], bv, accd, 0, 0, 0);
+#if D4B_VWLDS
+            const bf16x8 av = *reinterpret_cast<const bf16x8*>(lds_v + ((m * 32 + li) * 2 + lh) * 8);
+#else
+            const bf16x8 av = vw[m];
+#endif
+            if (D4B_ACC2 && (m & 1)) accd2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, accd2, 0, 0, 0);      // two chains of 6
+            else accd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, accd, 0, 0, 0);
+        }
+        if (D4B_ACC2) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) accd[v] += accd2[v];
         }
         {
             const int sp = dy * 16 + dx;                     // accumulator column = this lane's source pixel; rows = channels

@@ -62,6 +62,9 @@ enum { MODE_STD = 0, MODE_UP_FWD = 1, MODE_UP_DGRAD = 2 };
 #ifndef BF16_MT
 #define BF16_MT 2          // 128-pixel tiles per workgroup of the plain bf16 kernels (1 = round-1 structure)
 #endif
+#ifndef BF16_NT128
+#define BF16_NT128 0
+#endif
 #ifndef BF16_WDMA
 #define BF16_WDMA 0        // 1 (experiment, round 3): weight slabs travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) into a double
 #endif                     // buffer, one barrier per K stage.  Correct (tests green) but SLOWER on the MI355X: E2 fwd 227 -> 237 us, E2 dgrad
@@ -513,8 +516,13 @@ int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, c
     if (width == 64) {
         switch (layer) {
             case 1: return run_bf16<32, 64, 32, 64, EPI_BIAS_BNSTAT>(a, st);
+#if BF16_NT128       // experiment: 128 output channels per workgroup (8 accumulator tiles per wave, 0.75 LDS fragment reads per MFMA)
+            case 2: if (ns == 1) return run_bf16<64, 128, 16, 128, EPI_BIAS_BNSTAT>(a, st); else return run_bf16<64, 128, 16, 64, EPI_BIAS_BNSTAT>(a, st);
+            case 3: if (ns == 1) return run_bf16<128, 256, 8, 128, EPI_BIAS_BNSTAT>(a, st); else return run_bf16<128, 256, 8, 64, EPI_BIAS_BNSTAT>(a, st);
+#else
             case 2: return run_bf16<64, 128, 16, 64, EPI_BIAS_BNSTAT>(a, st);
             case 3: return run_bf16<128, 256, 8, 64, EPI_BIAS_BNSTAT>(a, st);
+#endif
             case 4: {     // 4x4 images: split-K x4 over the channel chunks so that 256 workgroups exist at B=256
                 const int64_t slice = (int64_t)B * 16 * 128;
                 a.out = ws; a.sliceFloats = slice;

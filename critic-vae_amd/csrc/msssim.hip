@@ -130,6 +130,26 @@ __device__ __forceinline__ void ms_point2(f32x2 mu1, f32x2 mu2, f32x2 a11, f32x2
     *dm = m; *d11 = e11; *d12 = e12;
 }
 
+// Sum over the SEG (4, 16 or 64) lanes of a lane's aligned segment with DPP row operations (6 VALU instructions per value
+// for the whole wave; the shuffle form costs ~6 per STEP); the result is valid in the LAST lane of each segment for
+// SEG = 64 and in every lane of the segment otherwise
+template <int SEG>
+__device__ __forceinline__ float seg_sum_dpp(float v) {
+#define MS_DPP(ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+    v += MS_DPP(0xB1, 0xf);       // quad_perm [1,0,3,2]
+    v += MS_DPP(0x4E, 0xf);       // quad_perm [2,3,0,1]: every lane holds its quad's sum
+    if constexpr (SEG >= 16) {
+        v += MS_DPP(0x141, 0xf);  // row_half_mirror
+        v += MS_DPP(0x140, 0xf);  // row_mirror: every lane holds its row's sum
+    }
+    if constexpr (SEG == 64) {
+        v += MS_DPP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+        v += MS_DPP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    }
+#undef MS_DPP
+    return v;
+}
+
 template <int S>
 __global__ __launch_bounds__(MS_NT, MS_NT / 128) void msssim_fwd_kernel(MsFwdArgs a) {
     using T = MsT<S>;
@@ -242,11 +262,12 @@ __global__ __launch_bounds__(MS_NT, MS_NT / 128) void msssim_fwd_kernel(MsFwdArg
             // rows it belongs to and dropped; an output row is finished — SSIM point, derivative maps — as soon as its
             // eleventh tap is in, so only the accumulators + one staged row are live.  Every output still sums its taps
             // in the order t = 0..10.
+            const float* pA = tA + rb * 2; const float* pB = tB + rb * 2; const float* pC = tC + rb;      // rows at immediate offsets
 #pragma unroll
             for (int i = 0; i < VR + 10; ++i) {
-                const f32x4 vA = *reinterpret_cast<const f32x4*>(tA + (rb + i * T::MCP) * 2);
-                const f32x4 vB = *reinterpret_cast<const f32x4*>(tB + (rb + i * T::MCP) * 2);
-                const f32x2 vC = *reinterpret_cast<const f32x2*>(tC + rb + i * T::MCP);
+                const f32x4 vA = *reinterpret_cast<const f32x4*>(pA + i * (T::MCP * 2));
+                const f32x4 vB = *reinterpret_cast<const f32x4*>(pB + i * (T::MCP * 2));
+                const f32x2 vC = *reinterpret_cast<const f32x2*>(pC + i * T::MCP);
 #pragma unroll
                 for (int o = 0; o < VR; ++o) {
                     if (i - o < 0 || i - o > 10) continue;
@@ -277,8 +298,8 @@ __global__ __launch_bounds__(MS_NT, MS_NT / 128) void msssim_fwd_kernel(MsFwdArg
             }
         }
     }
-    s_ssim = wave_sum(s_ssim); s_cs = wave_sum(s_cs);
-    if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = s_ssim; red[(threadIdx.x >> 6) * 2 + 1] = s_cs; }
+    s_ssim = seg_sum_dpp<64>(s_ssim); s_cs = seg_sum_dpp<64>(s_cs);          // totals in lane 63
+    if ((threadIdx.x & 63) == 63) { red[(threadIdx.x >> 6) * 2] = s_ssim; red[(threadIdx.x >> 6) * 2 + 1] = s_cs; }
     __syncthreads();
     if (threadIdx.x == 0) {
         float t0 = 0.f, t1 = 0.f;
@@ -348,9 +369,10 @@ __global__ __launch_bounds__(MS_NT, MS_NT / 128) void msssim_fwd_kernel(MsFwdArg
                 // every output still sums its taps in the order t = 0..10
 #pragma unroll
                 for (int o = 0; o < VR; ++o) { f01[o][0] = splat2(0.f); f01[o][1] = splat2(0.f); }
+                const float* pg = gA + (r * T::CS + c) * 2;
 #pragma unroll
                 for (int i = 0; i < VR + 10; ++i) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(gA + ((r + i) * T::CS + c) * 2);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(pg + i * (T::CS * 2));
 #pragma unroll
                     for (int o = 0; o < VR; ++o) {
                         if (i - o < 0 || i - o > 10) continue;
@@ -363,9 +385,10 @@ __global__ __launch_bounds__(MS_NT, MS_NT / 128) void msssim_fwd_kernel(MsFwdArg
             {
 #pragma unroll
                 for (int o = 0; o < VR; ++o) f2[o] = splat2(0.f);
+                const float* pg = gC + r * T::CS + c;
 #pragma unroll
                 for (int i = 0; i < VR + 10; ++i) {
-                    const f32x2 v = *reinterpret_cast<const f32x2*>(gC + (r + i) * T::CS + c);
+                    const f32x2 v = *reinterpret_cast<const f32x2*>(pg + i * T::CS);
 #pragma unroll
                     for (int o = 0; o < VR; ++o) {
                         if (i - o < 0 || i - o > 10) continue;
@@ -415,26 +438,6 @@ struct MsP {
     static_assert((DAS / 2) % 2 == 1 && DCS % 4 == 0 && TAS % 2 == 0 && PLANE % 4 == 0, "strides");
     static_assert(SMEM <= 160 * 1024 - 256, "LDS");
 };
-
-// Sum over the SEG (4, 16 or 64) lanes of a lane's aligned segment with DPP row operations (6 VALU instructions per value
-// for the whole wave; the shuffle form costs ~6 per STEP); the result is valid in the LAST lane of each segment for
-// SEG = 64 and in every lane of the segment otherwise
-template <int SEG>
-__device__ __forceinline__ float seg_sum_dpp(float v) {
-#define MS_DPP(ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
-    v += MS_DPP(0xB1, 0xf);       // quad_perm [1,0,3,2]
-    v += MS_DPP(0x4E, 0xf);       // quad_perm [2,3,0,1]: every lane holds its quad's sum
-    if constexpr (SEG >= 16) {
-        v += MS_DPP(0x141, 0xf);  // row_half_mirror
-        v += MS_DPP(0x140, 0xf);  // row_mirror: every lane holds its row's sum
-    }
-    if constexpr (SEG == 64) {
-        v += MS_DPP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
-        v += MS_DPP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3: lane 63 holds the total
-    }
-#undef MS_DPP
-    return v;
-}
 
 #ifdef MS_TIMING      // experiment builds only (profiles/experiments/variant.sh ... -DMS_TIMING): phase timestamps of a few waves
 __device__ long long ms_dbg[4 * 2 * 16];

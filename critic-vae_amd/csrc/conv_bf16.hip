@@ -65,6 +65,9 @@ enum { MODE_STD = 0, MODE_UP_FWD = 1, MODE_UP_DGRAD = 2 };
 #ifndef BF16_NT128
 #define BF16_NT128 0
 #endif
+#ifndef BF16_WDB
+#define BF16_WDB 0         // 1 (experiment, round 3): weight slabs double-buffered in LDS, staged between the MFMAs (see the stage loop): slower
+#endif
 #ifndef BF16_WDMA
 #define BF16_WDMA 0        // 1 (experiment, round 3): weight slabs travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) into a double
 #endif                     // buffer, one barrier per K stage.  Correct (tests green) but SLOWER on the MI355X: E2 fwd 227 -> 237 us, E2 dgrad
@@ -94,6 +97,19 @@ template <int H, int OCT> struct Bf16Geom {
 // MT = 128-pixel tiles per workgroup (bf16 mode: 2): one weight slab staged into LDS — and one weight fragment read
 // from LDS — serves MT times as many MFMAs; the K chunk shrinks to 32 channels so that the LDS footprint (and with
 // it the number of resident workgroups) stays where it was.
+#ifndef CONV_EXPERIMENT
+#define CONV_EXPERIMENT 0
+#endif
+#ifdef CONV_TIMING     // experiment builds only: where a wave of ONE instantiation (-DCONV_TIMING_KCH/NCH/H) spends its stages
+__device__ long long conv_dbg[16 * 4 * 10];
+extern "C" int cvae_conv_dbg_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(conv_dbg), sizeof(conv_dbg)); }
+#define CT_ON (KCH == CONV_TIMING_KCH && NCH == CONV_TIMING_NCH && H == CONV_TIMING_H && NS == 1 && MODE == MODE_STD)
+#define CT_STAMP(v) do { if (CT_ON) v = clock64(); } while (0)
+#else
+#define CT_ON false
+#define CT_STAMP(v)
+#endif
+
 template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT, int KS = 5, int MODE = MODE_STD, int NS = 1, int DMAX = 4, int MT = 1>
 __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     using T = Tile<H>;
@@ -109,6 +125,12 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     // registers, no ds_write_b128 (13 issue cycles each), and with two slab buffers ONE barrier per stage: the slab's unit
     // order in LDS is the staging thread order (unit q <- thread q), which is exactly the DMA's "wave base + lane * 16".
     constexpr bool WDMA = NS == 1 && BF16_WDMA != 0;
+    // WDB (bf16 mode, round 3): two slab buffers, the slab of stage st+1 is written (registers -> ds_write_b128) at the TOP of stage
+    // st, so the stores drain under this stage's MFMAs and the barrier at the top of stage st+1 both frees the other buffer and
+    // publishes the slab: ONE barrier per stage instead of two (a second one only where a new input chunk is staged, every fifth
+    // stage).  Stage timing of the two-barrier loop (profiles/experiments/conv_timing.py): 1.1-1.6 k cycles per stage between two
+    // MFMA phases of 1.5 k, most of it the store drain in front of the second barrier.
+    constexpr bool WDB = NS == 1 && BF16_WDB != 0 && !WDMA;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);      // [tile][split][octet][halo pixel]
     bf16x8* lds_w = lds_a + MT * NS * A_UNITS;                 // [buffer (WDMA: 2)][split][tap][kb][half][n]
@@ -169,13 +191,13 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
                                                  (__attribute__((address_space(3))) void*)(lds_w + buf * W_UNITS + i * 256 + wave * 64), 16, 0, 0);
         }
     };
-    auto store_w = [&]() {
+    auto store_w = [&](int buf = 0) {           // buf: WDB only (NS == 1)
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int q = tid + i * 256;
             if (W_UNITS % 256 == 0 || q < W_UNITS) {
 #pragma unroll
-                for (int sp = 0; sp < NS; ++sp) lds_w[sp * W_UNITS + q] = wreg[sp * WPT + i];
+                for (int sp = 0; sp < NS; ++sp) lds_w[(buf + sp) * W_UNITS + q] = wreg[sp * WPT + i];
             }
         }
     };
@@ -262,36 +284,102 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     const int st0 = blockIdx.z * NST, st1 = st0 + NST;
     if constexpr (WDMA) dma_w(st0, 0); else load_w(st0);
     load_input(st0 / KS);
+    if constexpr (WDB) {                       // prologue: slab st0 -> buffer 0, slab st0+1 -> registers (both loads in flight together)
+        bf16x8 wnext[WPT];
+        {
+            const int sn = st0 + 1 < st1 ? st0 + 1 : st0;
+            const bf16x8* wst = a.wp + (size_t)((sn % KS) * KS * (KCH / 16) + (sn / KS) * KB) * 2 * NCH;
+#pragma unroll
+            for (int i = 0; i < WPT; ++i)
+                if (W_UNITS % 256 == 0 || tid + i * 256 < W_UNITS) wnext[i] = wst[wbase[i]];
+        }
+        store_w(0);
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) wreg[i] = wnext[i];
+    }
+    [[maybe_unused]] long long ct0 = 0, ct1 = 0, ct2 = 0, ct3 = 0, ct4 = 0, cd[6] = {0, 0, 0, 0, 0, 0}, ctb = 0, cta = 0, ctw = 0;      // CONV_TIMING builds
+    CT_STAMP(ctb);
     for (int st = st0; st < st1; ++st) {
         const int r = st % KS;
         int wbuf = 0;
+        CT_STAMP(ct0);
         if constexpr (WDMA) {
             wbuf = (st - st0) & 1;
             if (r == 0) {
                 __syncthreads();                   // chunk boundary: everyone finished reading the previous chunk's input tiles
                 store_input();
             }
+            CT_STAMP(ct1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of slab st has landed (and the next chunk's inputs)
+            CT_STAMP(cta); CT_STAMP(ctw);
             __syncthreads();                       // slab st (and the input tiles) visible to all; everyone is done with slab st-1
+            CT_STAMP(ct2);
             if (r == 0 && st + KS < st1) load_input(st / KS + 1);
             if (st + 1 < st1) dma_w(st + 1, wbuf ^ 1);            // lands in the buffer stage st-1 read, while this stage computes
+            CT_STAMP(ct3);
+        } else if constexpr (WDB) {
+            wbuf = (st - st0) & 1;
+            __syncthreads();                   // everyone finished reading stage st-1 (input tiles, slab buffer wbuf^1); slab st is visible
+            CT_STAMP(ct1);
+            CT_STAMP(cta); CT_STAMP(ctw);
+            if (r == 0) {                      // chunk boundary: new input tiles, visible behind a second barrier
+                store_input();
+                if (st + KS < st1) load_input(st / KS + 1);
+                CT_STAMP(ct2);
+                __syncthreads();
+            } else CT_STAMP(ct2);
+            CT_STAMP(ct3);
         } else {
         __syncthreads();                       // everyone finished reading the previous stage
+        CT_STAMP(ct1);
         if (r == 0) store_input();
+        CT_STAMP(cta);
+#if CONV_EXPERIMENT == 1          // timing experiment (wrong results): weights staged at the first stage only
+        if (st == st0) store_w();
+#elif CONV_EXPERIMENT == 2        // timing experiment (wrong results): no second barrier
         store_w();
+#else
+        store_w();
+#endif
+        CT_STAMP(ctw);
         // issue order: vmcnt retires in order, so the (older) halo loads must not sit between a weight
         // load and the store_w that waits for it (see conv_mfma.hip)
         if (r == 0 && st + KS < st1) load_input(st / KS + 1);
+#if CONV_EXPERIMENT != 1
         if (st + 1 < st1) load_w(st + 1);      // in flight while this stage computes
+#endif
+        CT_STAMP(ct2);
+#if CONV_EXPERIMENT != 2
         __syncthreads();
+#endif
+        CT_STAMP(ct3);
         }
         const bf16x8* ap = lds_a + lh * PSP + aPix + (r + OFF) * T::HTW + OFF;
         const bf16x8* bp = lds_w + wbuf * W_UNITS + lh * NT + li;
+        // WDB: slab st+1 goes to the other buffer ONE 16-byte store per tap, between the MFMAs of this stage (a burst of stores
+        // in front of the loop makes the loop's first fragment reads wait for the whole burst: LDS operations of a wave complete
+        // in order), and each staging register is reloaded with its unit of slab st+2 right behind its store — a full stage
+        // ahead of its next use.  Past the last stage both touch valid but unused locations (no branch in the loop).
+        [[maybe_unused]] const bf16x8* wst2 = nullptr;
+        if constexpr (WDB) {
+            const int sn = st + 2 < st1 ? st + 2 : st1 - 1;
+            wst2 = a.wp + (size_t)((sn % KS) * KS * (KCH / 16) + (sn / KS) * KB) * 2 * NCH;
+        }
         if (NS == 1) __builtin_amdgcn_iglp_opt(0);         // interleave the LDS fragment reads with the MFMAs
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
+                if constexpr (WDB) {
+                    if (kb == 0) {
+#pragma unroll
+                        for (int i = 0; i < WPT; ++i)
+                            if (i % KS == s && (W_UNITS % 256 == 0 || tid + i * 256 < W_UNITS)) {
+                                lds_w[(wbuf ^ 1) * W_UNITS + tid + i * 256] = wreg[i];
+                                wreg[i] = wst2[wbase[i]];
+                            }
+                    }
+                }
                 if (NS == 1) {
                     bf16x8 bv[NB];
 #pragma unroll
@@ -324,9 +412,19 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
                     }
                 }
             }
+#ifdef CONV_TIMING
+        if (CT_ON) {
+            __builtin_amdgcn_sched_barrier(0);
+            long long te = clock64();
+            cd[0] += ct1 - ct0; cd[1] += ct2 - ct1; cd[2] += ct3 - ct2; cd[3] += te - ct3; cd[4] += cta - ct1; cd[5] += ctw - cta;
+        }
+#endif
     }
     float* smem = reinterpret_cast<float*>(smem_raw);
     const int numTiles = cdiv(a.B, T::IMGS) * T::TILES_PER_IMG;
+#ifdef CONV_TIMING
+    if (CT_ON) { CT_STAMP(ct4); cd[0] += 0; }
+#endif
 #pragma unroll
     for (int tl = 0; tl < MT; ++tl) {
     const int mt = mt0 + tl, img0 = img0v[tl], ty0 = ty0v[tl], tx0 = tx0v[tl];
@@ -399,6 +497,13 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
         else epilogue_store<H, NT, NCH, EPI>(acc[tl], a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0, numTiles);
     }
     }
+#ifdef CONV_TIMING
+    if (CT_ON && (blockIdx.x & 63) == 0 && blockIdx.x < 1024 && blockIdx.y == 0 && lane == 0) {
+        long long tend = clock64();
+        long long* o = conv_dbg + ((blockIdx.x >> 6) * 4 + wave) * 10;
+        o[0] = cd[0]; o[1] = cd[1]; o[2] = cd[2]; o[3] = cd[3]; o[4] = ct4 - ctb; o[5] = tend - ct4; o[6] = st1 - st0; o[7] = tend - ctb; o[8] = cd[4]; o[9] = cd[5];
+    }
+#endif
 }
 
 // ---- weight packing into bf16 units: unit ((tap*(K/16) + kb)*2 + half)*N + n holds k = kb*16 + half*8 .. +7.
@@ -485,7 +590,7 @@ template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT = 1, int KS = 5, 
 static int run_bf16_ns(const ConvBf16Args& a, hipStream_t st) {
     using T = Tile<H>;
     constexpr int KCB = Bf16Chunk<KCH, NS, MT>::KCB;
-    constexpr int WBUF = (NS == 1 && BF16_WDMA != 0) ? 2 : 1;          // LDS-DMA weight slabs are double-buffered
+    constexpr int WBUF = (NS == 1 && (BF16_WDMA != 0 || BF16_WDB != 0)) ? 2 : 1;          // double-buffered weight slabs
     constexpr int STAGE = (MT * NS * (KCB / 8) * Bf16Geom<H, KCB / 8>::PSP + WBUF * NS * KS * (KCB / 16) * 2 * NT) * 16;
     constexpr int EPI_BYTES = (8 * NT > 4 * 32 * 36 ? 8 * NT : 4 * 32 * 36) * 4;
     constexpr int SMEM = STAGE > EPI_BYTES ? STAGE : EPI_BYTES;

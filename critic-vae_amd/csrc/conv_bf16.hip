@@ -654,7 +654,9 @@ int launch_conv_dgrad_bf16(int layer, int width, int ns, int B, const float* dou
         switch (layer) {
             case 1: return run_bf16<64, 32, 32, 32, EPI_PLAIN>(a, st);
             case 2: return run_bf16<128, 64, 16, 64, EPI_PLAIN>(a, st);
-            case 3: return run_bf16<256, 128, 8, 32, EPI_PLAIN>(a, st);
+            // bf16: 64 output channels per workgroup (1.0 LDS fragment reads per MFMA; with 32 the MFMA phase of a stage ran at 40 % of
+            // the MFMA rate, LDS-bound at 1.5 reads per MFMA and 3 waves per SIMD: 207 -> 185 us at B = 2048); the emulation modes keep 32
+            case 3: if (ns == 1) return run_bf16<256, 128, 8, 64, EPI_PLAIN>(a, st); else return run_bf16<256, 128, 8, 32, EPI_PLAIN>(a, st);
             case 4: {
                 const int64_t slice = (int64_t)B * 16 * 256;
                 a.out = ws; a.sliceFloats = slice;

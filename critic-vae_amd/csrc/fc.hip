@@ -285,10 +285,10 @@ __global__ __launch_bounds__(256) void fc_bwd_dw_kernel(const float* __restrict_
 
 // precision mode 1: the two batch-contracted weight gradients  C[m][n] = sum_b A[b][m] * Bm[b][n]  on the bf16 MFMA
 // (fc_mu|fc_var: A = flat (bf16 activations), Bm = dml;  decoder_input: A = [zcat | 1] (the ones column yields the
-// bias gradient), Bm = dh (bf16)).  Both inputs are row-major in b, i.e. the contraction index is the ROW: tiles of 64
+// bias gradient), Bm = dh (bf16)).  Both inputs are row-major in b, i.e. the contraction index is the ROW: tiles of BG_BT
 // images are copied to LDS as they are (fp32 inputs rounded to bf16 on the way) and both MFMA operands are transposed
 // LDS reads (ds_read_b64_tr_b16).  Workgroup = (32*MBLK) x (32*NBLK) outputs over the whole batch (no split-K slabs);
-// wave w contracts images 16w..16w+15 of every 64-image tile, the four partial tiles are summed through LDS.
+// wave w contracts images [w*BG_BT/4, (w+1)*BG_BT/4) of every tile, the four partial tiles are summed through LDS.
 struct BGemmArgs {
     const float* A; const float* Bm;      // opaque: bf16 or fp32 per template flags
     int lda, ldb;                         // row strides in elements
@@ -299,11 +299,14 @@ struct BGemmArgs {
     int B;
 };
 
+// BT images per LDS tile: each tile costs two workgroup barriers, and at 64 images a wave had two MFMAs between them (41 / 35 us
+// at B = 2048 for 1 GFLOP); 256 images per tile = 4 k-steps per wave and tile
+static constexpr int BG_BT = 256;
 template <int MBLK, int NBLK, bool A_F32, bool B_F32>
 __global__ __launch_bounds__(256) void bgemm_tr_kernel(BGemmArgs a) {
-    constexpr int MC = 32 * MBLK, NC = 32 * NBLK;
-    __shared__ __attribute__((aligned(16))) __bf16 lds_a[64 * MC];
-    __shared__ __attribute__((aligned(16))) __bf16 lds_b[64 * NC];
+    constexpr int MC = 32 * MBLK, NC = 32 * NBLK, BT = BG_BT;
+    __shared__ __attribute__((aligned(16))) __bf16 lds_a[BT * MC];
+    __shared__ __attribute__((aligned(16))) __bf16 lds_b[BT * NC];
     __shared__ float red[3 * 1024];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int g = lane >> 4, h = g >> 1, qrow = (lane & 15) >> 2, cb = 16 * (g & 1) + 4 * (lane & 3);
@@ -315,8 +318,8 @@ __global__ __launch_bounds__(256) void bgemm_tr_kernel(BGemmArgs a) {
         for (int j = 0; j < NBLK; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-    constexpr int AU = A_F32 ? (64 * MC) / 256 : (64 * MC / 8 + 255) / 256;        // per-thread staging items
-    constexpr int BU = B_F32 ? (64 * NC / 4) / 256 : (64 * NC / 8 + 255) / 256;
+    constexpr int AU = A_F32 ? (BT * MC) / 256 : (BT * MC / 8 + 255) / 256;        // per-thread staging items
+    constexpr int BU = B_F32 ? (BT * NC / 4) / 256 : (BT * NC / 8 + 255) / 256;
     float ra32[A_F32 ? AU : 1];
     bf16x8 ra16[A_F32 ? 1 : AU];
     f32x4 rb32[B_F32 ? BU : 1];
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(256) void bgemm_tr_kernel(BGemmArgs a) {
 #pragma unroll
             for (int i = 0; i < AU; ++i) {
                 const int q = tid + i * 256, r = q / (MC / 8), c8 = q % (MC / 8), b = b0 + r;
-                const bool ok = (64 * MC / 8) % 256 == 0 || q < 64 * MC / 8;
+                const bool ok = (BT * MC / 8) % 256 == 0 || q < BT * MC / 8;
                 const bool inb = ok && b < a.B;
                 const bf16x8 l = Act<__bf16>::ld8(a.A, inb ? (size_t)b * a.lda + m0 + c8 * 8 : 0);
                 ra16[i] = inb ? l : zero8;
@@ -355,14 +358,14 @@ __global__ __launch_bounds__(256) void bgemm_tr_kernel(BGemmArgs a) {
 #pragma unroll
             for (int i = 0; i < BU; ++i) {
                 const int q = tid + i * 256, r = q / (NC / 8), c8 = q % (NC / 8), b = b0 + r;
-                const bool ok = ((64 * NC / 8) % 256 == 0 || q < 64 * NC / 8) && b < a.B;
+                const bool ok = ((BT * NC / 8) % 256 == 0 || q < BT * NC / 8) && b < a.B;
                 const bf16x8 l = Act<__bf16>::ld8(a.Bm, ok ? (size_t)b * a.ldb + n0 + c8 * 8 : 0);
                 rb16[i] = ok ? l : zero8;
             }
         }
     };
     fetch(0);
-    for (int b0 = 0; b0 < a.B; b0 += 64) {
+    for (int b0 = 0; b0 < a.B; b0 += BT) {
         __syncthreads();
         if constexpr (A_F32) {
 #pragma unroll
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(256) void bgemm_tr_kernel(BGemmArgs a) {
 #pragma unroll
             for (int i = 0; i < AU; ++i) {
                 const int q = tid + i * 256;
-                if ((64 * MC / 8) % 256 == 0 || q < 64 * MC / 8) *reinterpret_cast<bf16x8*>(lds_a + (size_t)q * 8) = ra16[i];
+                if ((BT * MC / 8) % 256 == 0 || q < BT * MC / 8) *reinterpret_cast<bf16x8*>(lds_a + (size_t)q * 8) = ra16[i];
             }
         }
         if constexpr (B_F32) {
@@ -385,20 +388,23 @@ __global__ __launch_bounds__(256) void bgemm_tr_kernel(BGemmArgs a) {
 #pragma unroll
             for (int i = 0; i < BU; ++i) {
                 const int q = tid + i * 256;
-                if ((64 * NC / 8) % 256 == 0 || q < 64 * NC / 8) *reinterpret_cast<bf16x8*>(lds_b + (size_t)q * 8) = rb16[i];
+                if ((BT * NC / 8) % 256 == 0 || q < BT * NC / 8) *reinterpret_cast<bf16x8*>(lds_b + (size_t)q * 8) = rb16[i];
             }
         }
         __syncthreads();
-        if (b0 + 64 < a.B) fetch(b0 + 64);
-        const int row = 16 * wave + 8 * h + qrow;            // this wave's 16 images of the tile
-        bf16x8 bv[NBLK];
+        if (b0 + BT < a.B) fetch(b0 + BT);
 #pragma unroll
-        for (int j = 0; j < NBLK; ++j) bv[j] = tr_frag(lds_b + row * NC + j * 32 + cb, lds_b + (row + 4) * NC + j * 32 + cb);
+        for (int ks = 0; ks < BT / 64; ++ks) {
+            const int row = (BT / 4) * wave + 16 * ks + 8 * h + qrow;      // this wave's BT/4 images of the tile, 16 per k-step
+            bf16x8 bv[NBLK];
 #pragma unroll
-        for (int i = 0; i < MBLK; ++i) {
-            const bf16x8 av = tr_frag(lds_a + row * MC + i * 32 + cb, lds_a + (row + 4) * MC + i * 32 + cb);
+            for (int j = 0; j < NBLK; ++j) bv[j] = tr_frag(lds_b + row * NC + j * 32 + cb, lds_b + (row + 4) * NC + j * 32 + cb);
 #pragma unroll
-            for (int j = 0; j < NBLK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < MBLK; ++i) {
+                const bf16x8 av = tr_frag(lds_a + row * MC + i * 32 + cb, lds_a + (row + 4) * MC + i * 32 + cb);
+#pragma unroll
+                for (int j = 0; j < NBLK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[j], acc[i][j], 0, 0, 0);
+            }
         }
     }
 #pragma unroll

@@ -493,7 +493,11 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
         epilogue_store<H, NT, NCH, EPI_PLAIN, float, NS == 1>(acc[tl], nullptr, a.out + (size_t)blockIdx.z * a.sliceFloats, nullptr, smem, a.B,
                                                               mt, n0, img0, ty0, tx0, numTiles);
     } else {
+#if CONV_EXPERIMENT == 3          // timing experiment (wrong results): no BatchNorm partials in the forward epilogue
+        if constexpr (NS == 1) epilogue_store<H, NT, NCH, EPI == EPI_BIAS_BNSTAT ? EPI_BIAS_RELU : EPI, __bf16, true>(acc[tl], a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0, numTiles);
+#else
         if constexpr (NS == 1) epilogue_store<H, NT, NCH, EPI, __bf16, true>(acc[tl], a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0, numTiles);
+#endif
         else epilogue_store<H, NT, NCH, EPI>(acc[tl], a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0, numTiles);
     }
     }

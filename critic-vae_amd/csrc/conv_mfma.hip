@@ -34,6 +34,16 @@ struct ConvArgs {
 // chunks to keep ~80 MFMAs per wave between barrier pairs; KCP = padded row of the transposed (dgrad) slab
 template <int NT> struct KChunk { static constexpr int KC = NT == 32 ? 32 : 16, KCP = KC + 1; };
 
+#ifdef CONVF_TIMING     // experiment builds only (see conv_bf16.hip CONV_TIMING): stage timing of one fp32 instantiation
+__device__ long long convf_dbg[16 * 4 * 10];
+extern "C" int cvae_convf_dbg_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(convf_dbg), sizeof(convf_dbg)); }
+#define CF_ON (KCH == CONVF_TIMING_KCH && NCH == CONVF_TIMING_NCH && H == CONVF_TIMING_H && !UP)
+#define CF_STAMP(v) do { if (CF_ON) v = clock64(); } while (0)
+#else
+#define CF_ON false
+#define CF_STAMP(v)
+#endif
+
 template <int KCH, int NCH, int H, bool UP, bool DGRAD, int NT, int EPI, int KSPLIT>
 __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
     using T = Tile<H>;
@@ -143,16 +153,24 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
     const int st0 = blockIdx.z * NST, st1 = st0 + NST;
     load_w(st0);
     load_input(st0 / 5);
+    [[maybe_unused]] long long ct0 = 0, ct1 = 0, ct2 = 0, ct3 = 0, ct4 = 0, cd[6] = {0, 0, 0, 0, 0, 0}, ctb = 0, cta = 0, ctw = 0;      // CONVF_TIMING builds
+    CF_STAMP(ctb);
     for (int st = st0; st < st1; ++st) {
         const int r = st % 5;
+        CF_STAMP(ct0);
         __syncthreads();                       // everyone finished reading the previous stage
+        CF_STAMP(ct1);
         if (r == 0) store_input();
+        CF_STAMP(cta);
         store_w();
+        CF_STAMP(ctw);
         // issue order matters: vmcnt retires in order, so the (older) halo loads must not sit
         // between a weight load and the store_w that waits for it
         if (r == 0 && st + 5 < st1) load_input(st / 5 + 1);     // lands during this stage's MFMAs
         if (st + 1 < st1) load_w(st + 1);      // in flight while this stage computes
+        CF_STAMP(ct2);
         __syncthreads();
+        CF_STAMP(ct3);
         const float* ap = lds_in + aBase + r * T::HTW;
         __builtin_amdgcn_iglp_opt(0);
 #pragma unroll
@@ -168,7 +186,15 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
                 }
             }
         }
+#ifdef CONVF_TIMING
+        if (CF_ON) {
+            __builtin_amdgcn_sched_barrier(0);
+            long long te = clock64();
+            cd[0] += ct1 - ct0; cd[1] += ct2 - ct1; cd[2] += ct3 - ct2; cd[3] += te - ct3; cd[4] += cta - ct1; cd[5] += ctw - cta;
+        }
+#endif
     }
+    CF_STAMP(ct4);
 
     // ------------------------------- epilogue -------------------------------
     if (KSPLIT > 1) {
@@ -200,6 +226,13 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
             a.out[o] = a.aux[o] > 0.f ? sum : 0.f;
         }
     }
+#ifdef CONVF_TIMING
+    if (CF_ON && (blockIdx.x & 63) == 0 && blockIdx.x < 1024 && blockIdx.y == 0 && lane == 0) {
+        long long tend = clock64();
+        long long* o = convf_dbg + ((blockIdx.x >> 6) * 4 + wave) * 10;
+        o[0] = cd[0]; o[1] = cd[1]; o[2] = cd[2]; o[3] = cd[3]; o[4] = ct4 - ctb; o[5] = tend - ct4; o[6] = st1 - st0; o[7] = tend - ctb; o[8] = cd[4]; o[9] = cd[5];
+    }
+#endif
 }
 
 template <int KCH, int NCH, int H, bool UP, bool DGRAD, int NT, int EPI, int KSPLIT = 1>

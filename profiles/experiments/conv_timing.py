@@ -16,7 +16,8 @@ from critic_vae_amd.train import FusedTrainer  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 dev = torch.device("cuda:0")
-vae = VariationalAutoencoder(max_batch=B, seed=0, precision="bf16").to(dev)
+PREC = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+vae = VariationalAutoencoder(max_batch=B, seed=0, precision=PREC).to(dev)
 tr = FusedTrainer(vae)
 x = torch.rand(B, 3, 64, 64, device=dev)
 pred = torch.rand(B, 1, device=dev)
@@ -25,7 +26,7 @@ for _ in range(5):
     tr.step(x, pred, eps)
 torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 640)()
-vae.handle.lib.cvae_conv_dbg_read(buf)
+(vae.handle.lib.cvae_conv_dbg_read if PREC == "bf16" else vae.handle.lib.cvae_convf_dbg_read)(buf)
 names = ["barrier1", "stage", "barrier2", "mfma"]
 for g in range(16):
     for w in range(4):

@@ -502,9 +502,9 @@ static constexpr int E1W_ROW = 128 * 32;
 //      fmaf(yb, scale, shift) in scan order; dy[p] = (p == argmax ? g*scale : 0) - (A + Bc*yb[p]) with g = d_a0*[a0 > 0],
 //      Bc = scale*k2*invstd, A = scale*k1 - Bc*mean (the apply pass's formula with the per-channel constants folded);
 //      a0 / d_a0 tiles arrive by one 16-byte load per thread, a tile ahead, and are picked up per (window, channel) from LDS;
-//   3. dy goes to LDS CHANNEL-major ([co][tile pixel], 8-byte stores of 4 consecutive pixels), so the B operand of the
-//      weight-gradient MFMA (8 consecutive pixels of one channel) is a plain 16-byte read.
-static constexpr int E1W_DT = 136;          // row stride of the channel-major dy tile in elements (68 dwords: conflict-free 16-byte reads)
+//   3. dy never leaves the registers: the weight-gradient MFMA contracts over pixels in any order, so accumulator elements
+//      8ks .. 8ks+7 of every lane ARE its B fragment of k-step ks (quadrant row ks), and the transposed reads of the A operand
+//      fetch the pixels in that order (an earlier form stored dy to LDS channel-major and read it back behind a third barrier).
 typedef float f32x2t __attribute__((ext_vector_type(2)));
 #ifndef E1W_OCC
 #define E1W_OCC 3          // workgroups per CU of the bf16 E1 weight-gradient kernel (VGPR budget 512 / (E1W_OCC) per lane; splits = E1W_OCC * CUs)
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256, E1W_OCC) void e1_wgrad_bf16_kernel(ThinWgradAr
     static_assert(T::TW == 32 && T::TH == 4 && T::IMGS == 1, "one tile row per wave");
     constexpr int HWX = 40, HR_ = T::TH + 4, NPXH = HR_ * HWX, U_ONES = NPXH + 8, U_ZERO = NPXH + 9;
     __shared__ __attribute__((aligned(16))) bf16x4 lds_x[NPXH + 10];          // strip | 8 over-read pad units | ones | zeros
-    __shared__ __attribute__((aligned(16))) __bf16 lds_d[FUSE ? 32 * E1W_DT : 128 * 32];     // FUSE: [co][E1W_DT]; else [px][32]
+    __shared__ __attribute__((aligned(16))) __bf16 lds_d[FUSE ? 8 : 128 * 32];               // !FUSE: dy tile [px][32] (FUSE: dy never leaves registers)
     __shared__ __attribute__((aligned(16))) __bf16 lds_p[FUSE ? 2 * 32 * 32 : 8];             // FUSE: a0 | d_a0 tiles [pooled px][32]
     __shared__ float red[3 * 1024];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -605,7 +605,12 @@ __global__ __launch_bounds__(256, E1W_OCC) void e1_wgrad_bf16_kernel(ThinWgradAr
             // 2. BatchNorm / pool / ReLU backward of the lane's four windows (quadrant columns 4lh + {0,2,8,10}), channel li;
             //    the two columns of a window row travel as one packed pair
             const f32x2t bv2 = {bv, bv}, sc2 = {bsc, bsc}, sh2 = {bsh, bsh}, bA2 = {bA, bA}, bB2 = {bB, bB};
-            bf16x4 dq[2][2];                         // [row of the quadrant][column group 0-3 / 8-11] -> 4 consecutive pixels
+            bf16x8 dyf[2];                           // [quadrant row = k-step]: dy of accumulator elements 8ks .. 8ks+7
+            // dy of the quadrant goes straight into the weight-gradient MFMA as its B operand (k = pixel, n = channel li): the
+            // contraction order over pixels is free, so k-step ks takes accumulator elements 8ks .. 8ks+7 of every lane as they
+            // are — lane half lh, element jj = quadrant row ks, column 4lh + (jj&3) + 8(jj>>2) — and the transposed reads of
+            // the A operand below fetch the pixels in that same order.  (Round 3 first wrote dy to LDS channel-major and read
+            // it back behind a third barrier.)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int v = 2 * j, m0 = (v & 3) + 8 * (v >> 2) + 4 * lh;          // first column of the window
@@ -624,33 +629,33 @@ __global__ __launch_bounds__(256, E1W_OCC) void e1_wgrad_bf16_kernel(ThinWgradAr
                 const f32x2t sel0 = {(!hi && !c01) ? gs : 0.f, (!hi && c01) ? gs : 0.f};
                 const f32x2t sel1 = {(hi && !c23) ? gs : 0.f, (hi && c23) ? gs : 0.f};
                 const f32x2t d0 = sel0 - t0v, d1 = sel1 - t1v;
-                dq[0][j >> 1][2 * (j & 1)] = (__bf16)d0.x; dq[0][j >> 1][2 * (j & 1) + 1] = (__bf16)d0.y;
-                dq[1][j >> 1][2 * (j & 1)] = (__bf16)d1.x; dq[1][j >> 1][2 * (j & 1) + 1] = (__bf16)d1.y;
+                dyf[0][v] = (__bf16)d0.x; dyf[0][v + 1] = (__bf16)d0.y;          // elements v, v+1 (row 0) and v+8, v+9 (row 1)
+                dyf[1][v] = (__bf16)d1.x; dyf[1][v + 1] = (__bf16)d1.y;
             }
-            // 3. channel-major dy tile: pixel index = tile row * 32 + column
+            // 3. weight gradient over the quadrant: k-step ks = quadrant row ks; transposed-read lane address: pixel column
+            //    4h + qrow for read 0, +8 for read 1 (K index 8h + 4*read + qrow <-> column 4h + qrow + 8*read, as dyf)
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
+            for (int ks = 0; ks < 2; ++ks) {
+                const __bf16* pb = xs + ((qr + ks) * HWX + qc + 4 * h + qrow) * 4;       // this lane's pixel in the strip (tap (0,0))
 #pragma unroll
-                for (int cg = 0; cg < 2; ++cg)
-                    *reinterpret_cast<bf16x4*>(lds_d + li * E1W_DT + (qr + rr) * 32 + qc + 8 * cg + 4 * lh) = dq[rr][cg];
-            __syncthreads();
-        }
+                for (int b = 0; b < 4; ++b) {
+                    const __bf16* ap = mconst[b] ? xs + moff[b] : pb + moff[b];
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(ap, mconst[b] ? ap : ap + 32), dyf[ks], acc[b], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int px = 16 * ks + 8 * h + qrow;                       // this lane's block row (pixel) for read 0; read 1: +4
-            bf16x8 bvv;
-            if constexpr (FUSE) {
-                bvv = *reinterpret_cast<const bf16x8*>(lds_d + li * E1W_DT + wave * 32 + 16 * ks + 8 * lh);   // B[k = pixel][n = li]
-            } else {
-                const __bf16* dp = lds_d + (wave * 32 + px) * 32 + cb;
-                bvv = tr_frag(dp, dp + 4 * 32);
-            }
+            const __bf16* dp = lds_d + (wave * 32 + px) * 32 + cb;
+            const bf16x8 bvv = tr_frag(dp, dp + 4 * 32);
             const __bf16* pb = xs + (wave * HWX + px) * 4;               // this lane's pixel in the strip (tap (0,0))
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const __bf16* ap = mconst[b] ? xs + moff[b] : pb + moff[b];
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(ap, mconst[b] ? ap : ap + 16), bvv, acc[b], 0, 0, 0);
             }
+        }
         }
     }
     // every wave contracted its own tile rows: fixed-order sum over the 4 waves, one accumulator at a time

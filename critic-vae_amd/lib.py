@@ -125,6 +125,8 @@ class Handle:
         if precision not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
         self.precision = precision
+        if os.environ.get("CVAE_OVERLAP_WGRAD") == "1":        # experiment switch: weight gradients on the side stream
+            overlap_wgrad = True
         cfg = _Config(width, max_batch, int(bool(overlap_wgrad)), self.PRECISIONS[precision])
         h = _p()
         rc = self.lib.cvae_create(C.byref(cfg), C.byref(h))

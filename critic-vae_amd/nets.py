@@ -154,13 +154,17 @@ class MSSIM(nn.Module):
 
 
 class VariationalAutoencoder(nn.Module):
-    def __init__(self, dims=(32, 64, 128, 256), width=P.w, max_batch=256, seed=None, precision="f32"):
+    def __init__(self, dims=(32, 64, 128, 256), width=P.w, max_batch=256, seed=None, precision="f32", overlap_wgrad=None):
         super().__init__()
         if tuple(dims) != P.dims:
             raise ValueError("dims[3] must be 256 (view(-1,256,4,4), vae_nets.py:144) and the HIP kernels are "
                              f"instantiated for {P.dims}")
         self.width, self.max_batch = width, max_batch
-        self.handle = Handle(width, max_batch, precision=precision)
+        # weight-gradient kernels on the library's low-priority side stream: pays in bf16 mode (+1.5 % at B = 2048: they fill the
+        # HBM-bound BatchNorm-backward stretches of the main stream), costs 3 % in fp32 mode (everything is MFMA-bound there)
+        if overlap_wgrad is None:
+            overlap_wgrad = precision == "bf16"
+        self.handle = Handle(width, max_batch, overlap_wgrad=overlap_wgrad, precision=precision)
         # PyTorch-default init distribution from the deterministic generator (seed None -> torch RNG seed)
         if seed is None:
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())

@@ -144,3 +144,27 @@ def test_fused_trainer_fit_u8_runs_the_feeder():
     scal = tr.fit_u8(frames, critic, B, epochs=1, generator=torch.Generator(device=DEV).manual_seed(1))
     torch.cuda.synchronize()
     assert tr.step_count == 3 and torch.isfinite(scal[:3]).all() and not torch.equal(before, vae.theta.detach())
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f32"])
+def test_side_stream_weight_gradients_are_bit_identical(precision):
+    """cvae_config.overlap_wgrad (default on in bf16 mode) moves the weight-gradient kernels and their slab reductions to the
+    library's side stream: same kernels, same arithmetic, so two steps give bit-identical gradients, parameters and scalars."""
+    import torch
+    from critic_vae_amd import synth
+    from critic_vae_amd.nets import VariationalAutoencoder
+    from critic_vae_amd.train import FusedTrainer
+    dev = torch.device("cuda:0")
+    B = 24
+    outs = []
+    for overlap in (False, True):
+        vae = VariationalAutoencoder(max_batch=B, seed=0, precision=precision, overlap_wgrad=overlap).to(dev)
+        tr = FusedTrainer(vae)
+        sc = []
+        for s in range(3):
+            x, pred, eps = (torch.from_numpy(a).to(dev) for a in synth.make_batch(77, s, B))
+            sc.append(tr.step(x, pred, eps).clone())
+        torch.cuda.synchronize()
+        outs.append((torch.stack(sc), tr.grads.clone(), vae.theta.data.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)

@@ -17,7 +17,8 @@ the C-ABI (critic-vae_amd FusedTrainer), inputs resident in HBM.  Rank 0 prints 
   config.config2 / config.config5 (N = 1) = the SAME timed loop (same barrier/sync bracket, same in-step kernel
       probe, --steps/--warmup as given) run right after it in this process on BASELINE.json configs[2]
       (bf16-MFMA, batch 2048) and on the per-GPU shard of configs[4] (128x128, bf16, batch 1024), each with
-      both rooflines;
+      both rooflines; `side_stream_wgrad` inside each = the rate with cvae_config.overlap_wgrad = 1 (weight-gradient
+      kernels on the library's side stream, bit-identical results; no rooflines: kernels share the chip);
   config.config4 / config.config5 (N > 1) = configs[3] / configs[4] per GPU, each timed with the gradient
       all-reduce in three buckets overlapped with backward AND as one all-reduce after backward, with
       allreduce_exposed_us for both;
@@ -185,7 +186,7 @@ class Ctx:
             torch.distributed.barrier()
 
 
-def time_workload(cx, spec, steps, warmup, probing, allreduce_dtype=None, overlaps=(None,), fwd_bwd_rate=False):
+def time_workload(cx, spec, steps, warmup, probing, allreduce_dtype=None, overlaps=(None,), fwd_bwd_rate=False, side_stream_wgrad=False):
     """Build the model for `spec` (precision, batch, width), run `warmup` untimed + `steps` timed training steps
     bracketed by barrier + synchronize on both sides, max over ranks.  Returns (result dict, trainer, inputs).
     overlaps: all-reduce modes to time at N > 1 (None = the trainer's default); the first one is the result, the
@@ -196,7 +197,7 @@ def time_workload(cx, spec, steps, warmup, probing, allreduce_dtype=None, overla
 
     prec, B, Wd = spec["precision"], spec["batch"], spec["width"]
     world, rank, dev = cx.world, cx.rank, cx.dev
-    vae = VariationalAutoencoder(width=Wd, max_batch=B, seed=0, precision=prec).to(dev)
+    vae = VariationalAutoencoder(width=Wd, max_batch=B, seed=0, precision=prec, overlap_wgrad=side_stream_wgrad).to(dev)
     tr = FusedTrainer(vae, world_size=world, reduce_dtype=allreduce_dtype)
     tr.measure_exposed = world > 1
     H = vae.handle
@@ -450,6 +451,11 @@ def main():
         if world == 1:
             for key in ("config2", "config5"):
                 res["config"][key] = time_workload(cx, dict(PRESETS[key], key=key), args.steps, args.warmup, probing)
+                # the same workload with the weight-gradient kernels on the library's side stream (cvae_config.overlap_wgrad,
+                # bit-identical results): kernels then share the chip, so it is a rate beside the line, without rooflines
+                ss = time_workload(cx, dict(PRESETS[key], key=key + " + side-stream weight gradients"), args.steps, args.warmup,
+                                   False, side_stream_wgrad=True)
+                res["config"][key]["side_stream_wgrad"] = {k: ss[k] for k in ("value", "unit", "ms_per_step", "steps", "final_loss")}
             # the same configs[1] workload in the two fp32-EMULATION modes (exact 3-way bf16 operand splits on the bf16 MFMA,
             # DESIGN.md 7b): they pass the same decisions-imposed 1e-4 parity test as the fp32 headline
             # (tests/test_gpu_step.py::test_step_b256_fp32_against_oracle[bf16x9|bf16x6]) but are reported beside it, never as it

@@ -402,8 +402,8 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
     const int W = h->cfg.width;
     float* sc = ws + w.scratch;
     float* scw = ws + w.scratch_w;
-    // cfg.overlap_wgrad != 0: weight-gradient work on a lower-priority side stream (+3% with the early kernels,
-    // -1.5% with the current ones); default: everything in order on the caller's stream.
+    // cfg.overlap_wgrad != 0: weight-gradient work on a lower-priority side stream (bit-identical results; round 3: +1.5 % in
+    // bf16 mode at B = 2048, -3 % in fp32 mode at B = 256); default: everything in order on the caller's stream.
     const bool overlap = h->cfg.overlap_wgrad != 0;
     const bool side_red = !overlap && h->side_reduce;          // slab reductions only (the wgrad kernels stay on `st`)
     if (overlap || side_red) RC(ensure_streams(h));

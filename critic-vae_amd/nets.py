@@ -160,10 +160,11 @@ class VariationalAutoencoder(nn.Module):
             raise ValueError("dims[3] must be 256 (view(-1,256,4,4), vae_nets.py:144) and the HIP kernels are "
                              f"instantiated for {P.dims}")
         self.width, self.max_batch = width, max_batch
-        # weight-gradient kernels on the library's low-priority side stream: pays in bf16 mode (+1.5 % at B = 2048: they fill the
-        # HBM-bound BatchNorm-backward stretches of the main stream), costs 3 % in fp32 mode (everything is MFMA-bound there)
-        if overlap_wgrad is None:
-            overlap_wgrad = precision == "bf16"
+        # overlap_wgrad=True: weight-gradient kernels on the library's low-priority side stream (bit-identical results).  Pays in
+        # bf16 mode (+1.5 % at B = 2048: they fill the HBM-bound BatchNorm-backward stretches of the main stream), costs 3 % in
+        # fp32 mode (everything is MFMA-bound there).  Off by default: with it, kernels share the chip and per-kernel times stop
+        # being comparable with a serialised rocprofv3 trace; bench.py reports the rate with it as an extra key.
+        overlap_wgrad = bool(overlap_wgrad)
         self.handle = Handle(width, max_batch, overlap_wgrad=overlap_wgrad, precision=precision)
         # PyTorch-default init distribution from the deterministic generator (seed None -> torch RNG seed)
         if seed is None:

@@ -52,15 +52,15 @@ def test_bf16_gradient_pack_is_rne_and_exact_back():
     h.grads_to_bf16(v[:0], out2[:0])                   # empty range: a no-op, not an invalid launch
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16"])          # bf16: weight gradients run on the side stream (joined per phase)
-def test_phased_backward_equals_single_call(precision):
+@pytest.mark.parametrize("precision,side", [("f32", False), ("bf16", False), ("bf16", True)])      # side: weight gradients on the side stream (joined per phase)
+def test_phased_backward_equals_single_call(precision, side):
     import torch
     from critic_vae_amd import synth
     from critic_vae_amd.nets import VariationalAutoencoder
     from critic_vae_amd.train import FusedTrainer
     dev = torch.device("cuda:0")
     B = 5
-    vae = VariationalAutoencoder(max_batch=B, seed=0, precision=precision).to(dev)
+    vae = VariationalAutoencoder(max_batch=B, seed=0, precision=precision, overlap_wgrad=side).to(dev)
     tr = FusedTrainer(vae)
     x, pred, eps = (torch.from_numpy(a).to(dev) for a in synth.make_batch(1234, 0, B))
     h, theta = vae.handle, vae.theta.data

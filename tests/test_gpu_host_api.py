@@ -148,7 +148,7 @@ def test_fused_trainer_fit_u8_runs_the_feeder():
 
 @pytest.mark.parametrize("precision", ["bf16", "f32"])
 def test_side_stream_weight_gradients_are_bit_identical(precision):
-    """cvae_config.overlap_wgrad (default on in bf16 mode) moves the weight-gradient kernels and their slab reductions to the
+    """cvae_config.overlap_wgrad (opt-in; bench.py times it as config2.side_stream_wgrad) moves the weight-gradient kernels and their slab reductions to the
     library's side stream: same kernels, same arithmetic, so two steps give bit-identical gradients, parameters and scalars."""
     import torch
     from critic_vae_amd import synth

@@ -377,7 +377,8 @@ def test_bf16_step_never_stores_y0_unless_a_block0_gamma_is_tiny():
             assert torch.isfinite(gk).all() and (gk - rk).abs().max() < 0.5 * rk.abs().max() + 0.02 * scale, (gk, rk, scale)
 
 
-def test_bf16_kernels_exact_on_their_stored_operands():
+@pytest.mark.parametrize("B", [8, 5])          # 5: ragged tile counts (the persistent D4 / MS-SSIM / E1 loops end unevenly)
+def test_bf16_kernels_exact_on_their_stored_operands(B):
     """Layout / indexing check of every bf16-mode contraction, independent of the bf16 rounding noise: after one
     bf16 step the workspace holds the bf16 activations and activation gradients the kernels actually consumed.
     Recomputing each layer's result on the CPU in fp32 from THOSE operands (weights rounded to bf16 as the packed
@@ -390,7 +391,7 @@ def test_bf16_kernels_exact_on_their_stored_operands():
     from critic_vae_amd.train import FusedTrainer
     from critic_vae_amd import layout as L
     dev = torch.device("cuda:0")
-    B, W = 8, 64
+    W = 64
     vae = VariationalAutoencoder(width=W, max_batch=B, seed=0, precision="bf16").to(dev)
     tr = FusedTrainer(vae)
     x, pred, eps = (torch.from_numpy(v).to(dev) for v in synth.make_batch(1234, 0, B, W))

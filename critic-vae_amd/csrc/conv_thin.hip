@@ -898,6 +898,121 @@ __global__ __launch_bounds__(256, THIN_F32_OCC) void d4_fwd_kernel(const float* 
     }
 }
 
+// fp32 mode (round 3): the phase-collapsed form of the bf16 kernel below on the exact fp32 MFMA (v_mfma_f32_16x16x4_f32: N = 16
+// columns for the 12 real ones, K = 9 taps x 32 channels = 72 MFMAs per 16 source pixels, A = one float per lane read in place
+// from the staged 10 x 18 halo tile, the 72 collapsed-weight values of a lane in registers).  The Q / gather form above spends
+// 48 MFMAs of 32x32x2 per 32 source rows (28 of 128 rows and 21 of 96 columns are padding) and then 75 LDS reads per output
+// pixel; this one is 0.75x its MFMA time and has no gather: 48 -> 2x us at B = 256.  Sums of up to four 5x5 taps are formed in
+// fp32 before the contraction (as D1..D3 do, conv_up.hip): the summation order differs from the direct form at the 1e-7 level.
+template <int H>
+__global__ __launch_bounds__(256, 2) void d4_fwd_pc_f32_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ recon, int B) {
+    constexpr int HS = H / 2, TXN = HS / 16, TPI = (HS / 8) * TXN;
+    constexpr int HW = 18, HP = 10 * HW, AS = 36;               // halo 10 x 18 source pixels, row stride 36 floats: 16-byte rows, and
+    constexpr int OS = 34;                                       // the (pixel, k) reads of a wave hit 64 different banks
+    __shared__ __attribute__((aligned(16))) float lds_a[HP * AS];
+    __shared__ __attribute__((aligned(16))) float lds_o[3 * 16 * OS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lg = lane >> 4;
+    // collapsed weights: B value of k-step (tap t, j): k = 4j + lg (channel), column n = lc = p*3 + co (n >= 12: zero)
+    float bw[72];
+    {
+        static_assert(9 * 32 * 16 <= HP * AS, "collapsed weights fit in the halo buffer");
+        // the 2400 weights travel to LDS first (coalesced, all loads in flight at once): summing them straight from global
+        // memory was a chain of up to 72 dependent scattered loads per thread — most of the kernel's time at B = 256
+        for (int q = tid; q < 2400; q += 256) lds_a[q] = w[q];
+        __syncthreads();
+        float cw[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            const int q = tid + i * 256, n = q & 15, ci = (q >> 4) & 31, t = q >> 9;
+            const int pz = n / 3, co = n % 3, py = pz >> 1, px = pz & 1, ta = t / 3, tb = t % 3;
+            const int r0 = py ? (ta == 0 ? 0 : 2 * ta - 1) : 2 * ta, r1 = py ? 2 * ta : (ta == 2 ? 4 : 2 * ta + 1);
+            const int s0 = px ? (tb == 0 ? 0 : 2 * tb - 1) : 2 * tb, s1 = px ? 2 * tb : (tb == 2 ? 4 : 2 * tb + 1);
+            float acc = 0.f;
+            if (n < 12)
+                for (int r = r0; r <= r1; ++r)
+                    for (int s5 = s0; s5 <= s1; ++s5) acc += lds_a[((r * 5 + s5) * 32 + ci) * 3 + co];
+            cw[i] = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 18; ++i) { const int q = tid + i * 256; lds_a[((q >> 9) * 32 + ((q >> 4) & 31)) * 16 + (q & 15)] = cw[i]; }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bw[t * 8 + j] = lds_a[(t * 32 + 4 * j + lg) * 16 + lc];
+        __syncthreads();
+    }
+    const float bv = lc < 12 ? bias[lc % 3] : 0.f;
+    const int numTiles = B * TPI;
+    constexpr int NQ = HP * 8, IPT = (NQ + 255) / 256;          // 16-byte units of the halo tile
+    f32x4 ra[IPT];
+    auto fetch = [&](int tile) {
+        const int ib = tile / TPI, t = tile % TPI;
+        const int sy0 = (t / TXN) * 8 - 1, sx0 = (t % TXN) * 16 - 1;
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int q = tid + i * 256, c4 = q & 7, sp = q >> 3;
+            const int sy = sy0 + sp / HW, sx = sx0 + sp % HW;
+            const bool ok = sp < HP && (unsigned)sy < (unsigned)HS && (unsigned)sx < (unsigned)HS;
+            const f32x4 l = *reinterpret_cast<const f32x4*>(in + (ok ? ((size_t)(ib * HS + sy) * HS + sx) * 32 + c4 * 4 : 0));
+            ra[i] = ok ? l : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    const int G = gridDim.x;
+    auto tile_of = [&](int n) {          // XCD-aware order, as the bf16 kernel
+        if ((G & 7) || (numTiles & 7)) return n;
+        const int b = n % G, k = n / G;
+        return (b & 7) * (numTiles >> 3) + k * (G >> 3) + (b >> 3);
+    };
+    if ((int)blockIdx.x < numTiles) fetch(tile_of(blockIdx.x));
+    for (int n = blockIdx.x; n < numTiles; n += G) {
+        const int tile = tile_of(n);
+        const int ib = tile / TPI, t = tile % TPI;
+        const int ty0 = (t / TXN) * 16, tx0 = (t % TXN) * 32;
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int q = tid + i * 256;
+            if (q < NQ) *reinterpret_cast<f32x4*>(lds_a + (q >> 3) * AS + (q & 7) * 4) = ra[i];
+        }
+        __syncthreads();       // also: every thread is past the previous tile's output rows, lds_o is free
+        if (n + G < numTiles) fetch(tile_of(n + G));
+        f32x4 acc[2], acc2[2];               // two source rows x two chains (even / odd k-steps): four independent MFMA chains
+#pragma unroll
+        for (int g = 0; g < 2; ++g) { acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const float* ap0 = lds_a + ((2 * wave) * HW + lc) * AS + lg;             // source row 2w, column lc; + tap and 4j; row 2w+1: + HW*AS
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; j += 2)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const float* ap = ap0 + g * HW * AS + ((t / 3) * HW + t % 3) * AS + 4 * j;
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[0], bw[t * 8 + j], acc[g], 0, 0, 0);
+                    acc2[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4], bw[t * 8 + j + 1], acc2[g], 0, 0, 0);
+                }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc[g] += acc2[g];
+        if (lc < 12) {
+            const int pz = lc / 3, co = lc % 3;
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    lds_o[(co * 16 + 2 * (2 * wave + g) + (pz >> 1)) * OS + 2 * (4 * lg + i) + (pz & 1)] = fast_tanh(acc[g][i] + bv);
+        }
+        __syncthreads();
+        {
+            const int oy = tid >> 4, ox = (tid & 15) * 2;
+#pragma unroll
+            for (int co = 0; co < 3; ++co)
+                *reinterpret_cast<float2*>(recon + ((size_t)(ib * 3 + co) * H + ty0 + oy) * H + tx0 + ox) =
+                    *reinterpret_cast<const float2*>(lds_o + (co * 16 + oy) * OS + ox);
+        }
+    }
+}
+
 // precision mode 1 (round 3): Upsample(2) -> Conv5x5 -> Tanh as the PHASE-COLLAPSED 3x3 conv of conv_up.hip over the stored
 // low-resolution o3, straight on the MFMA.  Output pixel (2y+py, 2x+px) reads source pixel (y+a-1, x+b-1) through the 5x5
 // taps r with floor((py+r-2)/2) = a-1 (and s likewise), so with wc[p][a][b] = the sum of those taps' weights
@@ -925,9 +1040,16 @@ __global__ __launch_bounds__(256, 4) void d4_fwd_bf16_kernel(const float* __rest
     bf16x8 bw[9];
     {
         __bf16* wl = reinterpret_cast<__bf16*>(lds_a);           // [t][n][lg][8]
-        static_assert(9 * 16 * 4 <= 4 * PSP, "weight fragments fit in the halo buffer");
-        for (int q = tid; q < 9 * 16 * 32; q += 256) {
-            const int ci = q & 31, n = (q >> 5) & 15, t = q >> 9;
+        static_assert(9 * 16 * 4 <= 4 * PSP && 2400 * 4 <= 4 * PSP * 16, "weight fragments / raw weights fit in the halo buffer");
+        // the 2400 weights travel to LDS first (coalesced, all loads in flight at once): summing them straight from global
+        // memory was a chain of dependent scattered loads per thread
+        float* wraw = reinterpret_cast<float*>(lds_a);
+        for (int q = tid; q < 2400; q += 256) wraw[q] = w[q];
+        __syncthreads();
+        float cw[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            const int q = tid + i * 256, ci = q & 31, n = (q >> 5) & 15, t = q >> 9;
             const int pz = n / 3, co = n % 3, py = pz >> 1, px = pz & 1, ta = t / 3, tb = t % 3;
             // 5x5 taps that reach source row offset ta-1 from output phase py: py = 0: {0,1},{2,3},{4}; py = 1: {0},{1,2},{3,4}
             const int r0 = py ? (ta == 0 ? 0 : 2 * ta - 1) : 2 * ta, r1 = py ? 2 * ta : (ta == 2 ? 4 : 2 * ta + 1);
@@ -935,8 +1057,14 @@ __global__ __launch_bounds__(256, 4) void d4_fwd_bf16_kernel(const float* __rest
             float acc = 0.f;
             if (n < 12)
                 for (int r = r0; r <= r1; ++r)
-                    for (int s5 = s0; s5 <= s1; ++s5) acc += w[((r * 5 + s5) * 32 + ci) * 3 + co];
-            wl[((t * 16 + n) * 4 + (ci >> 3)) * 8 + (ci & 7)] = (__bf16)acc;
+                    for (int s5 = s0; s5 <= s1; ++s5) acc += wraw[((r * 5 + s5) * 32 + ci) * 3 + co];
+            cw[i] = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            const int q = tid + i * 256, ci = q & 31, n = (q >> 5) & 15, t = q >> 9;
+            wl[((t * 16 + n) * 4 + (ci >> 3)) * 8 + (ci & 7)] = (__bf16)cw[i];
         }
         __syncthreads();
 #pragma unroll
@@ -1174,6 +1302,7 @@ __global__ __launch_bounds__(256, THIN_F32_OCC) void d4_bwd_kernel(ThinWgradArgs
 #endif
 static constexpr int D4P_ROW = 192 * 32;
 static constexpr int D4P_IW = 40;                 // image row stride in pixels (36 staged + 4 zero columns for the 8-wide runs)
+static constexpr int D4_BWD_BF16_SMEM_BYTES = 2 * 3 * 16 * 64 * 4;      // dynamic LDS of d4_bwd_bf16_kernel (see D4_BWD_BF16_SMEM)
 template <int H>
 __global__ __launch_bounds__(256, D4B_OCC) void d4_bwd_bf16_kernel(ThinWgradArgs a) {
     constexpr int HS = H / 2, TPI = (HS / 8) * (HS / 16);
@@ -1188,13 +1317,18 @@ __global__ __launch_bounds__(256, D4B_OCC) void d4_bwd_bf16_kernel(ThinWgradArgs
     // collapsed weights as A fragments of the input gradient: row ci = li, k-step m covers k = 16m + 8lh + jj
     bf16x8 vw[D4B_VWLDS ? 1 : 12];
     {
-        static_assert(12 * 32 * 2 * 8 <= IMG + 128 * 32, "weight fragments fit in the staging buffers");
+        static_assert(12 * 32 * 2 * 8 * 2 + 2400 * 4 <= D4_BWD_BF16_SMEM_BYTES, "weight fragments + raw weights fit in the dynamic LDS");
+        // the 2400 weights travel to LDS first (coalesced, all loads in flight at once; behind the fragment table): summing
+        // them straight from global memory was a chain of dependent scattered loads per thread
+        float* wraw = reinterpret_cast<float*>(smem_raw + 12 * 32 * 2 * 8 * 2);
+        for (int q = tid; q < 2400; q += 256) wraw[q] = a.w[q];
+        __syncthreads();
         for (int q = tid; q < 192 * 32; q += 256) {
             const int ci = q & 31, k = q >> 5, co = k & 3, j = (k >> 2) & 7, i = k >> 5;
             float acc = 0.f;
             if (co < 3 && j < 6)
                 for (int r = (4 - i < 0 ? 0 : 4 - i); r <= (5 - i > 4 ? 4 : 5 - i); ++r)
-                    for (int s5 = (4 - j < 0 ? 0 : 4 - j); s5 <= (5 - j > 4 ? 4 : 5 - j); ++s5) acc += a.w[((r * 5 + s5) * 32 + ci) * 3 + co];
+                    for (int s5 = (4 - j < 0 ? 0 : 4 - j); s5 <= (5 - j > 4 ? 4 : 5 - j); ++s5) acc += wraw[((r * 5 + s5) * 32 + ci) * 3 + co];
             img[(((k >> 4) * 32 + ci) * 2 + ((k >> 3) & 1)) * 8 + (k & 7)] = (__bf16)acc;
         }
         __syncthreads();
@@ -1352,7 +1486,7 @@ __global__ __launch_bounds__(256, D4B_OCC) void d4_bwd_bf16_kernel(ThinWgradArgs
     __syncthreads();
     if (tid < 32) slab[3 * 32 + tid] = tid < 3 ? (bred[0][tid] + bred[1][tid]) + (bred[2][tid] + bred[3][tid]) : 0.f;
 }
-static constexpr int D4_BWD_BF16_SMEM = 2 * 3 * 16 * 64 * 4;          // the final half-add of the accumulators (24 KB) exceeds the staging buffers (14.6 KB)
+static constexpr int D4_BWD_BF16_SMEM = D4_BWD_BF16_SMEM_BYTES;       // the final half-add of the accumulators (24 KB) exceeds the staging buffers (14.6 KB)
 static_assert(D4_BWD_BF16_SMEM >= (20 * D4P_IW * 4 + 128 * 32) * 2, "staging buffers");
 
 static constexpr int D4_BWD_SMEM = (3 * 720 + 128 * 32 + 128 * 77 + 32 + 76 * 32) * 4;
@@ -1369,14 +1503,15 @@ int64_t d4_bwd_ws_floats(int width, int B) {
 }
 
 int launch_d4_fwd(int width, int B, const float* in, const float* w, const float* bias, float* recon, hipStream_t st, bool bf16io) {
-    // persistent: bf16 mode 4 workgroups per CU (18 KB of LDS, 16 x 32-output tiles); fp32 66 KB -> two (16 x 16 tiles); each loops over its share
+    // persistent: 16 x 32-output tiles; bf16 mode 4 workgroups per CU (18 KB of LDS), fp32 2 (their prologue builds the 72 collapsed
+    // weight values of every lane: fewer, longer-lived workgroups); each loops over its share
     const int want = (bf16io ? 4 : 2) * cvae_num_cus();
-    const int tiles = bf16io ? B * (width / 16) * (width / 32) : B * (width / 16) * (width / 16), grid = tiles < want ? tiles : want;
+    const int tiles = B * (width / 16) * (width / 32), grid = tiles < want ? tiles : want;
     cvae_probe_begin(st);
     if (width == 64 && bf16io) hipLaunchKernelGGL(d4_fwd_bf16_kernel<64>, dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
     else if (width == 128 && bf16io) hipLaunchKernelGGL(d4_fwd_bf16_kernel<128>, dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
-    else if (width == 64) hipLaunchKernelGGL((d4_fwd_kernel<64, float>), dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
-    else if (width == 128) hipLaunchKernelGGL((d4_fwd_kernel<128, float>), dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
+    else if (width == 64) hipLaunchKernelGGL(d4_fwd_pc_f32_kernel<64>, dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
+    else if (width == 128) hipLaunchKernelGGL(d4_fwd_pc_f32_kernel<128>, dim3(grid), dim3(256), 0, st, in, w, bias, recon, B);
     else { cvae_set_error("d4_fwd: width %d unsupported", width); return -2; }
     cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();

@@ -805,105 +805,13 @@ int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw
 // the fp32 rounding of its own input sum)
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f); }
 
-// Persistent over 16x16 output tiles (10x10 source window -> 128 GEMM rows, 100 used): the permuted
-// weights B[ci][tap*3+co] live in 48 registers per lane, the next tile's window is fetched into
-// registers while the MFMAs of the current one run, and the tap gather + Tanh + NCHW store of one
-// workgroup overlaps the MFMAs of the other workgroup on the CU.
-template <int H, typename AT>   // H = output size (64); source o3 is (H/2)^2 x 32 NHWC, stored as AT
-__global__ __launch_bounds__(256, THIN_F32_OCC) void d4_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                     const float* __restrict__ bias, float* __restrict__ recon, int B) {
-    constexpr int HS = H / 2, TX = H / 16, TPI = TX * TX;
-    __shared__ __attribute__((aligned(16))) float lds_a[128 * 33];
-    __shared__ float lds_q[128 * 97];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    float bwr[16][3];
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-#pragma unroll
-        for (int nb = 0; nb < 3; ++nb) {
-            const int n = nb * 32 + li, ci = 2 * j + lh;
-            bwr[j][nb] = n < 75 ? w[((n / 3) * 32 + ci) * 3 + n % 3] : 0.f;
-        }
-    const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
-    const int numTiles = B * TPI;
-    float4 ra[4];
-    auto fetch = [&](int tile) {
-        const int ib = tile / TPI, t = tile % TPI;
-        const int sy0 = (t / TX) * 8 - 1, sx0 = (t % TX) * 8 - 1;           // 10x10 source window
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = tid + i * 256, c4 = q & 7, sp = q >> 3;
-            const int sy = sy0 + sp / 10, sx = sx0 + sp % 10;
-            const bool ok = sp < 100 && (unsigned)sy < (unsigned)HS && (unsigned)sx < (unsigned)HS;
-            const f32x4 v = Act<AT>::ld4(in, ok ? ((size_t)(ib * HS + sy) * HS + sx) * 32 + c4 * 4 : 0);
-            ra[i] = ok ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    // XCD-aware tile order (common.h, xcd_tile): workgroups b, b+8, ... share an XCD, so each XCD walks ONE contiguous
-    // eighth of the tiles — the 10x10 source windows of neighbouring tiles overlap by two rows / columns, and the overlap is
-    // then re-read from that XCD's L2 instead of from HBM by another XCD
-    const int G = gridDim.x;
-    auto tile_of = [&](int n) {
-        if ((G & 7) || (numTiles & 7)) return n;
-        const int b = n % G, k = n / G;
-        return (b & 7) * (numTiles >> 3) + k * (G >> 3) + (b >> 3);
-    };
-    if ((int)blockIdx.x < numTiles) fetch(tile_of(blockIdx.x));
-    for (int n = blockIdx.x; n < numTiles; n += G) {
-        const int tile = tile_of(n);
-        const int ib = tile / TPI, t = tile % TPI;
-        const int ty0 = (t / TX) * 16, tx0 = (t % TX) * 16, sy0 = ty0 / 2 - 1, sx0 = tx0 / 2 - 1;
-        // lds_a was last read before the previous tile's second barrier: free to refill
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = tid + i * 256;
-            float* d = lds_a + (q >> 3) * 33 + (q & 7) * 4;
-            d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
-        }
-        __syncthreads();       // also: every thread is past the previous tile's gather, lds_q is free
-        if (n + G < numTiles) fetch(tile_of(n + G));
-        f32x16 acc[3];
-#pragma unroll
-        for (int nb = 0; nb < 3; ++nb)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[nb][v] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float av = lds_a[(wave * 32 + li) * 33 + 2 * j + lh];
-#pragma unroll
-            for (int nb = 0; nb < 3; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bwr[j][nb], acc[nb], 0, 0, 0);
-        }
-#pragma unroll
-        for (int nb = 0; nb < 3; ++nb)
-#pragma unroll
-            for (int v = 0; v < 16; ++v)
-                lds_q[(wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh) * 97 + nb * 32 + li] = acc[nb][v];
-        __syncthreads();
-        const int oy = tid >> 4, ox = tid & 15;
-        float s0 = b0, s1 = b1, s2 = b2;
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            const int sr = ((ty0 + oy + r - 2) >> 1) - sy0;
-#pragma unroll
-            for (int s = 0; s < 5; ++s) {
-                const int sc = ((tx0 + ox + s - 2) >> 1) - sx0;
-                const float* qv = lds_q + (sr * 10 + sc) * 97 + (r * 5 + s) * 3;
-                s0 += qv[0]; s1 += qv[1]; s2 += qv[2];
-            }
-        }
-        const size_t o = ((size_t)(ib * 3) * H + ty0 + oy) * H + tx0 + ox;
-        recon[o] = fast_tanh(s0);
-        recon[o + (size_t)H * H] = fast_tanh(s1);
-        recon[o + 2 * (size_t)H * H] = fast_tanh(s2);
-    }
-}
-
-// fp32 mode (round 3): the phase-collapsed form of the bf16 kernel below on the exact fp32 MFMA (v_mfma_f32_16x16x4_f32: N = 16
-// columns for the 12 real ones, K = 9 taps x 32 channels = 72 MFMAs per 16 source pixels, A = one float per lane read in place
-// from the staged 10 x 18 halo tile, the 72 collapsed-weight values of a lane in registers).  The Q / gather form above spends
-// 48 MFMAs of 32x32x2 per 32 source rows (28 of 128 rows and 21 of 96 columns are padding) and then 75 LDS reads per output
-// pixel; this one is 0.75x its MFMA time and has no gather: 48 -> 2x us at B = 256.  Sums of up to four 5x5 taps are formed in
-// fp32 before the contraction (as D1..D3 do, conv_up.hip): the summation order differs from the direct form at the 1e-7 level.
+// fp32 mode (round 3): the phase-collapsed form (see the bf16 kernel below for the algebra) on the exact fp32 MFMA
+// (v_mfma_f32_16x16x4_f32: N = 16 columns for the 12 real ones, K = 9 taps x 32 channels = 72 MFMAs per 16 source pixels, A = one
+// float per lane read in place from the staged 10 x 18 halo tile, the 72 collapsed-weight values of a lane in registers, four
+// independent accumulator chains per wave).  Rounds 1-2 computed Q[source][tap, co] = o3 . W on 32x32x2 MFMAs (28 of 128 rows and 21
+// of 96 columns padding) and had every output pixel gather its 25 taps from LDS (75 reads): 48 -> 39 us at B = 256.  Sums of up to
+// four 5x5 taps are formed in fp32 before the contraction (as D1..D3 do, conv_up.hip): the summation order differs from the direct
+// form at the 1e-7 level.  Persistent, XCD-aware tile order, next tile prefetched into registers.
 template <int H>
 __global__ __launch_bounds__(256, 2) void d4_fwd_pc_f32_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ recon, int B) {

@@ -62,12 +62,6 @@ enum { MODE_STD = 0, MODE_UP_FWD = 1, MODE_UP_DGRAD = 2 };
 #ifndef BF16_MT
 #define BF16_MT 2          // 128-pixel tiles per workgroup of the plain bf16 kernels (1 = round-1 structure)
 #endif
-#ifndef BF16_NT128
-#define BF16_NT128 0
-#endif
-#ifndef BF16_WDB
-#define BF16_WDB 0         // 1 (experiment, round 3): weight slabs double-buffered in LDS, staged between the MFMAs (see the stage loop): slower
-#endif
 #ifndef BF16_WDMA
 #define BF16_WDMA 0        // 1 (experiment, round 3): weight slabs travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) into a double
 #endif                     // buffer, one barrier per K stage.  Correct (tests green) but SLOWER on the MI355X: E2 fwd 227 -> 237 us, E2 dgrad
@@ -97,9 +91,6 @@ template <int H, int OCT> struct Bf16Geom {
 // MT = 128-pixel tiles per workgroup (bf16 mode: 2): one weight slab staged into LDS — and one weight fragment read
 // from LDS — serves MT times as many MFMAs; the K chunk shrinks to 32 channels so that the LDS footprint (and with
 // it the number of resident workgroups) stays where it was.
-#ifndef CONV_EXPERIMENT
-#define CONV_EXPERIMENT 0
-#endif
 #ifdef CONV_TIMING     // experiment builds only: where a wave of ONE instantiation (-DCONV_TIMING_KCH/NCH/H) spends its stages
 __device__ long long conv_dbg[16 * 4 * 10];
 extern "C" int cvae_conv_dbg_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(conv_dbg), sizeof(conv_dbg)); }
@@ -125,12 +116,6 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     // registers, no ds_write_b128 (13 issue cycles each), and with two slab buffers ONE barrier per stage: the slab's unit
     // order in LDS is the staging thread order (unit q <- thread q), which is exactly the DMA's "wave base + lane * 16".
     constexpr bool WDMA = NS == 1 && BF16_WDMA != 0;
-    // WDB (bf16 mode, round 3): two slab buffers, the slab of stage st+1 is written (registers -> ds_write_b128) at the TOP of stage
-    // st, so the stores drain under this stage's MFMAs and the barrier at the top of stage st+1 both frees the other buffer and
-    // publishes the slab: ONE barrier per stage instead of two (a second one only where a new input chunk is staged, every fifth
-    // stage).  Stage timing of the two-barrier loop (profiles/experiments/conv_timing.py): 1.1-1.6 k cycles per stage between two
-    // MFMA phases of 1.5 k, most of it the store drain in front of the second barrier.
-    constexpr bool WDB = NS == 1 && BF16_WDB != 0 && !WDMA;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);      // [tile][split][octet][halo pixel]
     bf16x8* lds_w = lds_a + MT * NS * A_UNITS;                 // [buffer (WDMA: 2)][split][tap][kb][half][n]
@@ -191,13 +176,13 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
                                                  (__attribute__((address_space(3))) void*)(lds_w + buf * W_UNITS + i * 256 + wave * 64), 16, 0, 0);
         }
     };
-    auto store_w = [&](int buf = 0) {           // buf: WDB only (NS == 1)
+    auto store_w = [&]() {
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int q = tid + i * 256;
             if (W_UNITS % 256 == 0 || q < W_UNITS) {
 #pragma unroll
-                for (int sp = 0; sp < NS; ++sp) lds_w[(buf + sp) * W_UNITS + q] = wreg[sp * WPT + i];
+                for (int sp = 0; sp < NS; ++sp) lds_w[sp * W_UNITS + q] = wreg[sp * WPT + i];
             }
         }
     };
@@ -284,19 +269,6 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     const int st0 = blockIdx.z * NST, st1 = st0 + NST;
     if constexpr (WDMA) dma_w(st0, 0); else load_w(st0);
     load_input(st0 / KS);
-    if constexpr (WDB) {                       // prologue: slab st0 -> buffer 0, slab st0+1 -> registers (both loads in flight together)
-        bf16x8 wnext[WPT];
-        {
-            const int sn = st0 + 1 < st1 ? st0 + 1 : st0;
-            const bf16x8* wst = a.wp + (size_t)((sn % KS) * KS * (KCH / 16) + (sn / KS) * KB) * 2 * NCH;
-#pragma unroll
-            for (int i = 0; i < WPT; ++i)
-                if (W_UNITS % 256 == 0 || tid + i * 256 < W_UNITS) wnext[i] = wst[wbase[i]];
-        }
-        store_w(0);
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) wreg[i] = wnext[i];
-    }
     [[maybe_unused]] long long ct0 = 0, ct1 = 0, ct2 = 0, ct3 = 0, ct4 = 0, cd[6] = {0, 0, 0, 0, 0, 0}, ctb = 0, cta = 0, ctw = 0;      // CONV_TIMING builds
     CT_STAMP(ctb);
     for (int st = st0; st < st1; ++st) {
@@ -317,69 +289,28 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
             if (r == 0 && st + KS < st1) load_input(st / KS + 1);
             if (st + 1 < st1) dma_w(st + 1, wbuf ^ 1);            // lands in the buffer stage st-1 read, while this stage computes
             CT_STAMP(ct3);
-        } else if constexpr (WDB) {
-            wbuf = (st - st0) & 1;
-            __syncthreads();                   // everyone finished reading stage st-1 (input tiles, slab buffer wbuf^1); slab st is visible
-            CT_STAMP(ct1);
-            CT_STAMP(cta); CT_STAMP(ctw);
-            if (r == 0) {                      // chunk boundary: new input tiles, visible behind a second barrier
-                store_input();
-                if (st + KS < st1) load_input(st / KS + 1);
-                CT_STAMP(ct2);
-                __syncthreads();
-            } else CT_STAMP(ct2);
-            CT_STAMP(ct3);
         } else {
         __syncthreads();                       // everyone finished reading the previous stage
         CT_STAMP(ct1);
         if (r == 0) store_input();
         CT_STAMP(cta);
-#if CONV_EXPERIMENT == 1          // timing experiment (wrong results): weights staged at the first stage only
-        if (st == st0) store_w();
-#elif CONV_EXPERIMENT == 2        // timing experiment (wrong results): no second barrier
         store_w();
-#else
-        store_w();
-#endif
         CT_STAMP(ctw);
         // issue order: vmcnt retires in order, so the (older) halo loads must not sit between a weight
         // load and the store_w that waits for it (see conv_mfma.hip)
         if (r == 0 && st + KS < st1) load_input(st / KS + 1);
-#if CONV_EXPERIMENT != 1
         if (st + 1 < st1) load_w(st + 1);      // in flight while this stage computes
-#endif
         CT_STAMP(ct2);
-#if CONV_EXPERIMENT != 2
         __syncthreads();
-#endif
         CT_STAMP(ct3);
         }
         const bf16x8* ap = lds_a + lh * PSP + aPix + (r + OFF) * T::HTW + OFF;
         const bf16x8* bp = lds_w + wbuf * W_UNITS + lh * NT + li;
-        // WDB: slab st+1 goes to the other buffer ONE 16-byte store per tap, between the MFMAs of this stage (a burst of stores
-        // in front of the loop makes the loop's first fragment reads wait for the whole burst: LDS operations of a wave complete
-        // in order), and each staging register is reloaded with its unit of slab st+2 right behind its store — a full stage
-        // ahead of its next use.  Past the last stage both touch valid but unused locations (no branch in the loop).
-        [[maybe_unused]] const bf16x8* wst2 = nullptr;
-        if constexpr (WDB) {
-            const int sn = st + 2 < st1 ? st + 2 : st1 - 1;
-            wst2 = a.wp + (size_t)((sn % KS) * KS * (KCH / 16) + (sn / KS) * KB) * 2 * NCH;
-        }
         if (NS == 1) __builtin_amdgcn_iglp_opt(0);         // interleave the LDS fragment reads with the MFMAs
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
-                if constexpr (WDB) {
-                    if (kb == 0) {
-#pragma unroll
-                        for (int i = 0; i < WPT; ++i)
-                            if (i % KS == s && (W_UNITS % 256 == 0 || tid + i * 256 < W_UNITS)) {
-                                lds_w[(wbuf ^ 1) * W_UNITS + tid + i * 256] = wreg[i];
-                                wreg[i] = wst2[wbase[i]];
-                            }
-                    }
-                }
                 if (NS == 1) {
                     bf16x8 bv[NB];
 #pragma unroll
@@ -493,11 +424,7 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
         epilogue_store<H, NT, NCH, EPI_PLAIN, float, NS == 1>(acc[tl], nullptr, a.out + (size_t)blockIdx.z * a.sliceFloats, nullptr, smem, a.B,
                                                               mt, n0, img0, ty0, tx0, numTiles);
     } else {
-#if CONV_EXPERIMENT == 3          // timing experiment (wrong results): no BatchNorm partials in the forward epilogue
-        if constexpr (NS == 1) epilogue_store<H, NT, NCH, EPI == EPI_BIAS_BNSTAT ? EPI_BIAS_RELU : EPI, __bf16, true>(acc[tl], a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0, numTiles);
-#else
         if constexpr (NS == 1) epilogue_store<H, NT, NCH, EPI, __bf16, true>(acc[tl], a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0, numTiles);
-#endif
         else epilogue_store<H, NT, NCH, EPI>(acc[tl], a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0, numTiles);
     }
     }
@@ -597,7 +524,7 @@ template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT = 1, int KS = 5, 
 static int run_bf16_ns(const ConvBf16Args& a, hipStream_t st) {
     using T = Tile<H>;
     constexpr int KCB = Bf16Chunk<KCH, NS, MT>::KCB;
-    constexpr int WBUF = (NS == 1 && (BF16_WDMA != 0 || BF16_WDB != 0)) ? 2 : 1;          // double-buffered weight slabs
+    constexpr int WBUF = (NS == 1 && BF16_WDMA != 0) ? 2 : 1;          // LDS-DMA weight slabs are double-buffered
     constexpr int STAGE = (MT * NS * (KCB / 8) * Bf16Geom<H, KCB / 8>::PSP + WBUF * NS * KS * (KCB / 16) * 2 * NT) * 16;
     constexpr int EPI_BYTES = (8 * NT > 4 * 32 * 36 ? 8 * NT : 4 * 32 * 36) * 4;
     constexpr int SMEM = STAGE > EPI_BYTES ? STAGE : EPI_BYTES;
@@ -628,13 +555,8 @@ int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, c
     if (width == 64) {
         switch (layer) {
             case 1: return run_bf16<32, 64, 32, 64, EPI_BIAS_BNSTAT>(a, st);
-#if BF16_NT128       // experiment: 128 output channels per workgroup (8 accumulator tiles per wave, 0.75 LDS fragment reads per MFMA)
-            case 2: if (ns == 1) return run_bf16<64, 128, 16, 128, EPI_BIAS_BNSTAT>(a, st); else return run_bf16<64, 128, 16, 64, EPI_BIAS_BNSTAT>(a, st);
-            case 3: if (ns == 1) return run_bf16<128, 256, 8, 128, EPI_BIAS_BNSTAT>(a, st); else return run_bf16<128, 256, 8, 64, EPI_BIAS_BNSTAT>(a, st);
-#else
             case 2: return run_bf16<64, 128, 16, 64, EPI_BIAS_BNSTAT>(a, st);
             case 3: return run_bf16<128, 256, 8, 64, EPI_BIAS_BNSTAT>(a, st);
-#endif
             case 4: {     // 4x4 images: split-K x4 over the channel chunks so that 256 workgroups exist at B=256
                 const int64_t slice = (int64_t)B * 16 * 128;
                 a.out = ws; a.sliceFloats = slice;

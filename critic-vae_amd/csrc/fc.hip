@@ -318,7 +318,10 @@ __global__ __launch_bounds__(256) void bgemm_tr_kernel(BGemmArgs a) {
         for (int j = 0; j < NBLK; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-    constexpr int AU = A_F32 ? (BT * MC) / 256 : (BT * MC / 8 + 255) / 256;        // per-thread staging items
+    // fp32 A (decoder_input: [zcat | 1], 34 real columns of MC = 64): only the real columns travel — item q = (row q / AC, column
+    // q % AC); the LDS columns past them are zeroed once and never written again (half the loads and stores of a dense tile)
+    constexpr int AC = 34;
+    constexpr int AU = A_F32 ? (BT * AC) / 256 : (BT * MC / 8 + 255) / 256;        // per-thread staging items
     constexpr int BU = B_F32 ? (BT * NC / 4) / 256 : (BT * NC / 8 + 255) / 256;
     float ra32[A_F32 ? AU : 1];
     bf16x8 ra16[A_F32 ? 1 : AU];
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(256) void bgemm_tr_kernel(BGemmArgs a) {
         if constexpr (A_F32) {
 #pragma unroll
             for (int i = 0; i < AU; ++i) {
-                const int q = tid + i * 256, r = q / MC, c = q % MC, b = b0 + r;
+                const int q = tid + i * 256, r = q / AC, c = q % AC, b = b0 + r;
                 const bool ok = b < a.B && c < a.a_cols;
                 const float l = a.A[ok ? (size_t)b * a.lda + c : 0];
                 ra32[i] = ok ? l : ((b < a.B && c == a.a_cols) ? 1.0f : 0.f);
@@ -364,12 +367,16 @@ __global__ __launch_bounds__(256) void bgemm_tr_kernel(BGemmArgs a) {
             }
         }
     };
+    if constexpr (A_F32) {
+        static_assert((BT * AC) % 256 == 0 && AC <= MC, "whole staging rounds of the real columns");
+        for (int q = tid; q < BT * MC; q += 256) lds_a[q] = (__bf16)0.f;      // columns >= AC stay zero
+    }
     fetch(0);
     for (int b0 = 0; b0 < a.B; b0 += BT) {
         __syncthreads();
         if constexpr (A_F32) {
 #pragma unroll
-            for (int i = 0; i < AU; ++i) lds_a[tid + i * 256] = (__bf16)ra32[i];
+            for (int i = 0; i < AU; ++i) { const int q = tid + i * 256; lds_a[(q / AC) * MC + q % AC] = (__bf16)ra32[i]; }
         } else {
 #pragma unroll
             for (int i = 0; i < AU; ++i) {

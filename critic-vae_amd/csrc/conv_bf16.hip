@@ -191,6 +191,8 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     constexpr int NQ = T::HP * OCT, IPT = (NQ + 255) / 256;
     f32x4 ireg[NS == 1 ? 1 : 2 * IPT];
     bf16x8 breg[NS == 1 ? MT * IPT : 1];
+    unsigned okmask = 0u;                       // NS == 1: which staged units of breg are real (the others are zero padding)
+    static_assert(NS != 1 || MT * IPT <= 32, "one validity bit per staged unit");
     // element index of each staged unit's first channel at chunk 0 (-1: zero padding / past the batch / no unit)
     int ebase[MODE == MODE_UP_DGRAD ? 1 : MT * IPT];
     if constexpr (MODE != MODE_UP_DGRAD) {
@@ -228,11 +230,12 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
                 e = ok ? (size_t)(ebase[tl * IPT + i] + cc * KCB) : 0;
             }
             if constexpr (NS == 1) {
-                bf16x8 z;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) z[k] = (__bf16)0.f;
-                const bf16x8 ld = Act<__bf16>::ld8(a.in, e);          // e = 0 when !ok: the load itself is unconditional (no branch per unit)
-                breg[tl * IPT + i] = ok ? ld : z;
+                // e = 0 when !ok: the load itself is unconditional (no branch per unit).  The zero-select happens in store_input,
+                // a chunk later: selecting here makes the compiler wait for the loads right behind their issue (s_waitcnt
+                // vmcnt(0) in front of the MFMA loop) — the whole HBM latency of the next chunk's tiles was exposed at every
+                // chunk boundary instead of travelling under five stages of MFMAs
+                breg[tl * IPT + i] = Act<__bf16>::ld8(a.in, e);
+                okmask = ok ? (okmask | (1u << (tl * IPT + i))) : (okmask & ~(1u << (tl * IPT + i)));
             } else {
                 f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
                 if (ok) { lo = *reinterpret_cast<const f32x4*>(a.in + e); hi = *reinterpret_cast<const f32x4*>(a.in + e + 4); }
@@ -249,7 +252,10 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
             if (!(NQ % 256 == 0 || q < NQ)) continue;
             const int oct = q % OCT, hp = q / OCT;
             if constexpr (NS == 1) {
-                lds_a[tl * A_UNITS + oct * PSP + hp] = breg[tl * IPT + i];
+                bf16x8 z;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) z[k] = (__bf16)0.f;
+                lds_a[tl * A_UNITS + oct * PSP + hp] = ((okmask >> (tl * IPT + i)) & 1u) ? breg[tl * IPT + i] : z;
             } else {
                 const f32x4 lo = ireg[2 * i], hi = ireg[2 * i + 1];
                 bf16x8 u0, u1, u2;

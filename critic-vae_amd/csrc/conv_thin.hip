@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256, PASS == 1 ? 3 : 2) void e1_fwd_bf16_kernel(   
     }
     constexpr int NIT = (HR_ * HWX + 255) / 256;
     float v0[NIT], v1[NIT], v2[NIT];
-    auto fetch = [&](int strip) {                // all loads first (clamped address + select), the LDS writes follow later
+    unsigned okm = 0u;                          // validity bit per staged unit (frame pixels vs zero padding)
+    auto fetch = [&](int strip) {                // all loads first (clamped address), the LDS writes (+ zero select) follow later
         const int ib = strip / (SX * SY), t = strip % (SX * SY);
         const int ty0 = (t / SX) * SR, tx0 = (t % SX) * SW;
 #pragma unroll
@@ -203,8 +204,11 @@ __global__ __launch_bounds__(256, PASS == 1 ? 3 : 2) void e1_fwd_bf16_kernel(   
             const int gy = ty0 + hy - 2, gx = tx0 + hx - 2;
             const bool ok = q < HR_ * HWX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H;
             const size_t e = ok ? ((size_t)(ib * 3) * H + gy) * H + gx : 0;
-            const float a0 = x[e], a1v = x[e + (size_t)H * H], a2 = x[e + 2 * (size_t)H * H];
-            v0[i] = ok ? a0 : 0.f; v1[i] = ok ? a1v : 0.f; v2[i] = ok ? a2 : 0.f;
+            // raw values now, the zero padding is selected when the strip is staged (a turn later): a select HERE makes the
+            // compiler wait for the loads right behind their issue — 2.0-2.6 k of a strip's 6.6-7.5 k cycles were that wait
+            // (profiles/experiments/e1_timing.py), the prefetch hid nothing
+            v0[i] = x[e]; v1[i] = x[e + (size_t)H * H]; v2[i] = x[e + 2 * (size_t)H * H];
+            okm = ok ? (okm | (1u << i)) : (okm & ~(1u << i));
         }
     };
     if ((int)blockIdx.x < numStrips) fetch(blockIdx.x);
@@ -215,7 +219,8 @@ __global__ __launch_bounds__(256, PASS == 1 ? 3 : 2) void e1_fwd_bf16_kernel(   
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int q = tid + i * 256;
-            if (q < HR_ * HWX) { bf16x4 u; u[0] = (__bf16)v0[i]; u[1] = (__bf16)v1[i]; u[2] = (__bf16)v2[i]; u[3] = (__bf16)0.f; lds_x[q] = u; }
+            const bool ok = (okm >> i) & 1u;
+            if (q < HR_ * HWX) { bf16x4 u; u[0] = (__bf16)(ok ? v0[i] : 0.f); u[1] = (__bf16)(ok ? v1[i] : 0.f); u[2] = (__bf16)(ok ? v2[i] : 0.f); u[3] = (__bf16)0.f; lds_x[q] = u; }
         }
         __syncthreads();
         if (strip + (int)gridDim.x < numStrips) fetch(strip + gridDim.x);
@@ -352,7 +357,7 @@ struct E1Fuse { const float *y, *a, *da, *coef, *bcoef, *w, *bias; };     // w, 
 // (FUSE: thread = (channel quad, window column, window row): the window's four y quads in rd, a and da quads in rf)
 template <int H, bool FUSE>
 __device__ __forceinline__ void e1_wgrad_fetch(const ThinWgradArgs& a, const E1Fuse& fu, int mt, float (&rx)[(3 * Tile<H>::HPI + 255) / 256],
-                                               f32x4 (&rd)[4], f32x4 (&rf)[2]) {
+                                               f32x4 (&rd)[4], f32x4 (&rf)[2], unsigned& okm) {
     using T = Tile<H>;
     const int tid = threadIdx.x;
     const int ib = mt / T::TILES_PER_IMG, tileInImg = mt % T::TILES_PER_IMG;
@@ -363,8 +368,10 @@ __device__ __forceinline__ void e1_wgrad_fetch(const ThinWgradArgs& a, const E1F
         const int c = q / T::HPI, hp = q % T::HPI;
         const int gy = ty0 + hp / T::HTW - 2, gx = tx0 + hp % T::HTW - 2;
         const bool ok = q < 3 * T::HPI && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H;
-        const float l = a.a0[ok ? ((size_t)(ib * 3 + c) * H + gy) * H + gx : 0];      // no branch around the load
-        rx[i] = ok ? l : 0.f;
+        // no branch around the load, and no select behind it either: the zero padding is selected when the tile is staged
+        // (a select here makes the compiler wait for the load at once, and the prefetch hides nothing)
+        rx[i] = a.a0[ok ? ((size_t)(ib * 3 + c) * H + gy) * H + gx : 0];
+        okm = ok ? (okm | (1u << i)) : (okm & ~(1u << i));
     }
     if constexpr (FUSE) {
         const int c4 = tid & 7, gy = ty0 + 2 * (tid >> 7), gx = tx0 + 2 * ((tid >> 3) & 15);
@@ -414,6 +421,7 @@ __global__ __launch_bounds__(256, THIN_F32_OCC) void e1_wgrad_kernel(ThinWgradAr
     // MFMAs of the current tile run; LDS is refilled between two barriers
     constexpr int XQ = (3 * T::HPI + 255) / 256;
     float rx[XQ];
+    unsigned okm = 0u;                     // validity bit per staged x unit (frame pixel vs zero padding)
     f32x4 rd[4], rf[2];
     float bsc[4], bsh[4], bmean[4], binv[4], bk1[4], bk2[4];          // FUSE: this thread's four channels
     if constexpr (FUSE) {
@@ -424,13 +432,13 @@ __global__ __launch_bounds__(256, THIN_F32_OCC) void e1_wgrad_kernel(ThinWgradAr
             bk1[e] = fu.bcoef[c * 2]; bk2[e] = fu.bcoef[c * 2 + 1];
         }
     }
-    if (t0 < t1) e1_wgrad_fetch<H, FUSE>(a, fu, t0, rx, rd, rf);
+    if (t0 < t1) e1_wgrad_fetch<H, FUSE>(a, fu, t0, rx, rd, rf, okm);
     for (int mt = t0; mt < t1; ++mt) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < XQ; ++i) {
             const int q = tid + i * 256;
-            if (q < 3 * T::HPI) lds_x[(q / T::HPI) * T::PS + q % T::HPI] = rx[i];
+            if (q < 3 * T::HPI) lds_x[(q / T::HPI) * T::PS + q % T::HPI] = ((okm >> i) & 1u) ? rx[i] : 0.f;
         }
         if constexpr (FUSE) {
             f32x4 d[4];
@@ -462,7 +470,7 @@ __global__ __launch_bounds__(256, THIN_F32_OCC) void e1_wgrad_kernel(ThinWgradAr
             }
         }
         __syncthreads();
-        if (mt + 1 < t1) e1_wgrad_fetch<H, FUSE>(a, fu, mt + 1, rx, rd, rf);
+        if (mt + 1 < t1) e1_wgrad_fetch<H, FUSE>(a, fu, mt + 1, rx, rd, rf, okm);
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const int mm = wave * 32 + 2 * kk + lh;
@@ -544,6 +552,7 @@ __global__ __launch_bounds__(256, E1W_OCC) void e1_wgrad_bf16_kernel(ThinWgradAr
     int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
     constexpr int XQ = (NPXH + 255) / 256;
     float rx[XQ][3];
+    unsigned okm = 0u;                               // validity bit per staged strip unit
     bf16x8 rd[2];
     bf16x8 rp;                                       // FUSE: 8 channels of one pooled pixel of a0 (threads 0..127) / d_a0 (128..255)
     bf16x8 bw[7];                                    // FUSE: the forward's K-packed B fragments
@@ -565,8 +574,9 @@ __global__ __launch_bounds__(256, E1W_OCC) void e1_wgrad_bf16_kernel(ThinWgradAr
             const int gy = ty0 + hy - 2, gx = tx0 + hx - 2;
             const bool ok = q < NPXH && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H;
             const size_t e = ok ? ((size_t)(ib * 3) * H + gy) * H + gx : 0;
-            const float v0 = a.a0[e], v1 = a.a0[e + (size_t)H * H], v2 = a.a0[e + 2 * (size_t)H * H];
-            rx[i][0] = ok ? v0 : 0.f; rx[i][1] = ok ? v1 : 0.f; rx[i][2] = ok ? v2 : 0.f;
+            // raw values; the zero padding is selected at staging time (see e1_fwd_bf16_kernel: a select here exposes the load latency)
+            rx[i][0] = a.a0[e]; rx[i][1] = a.a0[e + (size_t)H * H]; rx[i][2] = a.a0[e + 2 * (size_t)H * H];
+            okm = ok ? (okm | (1u << i)) : (okm & ~(1u << i));
         }
         if constexpr (FUSE) {
             const int t = tid & 127, pp = t >> 2, c8 = t & 3;            // pooled pixel pp = prow*16 + pcol of the tile's 2 x 16
@@ -588,7 +598,8 @@ __global__ __launch_bounds__(256, E1W_OCC) void e1_wgrad_bf16_kernel(ThinWgradAr
 #pragma unroll
         for (int i = 0; i < XQ; ++i) {
             const int q = tid + i * 256;
-            if (q < NPXH) { bf16x4 u; u[0] = (__bf16)rx[i][0]; u[1] = (__bf16)rx[i][1]; u[2] = (__bf16)rx[i][2]; u[3] = (__bf16)0.f; lds_x[q] = u; }
+            const bool ok = (okm >> i) & 1u;
+            if (q < NPXH) { bf16x4 u; u[0] = (__bf16)(ok ? rx[i][0] : 0.f); u[1] = (__bf16)(ok ? rx[i][1] : 0.f); u[2] = (__bf16)(ok ? rx[i][2] : 0.f); u[3] = (__bf16)0.f; lds_x[q] = u; }
         }
         if constexpr (FUSE) {
             *reinterpret_cast<bf16x8*>(lds_p + (size_t)tid * 8) = rp;       // [a0 | d_a0][pp][32]: thread order IS the layout
@@ -856,6 +867,7 @@ __global__ __launch_bounds__(256, 2) void d4_fwd_pc_f32_kernel(const float* __re
     const int numTiles = B * TPI;
     constexpr int NQ = HP * 8, IPT = (NQ + 255) / 256;          // 16-byte units of the halo tile
     f32x4 ra[IPT];
+    unsigned okm = 0u;                          // validity bit per staged unit (see e1_fwd_bf16_kernel)
     auto fetch = [&](int tile) {
         const int ib = tile / TPI, t = tile % TPI;
         const int sy0 = (t / TXN) * 8 - 1, sx0 = (t % TXN) * 16 - 1;
@@ -864,8 +876,8 @@ __global__ __launch_bounds__(256, 2) void d4_fwd_pc_f32_kernel(const float* __re
             const int q = tid + i * 256, c4 = q & 7, sp = q >> 3;
             const int sy = sy0 + sp / HW, sx = sx0 + sp % HW;
             const bool ok = sp < HP && (unsigned)sy < (unsigned)HS && (unsigned)sx < (unsigned)HS;
-            const f32x4 l = *reinterpret_cast<const f32x4*>(in + (ok ? ((size_t)(ib * HS + sy) * HS + sx) * 32 + c4 * 4 : 0));
-            ra[i] = ok ? l : f32x4{0.f, 0.f, 0.f, 0.f};
+            ra[i] = *reinterpret_cast<const f32x4*>(in + (ok ? ((size_t)(ib * HS + sy) * HS + sx) * 32 + c4 * 4 : 0));      // raw; zero select at staging
+            okm = ok ? (okm | (1u << i)) : (okm & ~(1u << i));
         }
     };
     const int G = gridDim.x;
@@ -882,7 +894,7 @@ __global__ __launch_bounds__(256, 2) void d4_fwd_pc_f32_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < IPT; ++i) {
             const int q = tid + i * 256;
-            if (q < NQ) *reinterpret_cast<f32x4*>(lds_a + (q >> 3) * AS + (q & 7) * 4) = ra[i];
+            if (q < NQ) *reinterpret_cast<f32x4*>(lds_a + (q >> 3) * AS + (q & 7) * 4) = ((okm >> i) & 1u) ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();       // also: every thread is past the previous tile's output rows, lds_o is free
         if (n + G < numTiles) fetch(tile_of(n + G));
@@ -1069,7 +1081,7 @@ __global__ __launch_bounds__(256) void d4_actbwd_kernel(const float* __restrict_
 
 // tile mt of the D4 backward into registers: dOut halo planes [3][20][36] (zero padded) and the o3 tile
 template <int H, typename AT>
-__device__ __forceinline__ void d4_bwd_fetch(const ThinWgradArgs& a, int mt, float (&rg)[(3 * 720 + 255) / 256], f32x4 (&ro)[4]) {
+__device__ __forceinline__ void d4_bwd_fetch(const ThinWgradArgs& a, int mt, float (&rg)[(3 * 720 + 255) / 256], f32x4 (&ro)[4], unsigned& okm) {
     constexpr int HS = H / 2, TPI = (HS / 8) * (HS / 16), G0 = 3 * 720;
     const int tid = threadIdx.x;
     const int ib = mt / TPI, t = mt % TPI;
@@ -1079,8 +1091,8 @@ __device__ __forceinline__ void d4_bwd_fetch(const ThinWgradArgs& a, int mt, flo
         const int q = tid + i * 256, c = q / 720, rem = q % 720;
         const int uy = 2 * sy0 - 2 + rem / 36, ux = 2 * sx0 - 2 + rem % 36;
         const bool ok = q < G0 && (unsigned)uy < (unsigned)H && (unsigned)ux < (unsigned)H;
-        const float l = a.a0[ok ? ((size_t)(ib * 3 + c) * H + uy) * H + ux : 0];
-        rg[i] = ok ? l : 0.f;
+        rg[i] = a.a0[ok ? ((size_t)(ib * 3 + c) * H + uy) * H + ux : 0];       // raw; the zero padding is selected at staging (see e1_wgrad_fetch)
+        okm = ok ? (okm | (1u << i)) : (okm & ~(1u << i));
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1116,8 +1128,9 @@ __global__ __launch_bounds__(256, THIN_F32_OCC) void d4_bwd_kernel(ThinWgradArgs
     // tile's G build and MFMAs run
     constexpr int GQ = (G0 + 255) / 256;
     float rg[GQ];
+    unsigned okm = 0u;
     f32x4 ro[4];
-    if (t0 < t1) d4_bwd_fetch<H, AT>(a, t0, rg, ro);
+    if (t0 < t1) d4_bwd_fetch<H, AT>(a, t0, rg, ro, okm);
     const int gsp = tid & 127, ghalf = tid >> 7, gsy = gsp >> 4, gsx = gsp & 15;
     for (int mt = t0; mt < t1; ++mt) {
         const int ib = mt / TPI, t = mt % TPI;
@@ -1126,7 +1139,7 @@ __global__ __launch_bounds__(256, THIN_F32_OCC) void d4_bwd_kernel(ThinWgradArgs
 #pragma unroll
         for (int i = 0; i < GQ; ++i) {
             const int q = tid + i * 256;
-            if (q < G0) lds_g0[q] = rg[i];
+            if (q < G0) lds_g0[q] = ((okm >> i) & 1u) ? rg[i] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1134,7 +1147,8 @@ __global__ __launch_bounds__(256, THIN_F32_OCC) void d4_bwd_kernel(ThinWgradArgs
             *reinterpret_cast<f32x4*>(lds_o + (q >> 3) * 32 + (q & 7) * 4) = ro[i];
         }
         __syncthreads();
-        if (mt + 1 < t1) d4_bwd_fetch<H, AT>(a, mt + 1, rg, ro);
+        if (mt + 1 < t1) d4_bwd_fetch<H, AT>(a, mt + 1, rg, ro, okm);
+        __builtin_amdgcn_sched_barrier(0);            // keep the loads HERE (the scheduler sank them below the MFMAs: nothing was prefetched)
         // G[src][(r*5+s)*3+co] = sum of dOut over the 2x2 block of src shifted by the tap: thread =
         // (src pixel, half of the 15 (co, r) pairs); the five s taps of a pair share six column sums
 #pragma unroll

@@ -1045,7 +1045,7 @@ template <int CIN, int COUT, int HS>
 static int run_up_wgrad_bf16_main(int B, const float* in, const float* dout, float* slab, int Smax, int* S_out, hipStream_t st) {
     using T = UpWgTile<HS>;
     const int numTiles = cdiv(B, 8) * T::TILES_PER_GRP;
-    int S = cdiv(384, (CIN / 32) * (COUT / 32));
+    int S = cdiv(2 * cvae_num_cus(), (CIN / 32) * (COUT / 32));     // two resident workgroups per CU, equal tile counts
     if (S > Smax) S = Smax;
     if (S > numTiles) S = numTiles;
     if (S < 1) S = 1;

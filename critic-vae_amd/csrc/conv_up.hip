@@ -301,18 +301,28 @@ __global__ __launch_bounds__(256) void conv_up_dgrad_kernel(UpArgs a) {
             }
     }
     float* out = KSPLIT > 1 ? a.out + (size_t)blockIdx.z * a.sliceFloats : a.out;
+    // the ReLU mask values of one 32-channel block are all requested before the first store: `out` and `aux`
+    // may alias as far as the compiler knows, and a load behind each store is one memory round trip per element
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int nb = 0; nb < NB; ++nb) {
+        size_t o[16];
+        float mk[16];
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int mm = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
             const int im = mm / (T::TH * T::TW), rem = mm % (T::TH * T::TW), ib = img0 + im;
-            if (ib >= a.B) continue;
-            const size_t o = ((size_t)(ib * HS + ty0 + rem / T::TW) * HS + tx0 + rem % T::TW) * CIN + n0 + nb * 32 + li;
-            float x = acc[nb][v];
-            if (KSPLIT == 1) x = a.aux[o] > 0.f ? x : 0.f;
-            out[o] = x;
+            o[v] = ((size_t)(ib * HS + ty0 + rem / T::TW) * HS + tx0 + rem % T::TW) * CIN + n0 + nb * 32 + li;
+            if (KSPLIT == 1) mk[v] = a.aux[ib < a.B ? o[v] : 0];
         }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int mm = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            if (img0 + mm / (T::TH * T::TW) >= a.B) continue;
+            float x = acc[nb][v];
+            if (KSPLIT == 1) x = mk[v] > 0.f ? x : 0.f;
+            out[o[v]] = x;
+        }
+    }
 }
 
 // split-K finish kernels
@@ -572,15 +582,20 @@ static int run_up_wgrad(int B, const float* in, const float* dout, float* dw, fl
     using T = UpTile64<HS>;
     const int numTiles = cdiv(B, T::IMGS) * T::TILES_PER_IMG;
     const int bps = (CIN / 32) * (COUT / 32);
-    int S = cdiv(384, bps);
+    // splits: a whole number of workgroups per CU (one for the fp32 kernel, two for the bf16 one) with equal tile
+    // counts -- 1.5 per CU leaves a third of the CUs with twice the work of the rest
+    const int cus = cvae_num_cus();
+    int Scap = cdiv(2 * cus, bps);
+    if (Scap > numTiles) Scap = numTiles;
+    int S = cdiv(cus, bps);
     if (S > numTiles) S = numTiles;
     const int tps = cdiv(numTiles, S);
     S = cdiv(numTiles, tps);
     const int64_t nc = (int64_t)36 * CIN * COUT, row = nc + COUT;
     // ws = [S slabs | 16 mid rows | reduced row]
-    if (need) { *need = (int64_t)(S + 17) * row; return 0; }
+    if (need) { *need = (int64_t)(Scap + 17) * row; return 0; }
     if (bf16_layer) {          // precision mode 1: same slab rows from the bf16-MFMA kernel (conv_bf16.hip), S' <= S of them
-        int rc = launch_up_wgrad_bf16_main(bf16_layer, bf16_width, B, in, dout, ws, S, &S, st);
+        int rc = launch_up_wgrad_bf16_main(bf16_layer, bf16_width, B, in, dout, ws, Scap, &S, st);
         if (rc) return rc;
     } else {
         UpWgradArgs a{in, dout, ws, B, numTiles, tps};

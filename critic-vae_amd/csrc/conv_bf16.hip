@@ -667,12 +667,12 @@ int launch_conv_up_dgrad_bf16(int layer, int width, int ns, int B, const float* 
 // The bias gradient (column sums of dy) is one more MFMA per 8 pixel groups against an all-ones A operand.
 // ---------------------------------------------------------------------------------------------
 
-template <int H> struct WtTile {
+template <int H, int HALO = 2, int NP = 256> struct WtTile {          // HALO 2 / 256 pixels: 5x5 layers;  HALO 1 / 128: collapsed up-convs
     static constexpr int TW = H < 32 ? H : 32;
-    static constexpr int TH = H < 256 / TW ? H : 256 / TW;
-    static constexpr int IMGS = H == 4 ? 8 : 256 / (TW * TH);
+    static constexpr int TH = H < NP / TW ? H : NP / TW;
+    static constexpr int IMGS = H == 4 ? (NP >= 128 ? 8 : NP / 16) : NP / (TW * TH);
     static constexpr int NPX = IMGS * TH * TW, KG = NPX / 16;
-    static constexpr int HTW = TW + 4, HTH = TH + 4, HPI = HTW * HTH, HP = IMGS * HPI;
+    static constexpr int HTW = TW + 2 * HALO, HTH = TH + 2 * HALO, HPI = HTW * HTH, HP = IMGS * HPI;
     static constexpr int TILES_X = H / TW, TPI = TILES_X * (H / TH);
     // lane half h (k = 8h..8h+7) and the second read t (k += 4) move by these many dy pixels / halo pixels
     static constexpr int DH = 8, DT = 4;
@@ -930,95 +930,101 @@ int launch_conv_wgrad_bf16(int layer, int width, int B, const float* in, const f
 // ---------------------------------------------------------------------------------------------
 // weight gradients of the phase-collapsed up-convs (D1..D3) on the bf16 MFMA:
 //   dwc[p][t][ci][co] = sum_{img,y,x} in[img][y+a-1][x+b-1][ci] * dout[img][2y+py][2x+px][co],  t = a*3+b
-// Same operand scheme as conv5x5_wgrad_bf16_kernel (k over 8 images, lane halves = adjacent pixels);
-// workgroup = 8 images x 16 low-res pixels x 32 ci x 32 co, wave w = output phase w with its 9 taps
-// (as conv_up_wgrad_kernel).  The slab row [36][CIN][COUT] | bias[COUT] is what conv_up.hip's
-// reduce + expand_dw_kernel consume.
+// Same scheme as conv5x5_wgrad_tr_kernel: the contraction runs over PIXELS, both operands are transposed LDS reads
+// (ds_read_b64_tr_b16) of tiles staged as plain 16-byte copies, one tile ahead in registers.  Workgroup = 128 low-res
+// pixels x 32 ci x 32 co; the dy tile holds the four phase images [p][pixel][32 co] (dout[2y+py][2x+px]); wave w = output
+// phase w with its 9 taps (as conv_up_wgrad_kernel).  Round 3: the earlier version contracted over 8 images, transposed
+// 8x8 blocks in registers while staging and had no tile in flight (83 / 45 / 45 us at B = 2048).
+// The slab row [36][CIN][COUT] | bias[COUT] is what conv_up.hip's reduce + expand_dw_kernel consume.
 // ---------------------------------------------------------------------------------------------
-template <int HS> struct UpWgTile {
-    static constexpr int TW = HS < 8 ? HS : 8, TH = 16 / TW;              // 16 low-res pixels
-    static constexpr int HTW = TW + 2, HTH = TH + 2, HP = HTW * HTH, NPX = 16;
-    static constexpr int TILES_X = HS / TW, TILES_Y = HS / TH, TILES_PER_GRP = TILES_X * TILES_Y;
-};
+#ifndef UPW_NP
+#define UPW_NP 64
+#endif
+template <int HS> using UpWgTile = WtTile<HS, 1, UPW_NP>;        // low-res pixels per tile, halo 1
 
 template <int CIN, int COUT, int HS>
 __global__ __launch_bounds__(256, 2) void conv_up_wgrad_bf16_kernel(WgradBf16Args a) {
     using T = UpWgTile<HS>;
     constexpr int H = 2 * HS;
-    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[(T::HP + 4 * T::NPX) * 32 * 16];
-    bf16x8* lds_in = reinterpret_cast<bf16x8*>(smem_raw);       // [halo pixel][32 ci]
-    bf16x8* lds_d = lds_in + T::HP * 32;                        // [phase][pixel][32 co]
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[(T::HP + 4 * T::NPX) * 64];
+    __bf16* lds_in = reinterpret_cast<__bf16*>(smem_raw);       // [halo pixel][32 ci], 64-byte rows
+    __bf16* lds_d = lds_in + T::HP * 32;                        // [phase][low-res pixel][32 co]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int split = blockIdx.x, ci0 = blockIdx.y * 32, n0 = blockIdx.z * 32;
-    const int oct = tid & 3;
+    const int g = lane >> 4, h = g >> 1, laneoff = ((lane & 15) >> 2) * 32 + 16 * (g & 1) + 4 * (lane & 3);
+    const int ibase = h * T::IH * 32 + laneoff, dbase = wave * T::NPX * 32 + h * T::DH * 32 + laneoff;
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-    float bsum[8];
+    float bsum[8];                                              // column sums of this thread's dout units (channels 8*(tid&3)..+7)
 #pragma unroll
     for (int c = 0; c < 8; ++c) bsum[c] = 0.f;
     bf16x8 zero8;
 #pragma unroll
     for (int c = 0; c < 8; ++c) zero8[c] = (__bf16)0.f;
+
+    constexpr int IU = T::HP * 4, NI = (IU + 255) / 256, ND = 4 * T::NPX * 4 / 256;
+    constexpr int PPT = T::NPX / 64;                            // low-res pixels per thread: dout unit i = PPT * phase + j
+    static_assert(ND == 4 * PPT && T::NPX % 64 == 0, "unit q = tid + 256 i: phase i / PPT, pixel (tid >> 2) + 64 (i % PPT), octet tid & 3");
+    bf16x8 rin[NI], rdo[ND];
+    unsigned okm = 0u;                          // bit i: rin[i] valid, bit 8 + i: rdo[i] valid.  Out-of-range units are fetched from
+                                                // element 0 and zeroed when staged (a select here waits for the loads on the spot)
+    auto fetch = [&](int mt) {
+        const int grp = mt / T::TPI, t = mt % T::TPI;
+        const int img0 = grp * T::IMGS, ty0 = (t / T::TILES_X) * T::TH, tx0 = (t % T::TILES_X) * T::TW;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int q = tid + i * 256, hp = q >> 2, oc = q & 3;
+            const int img = hp / T::HPI, rem = hp % T::HPI;
+            const int gy = ty0 + rem / T::HTW - 1, gx = tx0 + rem % T::HTW - 1, ib = img0 + img;
+            const bool ok = (IU % 256 == 0 || q < IU) && (unsigned)gy < (unsigned)HS && (unsigned)gx < (unsigned)HS && ib < a.B;
+            rin[i] = Act<__bf16>::ld8(a.in, ok ? ((size_t)(ib * HS + gy) * HS + gx) * CIN + ci0 + oc * 8 : 0);
+            okm = ok ? (okm | (1u << i)) : (okm & ~(1u << i));
+        }
+        // dout unit i = PPT p + j: low-res pixel (tid >> 2) + 64 j of phase p -- one address per pixel, the phase is a constant offset
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int px = (tid >> 2) + 64 * j, img = px / (T::TH * T::TW), rem = px % (T::TH * T::TW), ib = img0 + img;
+            const bool ok = ib < a.B;
+            const size_t e = ok ? ((size_t)(ib * H + 2 * (ty0 + rem / T::TW)) * H + 2 * (tx0 + rem % T::TW)) * COUT + n0 + (tid & 3) * 8 : 0;
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                rdo[PPT * ph + j] = Act<__bf16>::ld8(a.dout, e + (size_t)(((ph >> 1) * H + (ph & 1)) * COUT));
+                okm = ok ? (okm | (256u << (PPT * ph + j))) : (okm & ~(256u << (PPT * ph + j)));
+            }
+        }
+    };
     const int t0 = split * a.tilesPerSplit;
     int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
+    if (t0 < t1) fetch(t0);
     for (int mt = t0; mt < t1; ++mt) {
-        const int grp = mt / T::TILES_PER_GRP, t = mt % T::TILES_PER_GRP;
-        const int img0 = grp * 8, ty0 = (t / T::TILES_X) * T::TH, tx0 = (t % T::TILES_X) * T::TW;
-        __syncthreads();
-        for (int q = tid; q < T::HP * 4; q += 256) {
-            const int hp = q >> 2;
-            const int gy = ty0 + hp / T::HTW - 1, gx = tx0 + hp % T::HTW - 1;
-            const bool inb = (unsigned)gy < (unsigned)HS && (unsigned)gx < (unsigned)HS;
-            bf16x8 v[8];
+        __syncthreads();                        // every wave is done reading the previous tile
 #pragma unroll
-            for (int im = 0; im < 8; ++im) {
-                const bool ok = inb && img0 + im < a.B;
-                const size_t e = ok ? ((size_t)((img0 + im) * HS + gy) * HS + gx) * CIN + ci0 + oct * 8 : 0;
-                const bf16x8 l = Act<__bf16>::ld8(a.in, e);
-                v[im] = ok ? l : zero8;
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                bf16x8 u;
-#pragma unroll
-                for (int im = 0; im < 8; ++im) u[im] = v[im][c];
-                lds_in[hp * 32 + oct * 8 + c] = u;
-            }
+        for (int i = 0; i < NI; ++i) {
+            const int q = tid + i * 256;
+            if (IU % 256 == 0 || q < IU) *reinterpret_cast<bf16x8*>(lds_in + (size_t)q * 8) = (okm >> i) & 1u ? rin[i] : zero8;
         }
-        for (int q = tid; q < 4 * T::NPX * 4; q += 256) {
-            const int px = (q >> 2) % T::NPX, p = q / (4 * T::NPX);
-            const int oy = 2 * (ty0 + px / T::TW) + (p >> 1), ox = 2 * (tx0 + px % T::TW) + (p & 1);
-            bf16x8 v[8];
 #pragma unroll
-            for (int im = 0; im < 8; ++im) {
-                const bool ok = img0 + im < a.B;
-                const size_t e = ok ? ((size_t)((img0 + im) * H + oy) * H + ox) * COUT + n0 + oct * 8 : 0;
-                const bf16x8 l = Act<__bf16>::ld8(a.dout, e);
-                v[im] = ok ? l : zero8;
+        for (int i = 0; i < ND; ++i) {
+            const bf16x8 d = (okm >> (8 + i)) & 1u ? rdo[i] : zero8;
+            *reinterpret_cast<bf16x8*>(lds_d + (size_t)(tid + i * 256) * 8) = d;            // unit order IS [phase][pixel][octet]
 #pragma unroll
-                for (int c = 0; c < 8; ++c) bsum[c] += (float)v[im][c];
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                bf16x8 u;
-#pragma unroll
-                for (int im = 0; im < 8; ++im) u[im] = v[im][c];
-                lds_d[(p * T::NPX + px) * 32 + oct * 8 + c] = u;
-            }
+            for (int c = 0; c < 8; ++c) bsum[c] += (float)d[c];
         }
         __syncthreads();
-        const bf16x8* dph = lds_d + wave * T::NPX * 32 + li;
+        if (mt + 1 < t1) fetch(mt + 1);         // in flight while this tile computes
 #pragma unroll
-        for (int pp = 0; pp < T::NPX / 2; ++pp) {
-            const int py = pp / (T::TW / 2), px = (pp % (T::TW / 2)) * 2;
-            const bf16x8 bv = dph[(py * T::TW + px + lh) * 32];
-            const bf16x8* ip = lds_in + (py * T::HTW + px + lh) * 32 + li;
+        for (int kg = 0; kg < T::KG; ++kg) {    // 16 low-res pixels per MFMA; wave = output phase, nine taps each
+            const __bf16* dp = lds_d + dbase + T::pixbase(kg) * 32;
+            const bf16x8 bv = tr_frag(dp, dp + T::DT * 32);
+            const __bf16* ip = lds_in + ibase + T::halobase(kg) * 32;
 #pragma unroll
-            for (int t9 = 0; t9 < 9; ++t9)
-                acc[t9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ip[((t9 / 3) * T::HTW + t9 % 3) * 32], bv, acc[t9], 0, 0, 0);
+            for (int t9 = 0; t9 < 9; ++t9) {
+                const __bf16* q = ip + ((t9 / 3) * T::HTW + t9 % 3) * 32;
+                acc[t9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(q, q + T::IT * 32), bv, acc[t9], 0, 0, 0);
+            }
         }
     }
     float* out = a.slab + (size_t)split * (36 * CIN * COUT + COUT);
@@ -1044,7 +1050,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_wgrad_bf16_kernel(WgradBf16Arg
 template <int CIN, int COUT, int HS>
 static int run_up_wgrad_bf16_main(int B, const float* in, const float* dout, float* slab, int Smax, int* S_out, hipStream_t st) {
     using T = UpWgTile<HS>;
-    const int numTiles = cdiv(B, 8) * T::TILES_PER_GRP;
+    const int numTiles = cdiv(B, T::IMGS) * T::TPI;
     int S = cdiv(2 * cvae_num_cus(), (CIN / 32) * (COUT / 32));     // two resident workgroups per CU, equal tile counts
     if (S > Smax) S = Smax;
     if (S > numTiles) S = numTiles;

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, PASS == 1 ? 3 : 2) void e1_fwd_bf16_kernel(   
             const size_t e = ok ? ((size_t)(ib * 3) * H + gy) * H + gx : 0;
             // raw values now, the zero padding is selected when the strip is staged (a turn later): a select HERE makes the
             // compiler wait for the loads right behind their issue — 2.0-2.6 k of a strip's 6.6-7.5 k cycles were that wait
-            // (profiles/experiments/e1_timing.py), the prefetch hid nothing
+            // (clock64 stamps around the strip phases in a throw-away build), the prefetch hid nothing
             v0[i] = x[e]; v1[i] = x[e + (size_t)H * H]; v2[i] = x[e + 2 * (size_t)H * H];
             okm = ok ? (okm | (1u << i)) : (okm & ~(1u << i));
         }

@@ -247,6 +247,157 @@ static int run(const ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 4x4 images (decoder block D0 at 64x64 frames, vae_nets.py:117, and its input gradient): 51 % of the 25-tap MACs of a
+// 5x5 / pad-2 conv on a 4x4 image multiply zero padding.  Here the M tile is 32 IMAGES x two image rows (0,1) or (2,3),
+// wave w = column x = w (its 32 MFMA rows per image row are 32 images at ONE pixel position), so "tap outside the image"
+// is uniform: a kernel row r runs only for the image rows y with y+r-2 inside (workgroup-uniform: 7 of 10 row-stages per
+// chunk, the same for both row pairs; the kernel row that neither needs is not staged), taps s with x+s-2 outside are
+// skipped by the wave (3 or 4 of 5).  One staged input chunk and one weight slab serve both image rows.  LDS holds the 16 real pixels of the 32 images as
+// [channel plane][pixel][image] (no halo: every tap that runs is inside; lanes = consecutive images: conflict-free
+// operand reads).  Weight slabs, register prefetch, k order inside a tap (channels ascending) as in conv5x5_mfma_kernel;
+// always split-K over channel chunks (raw partial sums to slab z, the callers' finish kernels add them in fixed order).
+// ---------------------------------------------------------------------------------------------
+template <int KCH, int NCH, bool DGRAD, int NT, int KSPLIT>
+__global__ __launch_bounds__(256) void conv4x4_row_kernel(ConvArgs a) {
+    constexpr int NB = NT / 32;
+    constexpr int KC = KChunk<NT>::KC, KCP = KChunk<NT>::KCP, QPP = KC / 4;
+    constexpr int PXS = 33, PS = 16 * PXS + 2;                 // [pixel][32 images + 1], plane stride
+    constexpr int IN_FLOATS = KC * PS;
+    constexpr int W_FLOATS = DGRAD ? 5 * NT * KCP : 5 * KC * NT;
+    __shared__ __attribute__((aligned(16))) float smem[IN_FLOATS + W_FLOATS];
+    float* lds_in = smem;
+    float* lds_w = smem + IN_FLOATS;
+    static_assert(IN_FLOATS % 4 == 0, "weight slab stays 16-byte aligned");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int ya = (blockIdx.x & 1) * 2, img0 = (blockIdx.x >> 1) * 32, n0 = blockIdx.y * NT;   // image rows ya, ya + 1
+    const int r0 = ya == 0 ? 1 : 0, r1 = ya == 0 ? 4 : 3;              // kernel rows that at least one of the two image rows needs
+    const int s0 = wave < 2 ? 2 - wave : 0, s1 = wave > 1 ? 5 - wave : 4;   // taps whose input column wave+s-2 exists
+    const int aBase = lh * PS + li;
+    const int bBase = DGRAD ? (li * KCP + lh) : (lh * NT + li);
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][nb][v] = 0.f;
+
+    constexpr int WQ = 5 * KC * NT / 4, WPT = (WQ + 255) / 256;
+    f32x4 wreg[WPT];
+    auto load_w = [&](int cc, int r) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int q = tid + i * 256;
+            if (WQ % 256 == 0 || q < WQ) {
+                const float* src;
+                if (!DGRAD) {
+                    const int row = q / (NT / 4), c4 = q % (NT / 4);
+                    const int s = row / KC, kc = row % KC;
+                    src = a.w + (size_t)((r * 5 + s) * KCH + cc * KC + kc) * NCH + n0 + c4 * 4;
+                } else {
+                    const int c4 = q % QPP, rown = q / QPP;
+                    const int n = rown % NT, s = rown / NT;
+                    src = a.w + (size_t)((24 - (r * 5 + s)) * NCH + n0 + n) * KCH + cc * KC + c4 * 4;
+                }
+                wreg[i] = *reinterpret_cast<const f32x4*>(src);
+            }
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int q = tid + i * 256;
+            if (WQ % 256 == 0 || q < WQ) {
+                if (!DGRAD) {
+                    *reinterpret_cast<f32x4*>(lds_w + q * 4) = wreg[i];
+                } else {
+                    const int c4 = q % QPP, rown = q / QPP;
+                    float* d = lds_w + rown * KCP + c4 * 4;
+                    d[0] = wreg[i].x; d[1] = wreg[i].y; d[2] = wreg[i].z; d[3] = wreg[i].w;
+                }
+            }
+        }
+    };
+    constexpr int NQ = 512 * QPP, IPT = NQ / 256;              // 32 images x 16 pixels x KC channels
+    f32x4 ireg[IPT];
+    auto load_input = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int q = tid + i * 256, c4 = q % QPP, hp = q / QPP, ib = img0 + (hp >> 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ib < a.B) v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)ib * 16 + (hp & 15)) * KCH + cc * KC + c4 * 4);
+            ireg[i] = v;
+        }
+    };
+    auto store_input = [&]() {
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int q = tid + i * 256, c4 = q % QPP, hp = q / QPP;
+            float* d = lds_in + (c4 * 4) * PS + (hp & 15) * PXS + (hp >> 4);
+            d[0] = ireg[i].x; d[PS] = ireg[i].y; d[2 * PS] = ireg[i].z; d[3 * PS] = ireg[i].w;
+        }
+    };
+
+    static_assert((KCH / KC) % KSPLIT == 0, "split-K must divide the channel chunks");
+    constexpr int CPS = (KCH / KC) / KSPLIT;
+    const int c0 = blockIdx.z * CPS, c1 = c0 + CPS;
+    load_w(c0, r0);
+    load_input(c0);
+    for (int cc = c0; cc < c1; ++cc)
+        for (int r = r0; r <= r1; ++r) {
+            __syncthreads();                       // everyone finished reading the previous stage
+            if (r == r0) store_input();
+            store_w();
+            // the (older) input loads must not sit between a weight load and the store_w that waits for it
+            if (r == r0 && cc + 1 < c1) load_input(cc + 1);
+            if (r < r1) load_w(cc, r + 1);
+            else if (cc + 1 < c1) load_w(cc + 1, r0);
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int yi = ya + t + r - 2;                 // input row of image row ya + t under kernel row r
+                if ((unsigned)yi > 3u) continue;               // workgroup-uniform
+                const float* ap = lds_in + aBase + (yi * 4 + wave - 2) * PXS;
+                for (int s = s0; s <= s1; ++s) {
+                    const float* as = ap + s * PXS;
+                    const float* bs = lds_w + bBase + (DGRAD ? s * NT * KCP : s * KC * NT);
+#pragma unroll
+                    for (int j = 0; j < KC / 2; ++j) {
+                        const float av = as[(2 * j) * PS];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const float bv = DGRAD ? bs[nb * 32 * KCP + 2 * j] : bs[(2 * j) * NT + nb * 32];
+                            acc[t][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t][nb], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    // raw partial sums of slab z: row (image) (v&3) + 8 (v>>2) + 4 lh of the wave's 32, pixel (ya + t, wave), channel n0 + 32 nb + li
+    float* out = a.out + (size_t)blockIdx.z * a.sliceFloats;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int ib = img0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+                if (ib < a.B) out[((size_t)ib * 16 + (ya + t) * 4 + wave) * NCH + n0 + nb * 32 + li] = acc[t][nb][v];
+            }
+}
+
+template <int KCH, int NCH, bool DGRAD, int NT, int KSPLIT>
+static int run4x4(const ConvArgs& a, hipStream_t st) {
+    static_assert(KCH % KChunk<NT>::KC == 0 && NCH % NT == 0, "channel tiling");
+    cvae_probe_begin(st);
+    hipLaunchKernelGGL((conv4x4_row_kernel<KCH, NCH, DGRAD, NT, KSPLIT>), dim3(cdiv(a.B, 32) * 2, NCH / NT, KSPLIT), dim3(256), 0, st, a);
+    cvae_probe_end(st);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}
+
 // out[i] = relu(bias[i % C] + sum_z slab[z][i])   (split-K finish of the decoder head)
 template <typename AT>
 __global__ __launch_bounds__(256) void splitk_bias_relu_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
@@ -271,7 +422,13 @@ int launch_splitk_bias_relu(const float* slab, const float* bias, float* out, in
     return 0;
 }
 
-static constexpr int D0_KSPLIT = 4;
+#ifndef D0_KS
+#define D0_KS 8
+#endif
+#ifndef D0_DKS
+#define D0_DKS 4
+#endif
+static constexpr int D0_KSPLIT = D0_KS;
 int64_t conv_fwd_ws_floats(int layer, int width, int B) {
     if (layer != 4 || width != 64) return 0;
     const int64_t h = kLayers[4].h * (width / 64);
@@ -289,7 +446,7 @@ int launch_conv_fwd(int layer, int width, int B, const float* in, const float* w
             case 4: {     // D0: 4x4 images, K = 6400 -> split-K over channel chunks to fill the chip
                 const int64_t slice = (int64_t)B * 4 * 4 * 128;
                 a.out = ws; a.sliceFloats = slice;
-                int rc = run<256, 128, 4, false, false, 64, EPI_PLAIN, D0_KSPLIT>(a, st);
+                int rc = run4x4<256, 128, false, 64, D0_KSPLIT>(a, st);
                 if (rc) return rc;
                 hipLaunchKernelGGL(splitk_bias_relu_kernel<float>, dim3((unsigned)((slice / 4 + 255) / 256)), dim3(256), 0, st,
                                    ws, bias, out, slice / 4, slice, D0_KSPLIT, 128);
@@ -312,7 +469,7 @@ int launch_conv_fwd(int layer, int width, int B, const float* in, const float* w
 
 // D0 dgrad at 4x4 images is 256 workgroups only: split-K x2 over the co chunks when the caller
 // provides scratch (the training step does; the single-op entry point runs the unsplit kernel)
-static constexpr int D0_DGRAD_KSPLIT = 2;
+static constexpr int D0_DGRAD_KSPLIT = D0_DKS;
 int64_t conv_dgrad_ws_floats(int layer, int width, int B) {
     if (layer != 4 || width != 64) return 0;
     return (int64_t)D0_DGRAD_KSPLIT * B * 16 * kLayers[4].cin;
@@ -325,7 +482,7 @@ int launch_conv_dgrad(int layer, int width, int B, const float* dout, const floa
     if (width == 64 && layer == 4 && ws != nullptr) {
         const int64_t slice = (int64_t)B * 16 * 256;
         a.out = ws; a.sliceFloats = slice;
-        int rc = run<128, 256, 4, false, true, 32, EPI_PLAIN, D0_DGRAD_KSPLIT>(a, st);
+        int rc = run4x4<128, 256, true, 64, D0_DGRAD_KSPLIT>(a, st);
         if (rc) return rc;
         return launch_reduce_slabs(ws, din, slice, D0_DGRAD_KSPLIT, slice, st, nullptr);
     }

@@ -32,7 +32,11 @@ def patterns(prec, width):
         cin, cout, h = LAYERS[l]
         h *= k
         if prec == "f32":
-            if l <= 4:
+            if l == 4 and h == 4:                      # D0 on 4x4 images: the padding-skipping kernel
+                p[f"conv_fwd_L{l}"] = rf"conv4x4_row_kernel<{cin}, {cout}, false"
+                p[f"conv_dgrad_L{l}"] = rf"conv4x4_row_kernel<{cout}, {cin}, true"
+                p[f"conv_wgrad_L{l}"] = rf"conv5x5_wgrad_kernel<{cin}, {cout}, {h},"
+            elif l <= 4:
                 p[f"conv_fwd_L{l}"] = rf"conv5x5_mfma_kernel<{cin}, {cout}, {h}, false, false"
                 p[f"conv_dgrad_L{l}"] = rf"conv5x5_mfma_kernel<{cout}, {cin}, {h}, false, true"
                 p[f"conv_wgrad_L{l}"] = rf"conv5x5_wgrad_kernel<{cin}, {cout}, {h},"
@@ -52,7 +56,7 @@ def patterns(prec, width):
     if prec == "f32":
         p["e1_fwd"] = rf"e1_fwd_kernel<{width}>"
         p["e1_wgrad"] = rf"e1_wgrad_kernel<{width}, true>"
-        p["d4_fwd"] = rf"d4_fwd_kernel<{width}, float>"
+        p["d4_fwd"] = rf"d4_fwd_pc_f32_kernel<{width}>"
         p["d4_bwd"] = rf"d4_bwd_kernel<{width}, float>"
     else:
         p["e1_fwd"] = rf"e1_fwd_bf16_kernel<{width}, 2>"

@@ -553,6 +553,132 @@ static int run_bf16(const ConvBf16Args& a, hipStream_t st) {
     return run_bf16_ns<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, 1, 4, BF16_MT>(a, st);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 4x4 images in bf16 mode (D0 forward and input gradient at 64x64 frames): the padding-skipping kernel of
+// conv_mfma.hip (conv4x4_row_kernel) on the bf16 MFMA.  M tile = 32 images x two image rows, wave = image column; a
+// kernel row runs only for the image rows it reaches, a wave skips the taps that leave its column; LDS holds the 16
+// real pixels as [octet][pixel][image] planes of 16-byte units (lanes = consecutive images).  Packed weights, K chunk
+// (32 channels), slab layout and k order as in conv5x5_bf16_kernel; always split-K (fp32 partial sums to slab z).
+// ---------------------------------------------------------------------------------------------
+template <int KCH, int NCH, int NT, int KSPLIT>
+__global__ __launch_bounds__(256) void conv4x4_row_bf16_kernel(ConvBf16Args a) {
+    constexpr int KCB = 32, KB = KCB / 16, OCT = KCB / 8, NB = NT / 32;
+    constexpr int PXS = 33, PSP = 16 * PXS + 2;                 // [pixel][32 images + 1] units, plane stride
+    constexpr int A_UNITS = OCT * PSP, W_UNITS = 5 * KB * 2 * NT;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[(A_UNITS + W_UNITS) * 16];
+    bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);
+    bf16x8* lds_w = lds_a + A_UNITS;                            // [tap s][kb][half][n]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int ya = (blockIdx.x & 1) * 2, img0 = (blockIdx.x >> 1) * 32, n0 = blockIdx.y * NT;   // image rows ya, ya + 1
+    const int r0 = ya == 0 ? 1 : 0, r1 = ya == 0 ? 4 : 3;              // kernel rows that at least one of the two image rows needs
+    const int s0 = wave < 2 ? 2 - wave : 0, s1 = wave > 1 ? 5 - wave : 4;   // taps whose input column wave+s-2 exists
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][nb][v] = 0.f;
+
+    constexpr int WPT = (W_UNITS + 255) / 256;
+    static_assert(W_UNITS % 256 == 0, "whole staging rounds");
+    bf16x8 wreg[WPT];
+    int wbase[WPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int q = tid + i * 256;
+        const int n = q % NT, row = q / NT, half = row & 1, kb = (row >> 1) % KB, s = row / (2 * KB);
+        wbase[i] = ((s * (KCH / 16) + kb) * 2 + half) * NCH + n0 + n;
+    }
+    auto load_w = [&](int cc, int r) {
+        const bf16x8* wst = a.wp + (size_t)(r * 5 * (KCH / 16) + cc * KB) * 2 * NCH;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) wreg[i] = wst[wbase[i]];
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) lds_w[tid + i * 256] = wreg[i];
+    };
+    constexpr int NQ = 512 * OCT, IPT = NQ / 256;              // 32 images x 16 pixels x OCT octets
+    bf16x8 breg[IPT];
+    unsigned okmask = 0u;                                       // zero-select deferred to store_input (see conv5x5_bf16_kernel)
+    auto load_input = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int q = tid + i * 256, oct = q % OCT, hp = q / OCT, ib = img0 + (hp >> 4);
+            const bool ok = ib < a.B;
+            breg[i] = Act<__bf16>::ld8(a.in, ok ? ((size_t)ib * 16 + (hp & 15)) * KCH + cc * KCB + oct * 8 : 0);
+            okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));
+        }
+    };
+    auto store_input = [&]() {
+        bf16x8 z;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) z[k] = (__bf16)0.f;
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int q = tid + i * 256, oct = q % OCT, hp = q / OCT;
+            lds_a[oct * PSP + (hp & 15) * PXS + (hp >> 4)] = (okmask >> i) & 1u ? breg[i] : z;
+        }
+    };
+
+    static_assert(KCH % KCB == 0 && (KCH / KCB) % KSPLIT == 0, "channel chunking");
+    constexpr int CPS = (KCH / KCB) / KSPLIT;
+    const int c0 = blockIdx.z * CPS, c1 = c0 + CPS;
+    load_w(c0, r0);
+    load_input(c0);
+    for (int cc = c0; cc < c1; ++cc)
+        for (int r = r0; r <= r1; ++r) {
+            __syncthreads();                       // everyone finished reading the previous stage
+            if (r == r0) store_input();
+            store_w();
+            if (r == r0 && cc + 1 < c1) load_input(cc + 1);        // older than the weight load below (vmcnt retires in order)
+            if (r < r1) load_w(cc, r + 1);
+            else if (cc + 1 < c1) load_w(cc + 1, r0);
+            __syncthreads();
+            const bf16x8* bp = lds_w + lh * NT + li;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int yi = ya + t + r - 2;                 // input row of image row ya + t under kernel row r
+                if ((unsigned)yi > 3u) continue;               // workgroup-uniform
+                const bf16x8* ap = lds_a + lh * PSP + (yi * 4 + wave - 2) * PXS + li;
+                for (int s = s0; s <= s1; ++s)
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) {
+                        const bf16x8 av = ap[(kb * 2) * PSP + s * PXS];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[t][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bp[((s * KB + kb) * 2) * NT + nb * 32], acc[t][nb], 0, 0, 0);
+                    }
+            }
+        }
+    // KSPLIT > 1: fp32 partial sums to slab z (the callers' finish kernels add them, add the bias, round);  KSPLIT == 1: the plain
+    // result straight to the bf16 tensor (input gradient at large batches: no slab, no finish launch)
+    float* out = a.out + (size_t)blockIdx.z * a.sliceFloats;
+    __bf16* out16 = reinterpret_cast<__bf16*>(a.out);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int ib = img0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+                const size_t o = ((size_t)ib * 16 + (ya + t) * 4 + wave) * NCH + n0 + nb * 32 + li;
+                if (ib < a.B) { if (KSPLIT > 1) out[o] = acc[t][nb][v]; else out16[o] = (__bf16)acc[t][nb][v]; }
+            }
+}
+
+template <int KCH, int NCH, int NT, int KSPLIT>
+static int run4x4_bf16(const ConvBf16Args& a, hipStream_t st) {
+    static_assert(NCH % NT == 0, "channel tiling");
+    cvae_probe_begin(st);
+    hipLaunchKernelGGL((conv4x4_row_bf16_kernel<KCH, NCH, NT, KSPLIT>), dim3(cdiv(a.B, 32) * 2, NCH / NT, KSPLIT), dim3(256), 0, st, a);
+    cvae_probe_end(st);
+    CVAE_CHECK_LAUNCH();
+    return 0;
+}
+
 bool conv_bf16_supported(int layer, int width) { return (width == 64 || width == 128) && layer >= 1 && layer <= 7; }
 
 int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, const float* packed, const float* bias, float* out,
@@ -566,9 +692,12 @@ int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, c
             case 4: {     // 4x4 images: split-K x4 over the channel chunks so that 256 workgroups exist at B=256
                 const int64_t slice = (int64_t)B * 16 * 128;
                 a.out = ws; a.sliceFloats = slice;
-                int rc = run_bf16<256, 128, 4, 64, EPI_PLAIN, 4>(a, st);
+                // bf16 mode: the padding-skipping kernel; large batches need only two K slices to fill the chip (half the slab traffic)
+                const int ks = (ns == 1 && B >= 1024) ? 2 : 4;
+                int rc = ns != 1 ? run_bf16<256, 128, 4, 64, EPI_PLAIN, 4>(a, st)
+                                 : (ks == 2 ? run4x4_bf16<256, 128, 64, 2>(a, st) : run4x4_bf16<256, 128, 64, 4>(a, st));
                 if (rc) return rc;
-                return launch_splitk_bias_relu(ws, bias, out, slice, 4, 128, st, ns == 1);
+                return launch_splitk_bias_relu(ws, bias, out, slice, ks, 128, st, ns == 1);
             }
         }
     } else if (width == 128) {
@@ -594,8 +723,10 @@ int launch_conv_dgrad_bf16(int layer, int width, int ns, int B, const float* dou
             case 3: if (ns == 1) return run_bf16<256, 128, 8, 64, EPI_PLAIN>(a, st); else return run_bf16<256, 128, 8, 32, EPI_PLAIN>(a, st);
             case 4: {
                 const int64_t slice = (int64_t)B * 16 * 256;
+                const ConvBf16Args a2 = a;                 // out = din
                 a.out = ws; a.sliceFloats = slice;
-                int rc = run_bf16<128, 256, 4, 64, EPI_PLAIN, 2>(a, st);
+                if (ns == 1 && B >= 1024) return run4x4_bf16<128, 256, 64, 1>(a2, st);     // enough workgroups without split-K: bf16 result directly
+                int rc = ns == 1 ? run4x4_bf16<128, 256, 64, 2>(a, st) : run_bf16<128, 256, 4, 64, EPI_PLAIN, 2>(a, st);
                 if (rc) return rc;
                 return launch_reduce_slabs(ws, din, slice, 2, slice, st, nullptr, ns == 1);
             }

@@ -45,7 +45,11 @@ def patterns(prec, width):
                 p[f"conv_dgrad_L{l}"] = rf"conv_up_dgrad_kernel<{cin}, {cout}, {h // 2},"
                 p[f"conv_wgrad_L{l}"] = rf"conv_up_wgrad_kernel<{cin}, {cout}, {h // 2}>"
         else:
-            if l <= 4:
+            if l == 4 and h == 4:                      # D0 on 4x4 images: the padding-skipping kernel
+                p[f"conv_fwd_L{l}"] = rf"conv4x4_row_bf16_kernel<{cin}, {cout},"
+                p[f"conv_dgrad_L{l}"] = rf"conv4x4_row_bf16_kernel<{cout}, {cin},"
+                p[f"conv_wgrad_L{l}"] = rf"conv5x5_wgrad_tr_kernel<{cin}, {cout}, {h},"
+            elif l <= 4:
                 p[f"conv_fwd_L{l}"] = rf"conv5x5_bf16_kernel<{cin}, {cout}, {h}, \d+, [02], \d+, 5, 0,"
                 p[f"conv_dgrad_L{l}"] = rf"conv5x5_bf16_kernel<{cout}, {cin}, {h}, \d+, 2, \d+, 5, 0,"
                 p[f"conv_wgrad_L{l}"] = rf"conv5x5_wgrad_tr_kernel<{cin}, {cout}, {h},"

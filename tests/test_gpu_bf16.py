@@ -485,3 +485,39 @@ def test_bf16_kernels_exact_on_their_stored_operands(B):
     d_up = F.conv_transpose2d(dout, bf(w4), padding=2)
     d_o3 = F.avg_pool2d(d_up, 2) * 4.0 * (o3 > 0).float()                # Upsample backward = 2x2 sum, then the ReLU mask
     close(act("d_o3", 32, 32), d_o3, "d_o3", 2.0 ** -6)
+
+
+@pytest.mark.parametrize("B", [40, 1029])      # 40: two ragged 32-image groups, four / two K slices;  1029: the large-batch paths
+def test_bf16_d0_padding_skip_kernels_exact_on_their_stored_operands(B):
+    """D0 (4x4 images) runs on conv4x4_row_bf16_kernel in bf16 mode: image-major M tiles that skip the zero padding, two K
+    slices for the forward and NO split (bf16 result written directly) for the input gradient at B >= 1024.  Both passes
+    recomputed on the CPU from the bf16 operands the kernels consumed (same bar as the test above: one bf16 rounding of the
+    stored result); the input gradient d_h is not covered there."""
+    import torch.nn.functional as F
+    from critic_vae_amd.nets import VariationalAutoencoder
+    from critic_vae_amd.train import FusedTrainer
+    from critic_vae_amd import layout as L
+    dev = torch.device("cuda:0")
+    vae = VariationalAutoencoder(width=64, max_batch=B, seed=0, precision="bf16").to(dev)
+    tr = FusedTrainer(vae)
+    x, pred, eps = (torch.from_numpy(v).to(dev) for v in synth.make_batch(77, 0, B, 64))
+    h, theta = vae.handle, vae.theta.data
+    h.forward(B, x, pred, eps, theta, vae.bn_state, tr.mu, tr.logvar, tr.recon, tr.ws, train=True)
+    h.loss(B, x, tr.mu, tr.logvar, tr.recon, tr.ws, tr.scalars, tr.d_recon, tr.d_mu, tr.d_logvar)
+    h.backward(B, x, pred, eps, theta, tr.logvar, tr.recon, tr.d_recon, tr.d_mu, tr.d_logvar, tr.ws, tr.grads)
+    torch.cuda.synchronize()
+    ws16 = tr.ws.view(torch.bfloat16)
+
+    def act(name, c, s):
+        off = h.lib.cvae_ws_offset(h.h, B, name.encode())
+        assert off >= 0, name
+        return ws16[2 * off:2 * off + B * s * s * c].float().view(B, s, s, c).permute(0, 3, 1, 2).contiguous().cpu()
+
+    ref = L.native_to_ref(h.layout, theta.cpu())
+    w0 = ref["decoder.model.0.weight"].to(torch.bfloat16).float()
+    o0 = torch.relu(F.conv2d(act("h", 256, 4), w0, ref["decoder.model.0.bias"], padding=2))
+    got = act("o0", 128, 4)
+    assert torch.isfinite(got).all() and (got - o0).abs().max().item() <= 2.0 ** -8 * o0.abs().max().item(), "o0"
+    d_h = F.conv_transpose2d(act("d_o0", 128, 4), w0, padding=2)
+    got = act("d_h", 256, 4)
+    assert torch.isfinite(got).all() and (got - d_h).abs().max().item() <= 2.0 ** -8 * d_h.abs().max().item(), "d_h"

@@ -78,6 +78,21 @@ def test_conv_fwd(H, layer, B):
     check(got, ref, f"conv_fwd L{layer}")
 
 
+@pytest.mark.parametrize("B", [37, 64])
+def test_conv_fwd_d0_image_major_tiles(H, B):
+    """D0 (4x4 images) runs on conv4x4_row_kernel: M tiles of 32 IMAGES x two image rows that skip the zero padding, split-K
+    over channel chunks.  Batches that end inside a 32-image group (the cases above stay inside the first one)."""
+    cin, cout, h, _ = LAYERS[4]
+    x = rnd("x4r", (B, cin, h, h))
+    w = rnd("w4r", (cout, cin, 5, 5), -0.1, 0.1)
+    b = rnd("b4r", (cout,))
+    ref = torch.relu(orc.conv5x5(x, w, b, upsample_input=False))
+    out = torch.full((B * h * h * cout,), float("nan"), device="cuda")
+    H.op_conv_fwd(4, B, nhwc(x), wnat(w), dev(b), out, None, torch.empty(H.op_scratch_floats(B), device="cuda"))
+    torch.cuda.synchronize()
+    check(to_nchw(out, B, h, cout), ref, "conv_fwd L4 (ragged image groups)")
+
+
 @pytest.mark.parametrize("layer", range(4))
 @pytest.mark.parametrize("B,ties", [(3, False), (8, True), (5, "tiny_gamma")])
 def test_bn_pool_act_fwd_bwd(H, layer, B, ties):

@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void conv4x4_row_bf16_kernel(ConvBf16Args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int ya = (blockIdx.x & 1) * 2, img0 = (blockIdx.x >> 1) * 32, n0 = blockIdx.y * NT;   // image rows ya, ya + 1
     const int r0 = ya == 0 ? 1 : 0, r1 = ya == 0 ? 4 : 3;              // kernel rows that at least one of the two image rows needs
-    const int s0 = wave < 2 ? 2 - wave : 0, s1 = wave > 1 ? 5 - wave : 4;   // taps whose input column wave+s-2 exists
+    // image column of this wave: w in the first image row, w ^ 1 in the second (7 taps per two-row stage on every wave, see conv4x4_row_kernel)
 
     f32x16 acc[2][NB];
 #pragma unroll
@@ -642,7 +642,9 @@ __global__ __launch_bounds__(256) void conv4x4_row_bf16_kernel(ConvBf16Args a) {
             for (int t = 0; t < 2; ++t) {
                 const int yi = ya + t + r - 2;                 // input row of image row ya + t under kernel row r
                 if ((unsigned)yi > 3u) continue;               // workgroup-uniform
-                const bf16x8* ap = lds_a + lh * PSP + (yi * 4 + wave - 2) * PXS + li;
+                const int xc = wave ^ t;                       // taps whose input column xc+s-2 exists: s0..s1
+                const int s0 = xc < 2 ? 2 - xc : 0, s1 = xc > 1 ? 5 - xc : 4;
+                const bf16x8* ap = lds_a + lh * PSP + (yi * 4 + xc - 2) * PXS + li;
                 for (int s = s0; s <= s1; ++s)
 #pragma unroll
                     for (int kb = 0; kb < KB; ++kb) {
@@ -664,7 +666,7 @@ __global__ __launch_bounds__(256) void conv4x4_row_bf16_kernel(ConvBf16Args a) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int ib = img0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-                const size_t o = ((size_t)ib * 16 + (ya + t) * 4 + wave) * NCH + n0 + nb * 32 + li;
+                const size_t o = ((size_t)ib * 16 + (ya + t) * 4 + (wave ^ t)) * NCH + n0 + nb * 32 + li;
                 if (ib < a.B) { if (KSPLIT > 1) out[o] = acc[t][nb][v]; else out16[o] = (__bf16)acc[t][nb][v]; }
             }
 }

@@ -249,13 +249,15 @@ static int run(const ConvArgs& a, hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------------
 // 4x4 images (decoder block D0 at 64x64 frames, vae_nets.py:117, and its input gradient): 51 % of the 25-tap MACs of a
-// 5x5 / pad-2 conv on a 4x4 image multiply zero padding.  Here the M tile is 32 IMAGES x two image rows (0,1) or (2,3),
-// wave w = column x = w (its 32 MFMA rows per image row are 32 images at ONE pixel position), so "tap outside the image"
-// is uniform: a kernel row r runs only for the image rows y with y+r-2 inside (workgroup-uniform: 7 of 10 row-stages per
-// chunk, the same for both row pairs; the kernel row that neither needs is not staged), taps s with x+s-2 outside are
-// skipped by the wave (3 or 4 of 5).  One staged input chunk and one weight slab serve both image rows.  LDS holds the 16 real pixels of the 32 images as
-// [channel plane][pixel][image] (no halo: every tap that runs is inside; lanes = consecutive images: conflict-free
-// operand reads).  Weight slabs, register prefetch, k order inside a tap (channels ascending) as in conv5x5_mfma_kernel;
+// 5x5 / pad-2 conv on a 4x4 image multiply zero padding.  Here the M tile is 32 IMAGES x two image rows (0,1) or (2,3);
+// wave w = column w of the first image row and column w ^ 1 of the second (32 MFMA rows = 32 images at ONE pixel
+// position), so "tap outside the image" is uniform: a kernel row r runs only for the image rows y with y+r-2 inside
+// (workgroup-uniform: 7 of 10 row-stages per chunk, the same for both row pairs; the kernel row that neither needs is not
+// staged), taps s with x+s-2 outside are skipped by the wave (3 of 5 in columns 0 / 3, 4 in columns 1 / 2: the column
+// swap between the rows gives every wave 7 taps per two-row stage).  One staged input chunk and one weight slab serve
+// both image rows.  LDS holds the 16 real pixels of the 32 images as [channel plane][pixel][image] (no halo: every tap
+// that runs is inside; lanes = consecutive images: conflict-free operand reads).  Weight slabs, register prefetch, k order
+// inside a tap (channels ascending) as in conv5x5_mfma_kernel;
 // always split-K over channel chunks (raw partial sums to slab z, the callers' finish kernels add them in fixed order).
 // ---------------------------------------------------------------------------------------------
 template <int KCH, int NCH, bool DGRAD, int NT, int KSPLIT>
@@ -272,7 +274,8 @@ __global__ __launch_bounds__(256) void conv4x4_row_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int ya = (blockIdx.x & 1) * 2, img0 = (blockIdx.x >> 1) * 32, n0 = blockIdx.y * NT;   // image rows ya, ya + 1
     const int r0 = ya == 0 ? 1 : 0, r1 = ya == 0 ? 4 : 3;              // kernel rows that at least one of the two image rows needs
-    const int s0 = wave < 2 ? 2 - wave : 0, s1 = wave > 1 ? 5 - wave : 4;   // taps whose input column wave+s-2 exists
+    // image column of this wave: w in the first image row, w ^ 1 in the second -- columns 0 / 3 have three taps inside the image,
+    // columns 1 / 2 four, so every wave carries 3 + 4 = 7 taps per stage in which both rows run (8 on two of the waves otherwise)
     const int aBase = lh * PS + li;
     const int bBase = DGRAD ? (li * KCP + lh) : (lh * NT + li);
 
@@ -359,7 +362,9 @@ __global__ __launch_bounds__(256) void conv4x4_row_kernel(ConvArgs a) {
             for (int t = 0; t < 2; ++t) {
                 const int yi = ya + t + r - 2;                 // input row of image row ya + t under kernel row r
                 if ((unsigned)yi > 3u) continue;               // workgroup-uniform
-                const float* ap = lds_in + aBase + (yi * 4 + wave - 2) * PXS;
+                const int xc = wave ^ t;                       // taps whose input column xc+s-2 exists: s0..s1
+                const int s0 = xc < 2 ? 2 - xc : 0, s1 = xc > 1 ? 5 - xc : 4;
+                const float* ap = lds_in + aBase + (yi * 4 + xc - 2) * PXS;
                 for (int s = s0; s <= s1; ++s) {
                     const float* as = ap + s * PXS;
                     const float* bs = lds_w + bBase + (DGRAD ? s * NT * KCP : s * KC * NT);
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(256) void conv4x4_row_kernel(ConvArgs a) {
                 }
             }
         }
-    // raw partial sums of slab z: row (image) (v&3) + 8 (v>>2) + 4 lh of the wave's 32, pixel (ya + t, wave), channel n0 + 32 nb + li
+    // raw partial sums of slab z: row (image) (v&3) + 8 (v>>2) + 4 lh of the wave's 32, pixel (ya + t, wave ^ t), channel n0 + 32 nb + li
     float* out = a.out + (size_t)blockIdx.z * a.sliceFloats;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(256) void conv4x4_row_kernel(ConvArgs a) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int ib = img0 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-                if (ib < a.B) out[((size_t)ib * 16 + (ya + t) * 4 + wave) * NCH + n0 + nb * 32 + li] = acc[t][nb][v];
+                if (ib < a.B) out[((size_t)ib * 16 + (ya + t) * 4 + (wave ^ t)) * NCH + n0 + nb * 32 + li] = acc[t][nb][v];
             }
 }
 

@@ -14,6 +14,10 @@ the C-ABI (critic-vae_amd FusedTrainer), inputs resident in HBM.  Rank 0 prints 
   headline (value, ms_per_step, roofline, roofline_hbm, cpu_baseline) = BASELINE.json configs[1]: fp32,
       per-GPU batch 256 (weak scaling: global batch 256*N) — unless --preset/--batch/--precision/--width ask
       for another workload;
+  Every sub-workload below lands in `config` twice: as FLAT scalar keys (config2_images_per_s, config2_ms_per_step,
+      config2_steps, config2_roofline_kernel / _frac / _avg_launch_us / _traffic_over_algorithmic, config2_roofline_hbm_frac,
+      ... the same for config5 / bf16x9 / bf16x6, dropin_images_per_s — a record that keeps scalars only keeps these) and as
+      a compact nested object; per-kernel tables and long descriptions go to config.detail_file (+ stderr).
   config.config2 / config.config5 (N = 1) = the SAME timed loop (same barrier/sync bracket, same in-step kernel
       probe, --steps/--warmup as given) run right after it in this process on BASELINE.json configs[2]
       (bf16-MFMA, batch 2048) and on the per-GPU shard of configs[4] (128x128, bf16, batch 1024), each with
@@ -46,6 +50,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# this pool's hosts only support dmabuf IPC: without it RCCL's hipIpcGetMemHandle fails at init.  Set before torch / HIP
+# load so the documented torchrun form works as well as the self-launch (an exported value wins)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
@@ -76,7 +83,9 @@ PRESETS = {   # BASELINE.json configs (configs[0] is the CPU case: cpu_baseline.
 DTYPE_NOTE = {
     "f32": "f32",
     "bf16": "bf16 (MFMA operands of every conv pass incl. E1/D4; activations and activation gradients stored as bf16; "
-            "fp32 accumulate, BatchNorm statistics, loss, master weights, gradients, Adam)",
+            "fp32 accumulate, BatchNorm statistics, loss, master weights, gradients, Adam).  NOT held to the 1e-4 bar: "
+            "outputs within 3e-2, loss within 2e-3, gradient tensors 1e-4..0.09 relative L2 of the fp32 oracle "
+            "(first conv's weight 0.10 at 64x64 / 0.16 at 128x128), bounds asserted in tests/test_gpu_bf16.py",
     "bf16x9": "f32 emulated: 3-way exact bf16 operand splits, 9 bf16 MFMAs per product block, f32 elsewhere",
     "bf16x6": "f32 emulated: 3-way exact bf16 operand splits, the 6 leading partial products, f32 elsewhere"}
 
@@ -86,6 +95,58 @@ def conv_flops(layer, B, width=64):
     cin, cout, h, _ = LAYERS[layer]
     h = h * width // 64
     return 2.0 * 25 * cin * cout * h * h * B
+
+
+def conv_bytes(pid, B, width, precision):
+    """Algorithmic HBM bytes of one launch of conv kernel `pid` = kind*9 + layer (kind 0 forward, 1 input gradient,
+    2 weight gradient): each activation tensor it touches once, in the storage type of the mode, plus the fp32 weights
+    (read by forward / input gradient, written by the weight gradient).  Layers 5..7 read / write their input side at
+    the stored (pre-Upsample) resolution; their input gradient also reads the producer's output for the ReLU mask."""
+    kind, layer = pid // 9, pid % 9
+    cin, cout, h, up = LAYERS[layer]
+    h = h * width // 64
+    hin = h // 2 if up else h
+    e = 2.0 if precision == "bf16" else 4.0
+    a_in, a_out, w = B * hin * hin * cin * e, B * h * h * cout * e, 25.0 * cin * cout * 4
+    if kind == 1 and up:
+        a_in *= 2                                   # d_in written + the forward activation read for the ReLU mask
+    return a_in + a_out + w
+
+
+def flat_summary(prefix, r):
+    """Scalar keys for `config` (the driver's record keeps scalars only): rate, time, both rooflines of a sub-workload."""
+    out = {f"{prefix}_images_per_s": r["value"], f"{prefix}_ms_per_step": r["ms_per_step"], f"{prefix}_steps": r["steps"],
+           f"{prefix}_warmup": r["warmup"], f"{prefix}_batch_per_gpu": r["batch_per_gpu"], f"{prefix}_final_loss": r["final_loss"]}
+    for k in ("whole_step_algorithmic_TFLOPs", "whole_step_algorithmic_GBps"):
+        if k in r:
+            out[f"{prefix}_{k}"] = r[k]
+    rf, rh = r.get("roofline"), r.get("roofline_hbm")
+    if rf:
+        out.update({f"{prefix}_roofline_kernel": rf["kernel"], f"{prefix}_roofline_frac": rf["frac"],
+                    f"{prefix}_roofline_achieved_TFLOPs": rf["achieved"], f"{prefix}_roofline_peak_TFLOPs": rf["peak"],
+                    f"{prefix}_roofline_avg_launch_us": rf["avg_launch_us"], f"{prefix}_roofline_launches_timed": rf["launches_timed"],
+                    f"{prefix}_roofline_traffic_bytes": rf["traffic"],
+                    f"{prefix}_roofline_algorithmic_bytes": rf["algorithmic_bytes_per_launch"],
+                    f"{prefix}_roofline_traffic_over_algorithmic": (None if not rf["traffic"] else
+                                                                    round(rf["traffic"] / rf["algorithmic_bytes_per_launch"], 3))})
+    if rh:
+        out.update({f"{prefix}_roofline_hbm_kernel": rh["kernel"], f"{prefix}_roofline_hbm_frac": rh["frac"],
+                    f"{prefix}_roofline_hbm_achieved_GBps": rh["achieved"], f"{prefix}_roofline_hbm_avg_launch_us": rh["avg_launch_us"],
+                    f"{prefix}_roofline_hbm_traffic_over_algorithmic": (None if not rh["traffic"] else
+                                                                        round(rh["traffic"] / rh["algorithmic_bytes_per_launch"], 3))})
+    return out
+
+
+def compact(r):
+    """A sub-workload's nested object without the per-kernel tables and the long description strings (those go to the
+    detail file): what stays is what the flat keys summarise, in structured form."""
+    r = dict(r)
+    for k in ("workload", "dtype", "frame", "n_gpus", "global_batch", "loss_finite"):
+        r.pop(k, None)
+    for k in ("roofline", "roofline_hbm"):
+        if k in r:
+            r[k] = {a: b for a, b in r[k].items() if not a.startswith("in_step_")}
+    return r
 
 
 def probe_name(pid):
@@ -275,7 +336,7 @@ def time_workload(cx, spec, steps, warmup, probing, allreduce_dtype=None, overla
                     "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak, 4),
                     "traffic": measured_traffic(wkey, probe_name(dominant)),
                     "avg_launch_us": round(sec * 1e6, 2), "launches_timed": len(ms),
-                    "algorithmic_flops_per_launch": fl,
+                    "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": conv_bytes(dominant, B, Wd, prec),
                     "in_step_TFLOPs_all_conv_kernels": {probe_name(k): round(conv_flops(k % 9, B, Wd) / (v * 1e-3) / 1e12, 1)
                                                         for k, v in sorted(survey.items()) if k in MFMA_PROBE_IDS}}
                 if ms_hbm:          # second roofline: the largest HBM-bound kernel of the step
@@ -446,16 +507,26 @@ def main():
         if head["batch"] != 32:       # the reference's own CPU-runnable case (configs[0], batch 32) beside it
             res["cpu_baseline"]["batch32"] = cpu_baseline(32, steps=10, width=head["width"])
 
-    # The other BASELINE configs, in the same process and with the same timed loop, after the headline
+    # The other BASELINE configs, in the same process and with the same timed loop, after the headline.  Each lands in
+    # `config` twice: as FLAT scalar keys (config2_images_per_s, config2_roofline_frac, ... — the driver's record keeps
+    # scalars only) and as a compact nested object; the per-kernel tables and description strings of every sub-workload go
+    # to the detail file named by config.detail_file (and to stderr), so the stdout line stays short enough to be kept whole.
+    detail = {"headline": h}
+    cfgd = res["config"]
     if not explicit and not args.no_extra_configs:
         if world == 1:
             for key in ("config2", "config5"):
-                res["config"][key] = time_workload(cx, dict(PRESETS[key], key=key), args.steps, args.warmup, probing)
+                full = time_workload(cx, dict(PRESETS[key], key=key), args.steps, args.warmup, probing)
                 # the same workload with the weight-gradient kernels on the library's side stream (cvae_config.overlap_wgrad,
                 # bit-identical results): kernels then share the chip, so it is a rate beside the line, without rooflines
                 ss = time_workload(cx, dict(PRESETS[key], key=key + " + side-stream weight gradients"), args.steps, args.warmup,
                                    False, side_stream_wgrad=True)
-                res["config"][key]["side_stream_wgrad"] = {k: ss[k] for k in ("value", "unit", "ms_per_step", "steps", "final_loss")}
+                full["side_stream_wgrad"] = {k: ss[k] for k in ("value", "unit", "ms_per_step", "steps", "final_loss")}
+                detail[key] = full
+                cfgd.update(flat_summary(key, full))
+                cfgd[f"{key}_side_stream_wgrad_images_per_s"] = ss["value"]
+                cfgd[f"{key}_dtype"] = "bf16 MFMA + bf16 activation storage; not held to 1e-4: gradient tensors 1e-4..0.16 rel-L2 of fp32 (tests/test_gpu_bf16.py)"
+                cfgd[key] = compact(full)
             # the same configs[1] workload in the two fp32-EMULATION modes (exact 3-way bf16 operand splits on the bf16 MFMA,
             # DESIGN.md 7b): they pass the same decisions-imposed 1e-4 parity test as the fp32 headline
             # (tests/test_gpu_step.py::test_step_b256_fp32_against_oracle[bf16x9|bf16x6]) but are reported beside it, never as it
@@ -463,14 +534,39 @@ def main():
                                ("bf16x6", "the six leading partial products (drops <= 3*2^-24 of each product)")):
                 spec = dict(PRESETS["config1"], precision=prec, key=f"fp32_emulated_{prec}",
                             label=f"BASELINE.json configs[1] workload with fp32 EMULATED on the bf16 MFMA ({what}; forward + input gradients of E2-E4 / D0)")
-                res["config"][f"fp32_emulated_{prec}"] = time_workload(cx, spec, args.steps, args.warmup, probing)
-            res["config"]["dropin_images_per_s"] = dropin_rate(cx)
+                full = time_workload(cx, spec, args.steps, args.warmup, probing)
+                detail[f"fp32_emulated_{prec}"] = full
+                cfgd.update(flat_summary(prec, full))
+                cfgd[f"fp32_emulated_{prec}"] = compact(full)
+            dr = dropin_rate(cx)
+            detail["dropin"] = dr
+            cfgd["dropin_images_per_s"] = dr["value"]
         else:
             for key in ("config4", "config5"):
-                res["config"][key] = time_workload(cx, dict(PRESETS[key], key=key), args.steps, args.warmup, False,
-                                                   args.allreduce_dtype, overlaps=(True, False))
+                full = time_workload(cx, dict(PRESETS[key], key=key), args.steps, args.warmup, False,
+                                     args.allreduce_dtype, overlaps=(True, False))
+                detail[key] = full
+                cfgd.update(flat_summary(key, full))
+                for mode, m in full.get("allreduce_modes", {}).items():
+                    cfgd[f"{key}_allreduce_{mode}_images_per_s"] = m["value"]
+                    cfgd[f"{key}_allreduce_{mode}_exposed_us"] = m.get("allreduce_exposed_us")
+                cfgd[f"{key}_allreduce_exposed_us"] = full.get("allreduce_exposed_us")
+                cfgd[key] = compact(full)
+    # the headline keeps its per-kernel tables in the detail file too; the line carries the two rooflines without them
+    for k in ("roofline", "roofline_hbm"):
+        if k in res:
+            res[k] = {a: b for a, b in res[k].items() if not a.startswith("in_step_")}
 
     if rank == 0:
+        path = os.environ.get("CVAE_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out" if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "",
+                                                                  "bench_detail.json")
+        try:
+            with open(path, "w") as f:
+                json.dump({"line": res, "detail": detail}, f)
+            res["config"]["detail_file"] = os.path.relpath(path, ROOT)
+        except OSError:
+            res["config"]["detail_file"] = None
+        print("[bench] detail " + json.dumps(detail), file=sys.stderr, flush=True)
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -35,14 +35,25 @@ void cvae_probe_end(hipStream_t st) {
     if (p && p->n < PROBE_CAP) { (void)hipEventRecord(p->e1[p->n], st); p->n++; }
 }
 
+// Compute units of the current device.  Sizes persistent grids and split counts only (never a result), so a failed
+// query falls back to the MI355X's 256 — but not silently: the error string says so (the launch that follows still
+// succeeds, and cvae_last_error() then explains an unexpected grid).  Cached per device ordinal (ordinals past the
+// table are queried every time rather than aliased onto another device's entry).
 int cvae_num_cus() {
-    static std::atomic<int> cached[64];                      // per device ordinal; 0 = not yet queried
+    constexpr int NCACHE = 64;
+    static std::atomic<int> cached[NCACHE];                  // 0 = not yet queried
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    int n = cached[dev & 63].load(std::memory_order_relaxed);
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { cvae_set_error("cvae_num_cus: hipGetDevice failed (%s); assuming 256 compute units", hipGetErrorString(e)); return 256; }
+    const bool cacheable = dev >= 0 && dev < NCACHE;
+    int n = cacheable ? cached[dev].load(std::memory_order_relaxed) : 0;
     if (n > 0) return n;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cached[dev & 63].store(n, std::memory_order_relaxed);
+    e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess || n <= 0) {
+        cvae_set_error("cvae_num_cus: compute-unit query failed on device %d (%s); assuming 256", dev, hipGetErrorString(e));
+        return 256;                                          // not cached: the next call asks again
+    }
+    if (cacheable) cached[dev].store(n, std::memory_order_relaxed);
     return n;
 }
 
@@ -534,12 +545,13 @@ int cvae_scale_loss_grads(cvae_handle h, int32_t B, const float* gscale, const f
 int32_t cvae_critic_param_count(void) { return critic_param_count(); }
 
 int cvae_critic_forward(cvae_handle h, int32_t B, const float* x, const float* critic_params, float* pred, void* stream) {
-    if (!h || B < 1) { cvae_set_error("cvae_critic_forward: bad handle/batch"); return CVAE_EINVAL; }
+    if (!h || B < 1 || B > h->cfg.max_batch) { cvae_set_error("cvae_critic_forward: bad handle, or batch %d outside [1, max_batch]", B); return CVAE_EINVAL; }
     return launch_critic_fwd(h->cfg.width, B, x, critic_params, pred, (hipStream_t)stream);
 }
 
 int cvae_preprocess_u8(cvae_handle h, int32_t B, const uint8_t* frames_hwc, float* x, void* stream) {
-    if (!h || B < 1) { cvae_set_error("cvae_preprocess_u8: bad handle/batch"); return CVAE_EINVAL; }
+    if (!h || B < 1 || !frames_hwc || !x) { cvae_set_error("cvae_preprocess_u8: bad handle/batch/pointer"); return CVAE_EINVAL; }
+    if (B > h->cfg.max_batch) { cvae_set_error("cvae_preprocess_u8: batch %d outside [1, %d]", B, h->cfg.max_batch); return CVAE_EINVAL; }
     return launch_preprocess_u8(h->cfg.width, B, frames_hwc, x, (hipStream_t)stream);
 }
 

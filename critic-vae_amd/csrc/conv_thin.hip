@@ -735,7 +735,12 @@ __global__ __launch_bounds__(256) void d4_perm_kernel(const float* __restrict__ 
     dst[i] = red[(tap * 3 + co) * 32 + ci];
 }
 
+// Split counts of the E1 weight-gradient / D4 backward kernels.  THIN_SPLIT_CAP is the ONE bound shared by the workspace
+// sizing (e1_wgrad_ws_floats / d4_bwd_ws_floats) and the launches: whatever occupancy switch (-DE1W_OCC, -DD4B_OCC) or
+// device CU count asks for, a launch never writes more slab rows than the workspace was sized for.
+static constexpr int THIN_SPLIT_CAP = 1024;
 static int thin_splits(int numTiles, int* tps, int want = 512) {
+    if (want > THIN_SPLIT_CAP) want = THIN_SPLIT_CAP;
     int S = numTiles < want ? numTiles : want;
     *tps = cdiv(numTiles, S);
     return cdiv(numTiles, *tps);
@@ -743,7 +748,7 @@ static int thin_splits(int numTiles, int* tps, int want = 512) {
 
 int64_t e1_wgrad_ws_floats(int width, int B) {
     int tps; const int tiles = B * (width / 4) * (width / 32);
-    const int64_t S = thin_splits(tiles, &tps, 1024);            // upper bound of the split counts used below
+    const int64_t S = thin_splits(tiles, &tps, THIN_SPLIT_CAP);   // upper bound of the split counts used below
     const int64_t f32 = S * 3072 + col_reduce_ws_floats(3072);
     const int64_t b16 = S * E1W_ROW + E1W_ROW + 32 + col_reduce_ws_floats(E1W_ROW);     // slabs | reduced row | column-reduce scratch
     return f32 > b16 ? f32 : b16;
@@ -1419,7 +1424,7 @@ static int d4_splits(int width, int B, int* tps, bool bf16io = false) {
 // ws of launch_d4_bwd = [S*3072 split-K slab | B*3 plane sums of dOut]
 int64_t d4_bwd_ws_floats(int width, int B) {
     int tps;
-    const int64_t S = thin_splits(B * (width / 16) * (width / 32), &tps, 1024);        // upper bound of the split counts used
+    const int64_t S = thin_splits(B * (width / 16) * (width / 32), &tps, THIN_SPLIT_CAP);   // upper bound of the split counts used
     const int64_t row = D4P_ROW;                                                        // bf16 mode's slab row (fp32: 3072)
     return S * row + align_up((int64_t)B * 3, 64) + row + col_reduce_ws_floats((int)row);
 }

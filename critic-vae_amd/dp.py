@@ -8,8 +8,13 @@ xGMI when the backend is "nccl") and the 1/N is folded into the fused Adam's gra
 """
 import os
 
-import torch
-import torch.distributed as dist
+# The pool's hosts only support dmabuf IPC; with the legacy mode RCCL's hipIpcGetMemHandle fails ("invalid argument")
+# as soon as two ranks exchange buffers.  The HSA runtime reads the variable when the process first touches the GPU,
+# so it is set at import (an exported value wins) and again in init() for callers that import late.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 def env_world():
@@ -20,6 +25,7 @@ def env_world():
 def init(backend=None):
     """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
     world, rank, local = env_world()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

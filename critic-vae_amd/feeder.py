@@ -30,7 +30,15 @@ class FrameFeeder:
     """
 
     def __init__(self, frames_u8, batch_size, device, handle, critic=None, depth=2):
-        assert frames_u8.dtype == np.uint8 and frames_u8.ndim == 4 and frames_u8.shape[3] == 3
+        if not (isinstance(frames_u8, np.ndarray) and frames_u8.dtype == np.uint8 and frames_u8.ndim == 4 and frames_u8.shape[3] == 3):
+            raise ValueError("frames_u8 must be a host uint8 array of shape (N, W, W, 3)")
+        # cvae_preprocess_u8 / cvae_critic_forward index with the HANDLE's width and trust the caller's batch: a mismatch
+        # here would be an out-of-bounds access on the GPU, not a Python error
+        if not (frames_u8.shape[1] == frames_u8.shape[2] == handle.width):
+            raise ValueError(f"frames are {frames_u8.shape[1]}x{frames_u8.shape[2]}, the handle was created for "
+                             f"{handle.width}x{handle.width} frames")
+        if not 1 <= int(batch_size) <= handle.max_batch:
+            raise ValueError(f"batch_size {batch_size} outside 1..max_batch ({handle.max_batch}) of the handle")
         self.frames = frames_u8
         self.B, self.W = int(batch_size), int(frames_u8.shape[1])
         self.device = torch.device(device)

@@ -113,7 +113,7 @@ class Handle:
 
     PRECISIONS = {"f32": 0, "bf16": 1, "bf16x9": 2, "bf16x6": 3}
 
-    def __init__(self, width=64, max_batch=256, overlap_wgrad=False, precision="f32"):
+    def __init__(self, width=64, max_batch=256, overlap_wgrad=None, precision="f32"):
         """precision "f32": every contraction on the exact-fp32 MFMA (the 1e-4 parity path).
         "bf16": forward and input-gradient convs of E2..E4 / D0 on the bf16 MFMA (fp32 accumulate,
         fp32 tensors in HBM; BASELINE.json configs 3-5).
@@ -125,9 +125,10 @@ class Handle:
         if precision not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
         self.precision = precision
-        if os.environ.get("CVAE_OVERLAP_WGRAD") == "1":        # experiment switch: weight gradients on the side stream
-            overlap_wgrad = True
-        cfg = _Config(width, max_batch, int(bool(overlap_wgrad)), self.PRECISIONS[precision])
+        if overlap_wgrad is None:      # unset: the experiment switch CVAE_OVERLAP_WGRAD=1 decides; an explicit
+            overlap_wgrad = os.environ.get("CVAE_OVERLAP_WGRAD") == "1"       # argument always wins (tests compare True with False)
+        self.overlap_wgrad = bool(overlap_wgrad)                               # the effective value, for bench lines and tests
+        cfg = _Config(width, max_batch, int(self.overlap_wgrad), self.PRECISIONS[precision])
         h = _p()
         rc = self.lib.cvae_create(C.byref(cfg), C.byref(h))
         self._check(rc)

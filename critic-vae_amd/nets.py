@@ -210,6 +210,9 @@ class VariationalAutoencoder(nn.Module):
                     self.bn_state[L.BN_OFF[l]:L.BN_OFF[l] + c] = ref[km]
                 if kv in ref:
                     self.bn_state[L.BN_TOTAL + L.BN_OFF[l]:L.BN_TOTAL + L.BN_OFF[l] + c] = ref[kv]
+            nbt = ref.get(f"encoder.model.{L.ENC_CONV[0] + 1}.num_batches_tracked")      # one counter: the four layers step together
+            if nbt is not None:
+                self.num_batches_tracked = int(nbt)
 
     def load_reference_params(self, ref):
         """ref: {encoder./decoder.-prefixed reference key: tensor or ndarray}."""

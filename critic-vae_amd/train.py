@@ -224,8 +224,33 @@ def synthetic_dataset(n_frames, width=P.w, seed=1234):
     return [x[i:i + 1] for i in range(n_frames)]
 
 
+ENCODER_FILE, DECODER_FILE = "vae_encoder.pt", "vae_decoder.pt"      # vae_parameters.py:25-26 (under saved-networks/)
+
+
+def save_networks(vae, directory):
+    """End of `-train` (vae.py:162-163): torch.save(vae.encoder.state_dict(), ENCODER_PATH) and the same for the decoder —
+    the reference's key names and layouts (OIHW conv weights, (C,H,W)-ordered fc columns / decoder_input rows, BatchNorm
+    running statistics), so the two files load into the reference's own modules with strict=True and into
+    `VariationalAutoencoder.encoder / .decoder.load_state_dict` here.  Returns the two paths."""
+    os.makedirs(directory, exist_ok=True)
+    enc, dec = os.path.join(directory, ENCODER_FILE), os.path.join(directory, DECODER_FILE)
+    torch.save({k: v.detach().cpu() for k, v in vae.encoder.state_dict().items()}, enc)
+    torch.save({k: v.detach().cpu() for k, v in vae.decoder.state_dict().items()}, dec)
+    return enc, dec
+
+
+def load_networks(vae, directory, device=None):
+    """load_vae_network (vae_utility.py:345-361) for the two files save_networks / the reference wrote."""
+    vae.encoder.load_state_dict(torch.load(os.path.join(directory, ENCODER_FILE), map_location=device or "cpu"))
+    vae.decoder.load_state_dict(torch.load(os.path.join(directory, DECODER_FILE), map_location=device or "cpu"))
+    return vae
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="Critic-VAE -train on synthetic frames (vae.py:154-163)")
+    ap.add_argument("--save", metavar="DIR", default=None,
+                    help="write DIR/vae_encoder.pt and DIR/vae_decoder.pt when training ends (vae.py:162-163; the reference's "
+                         "DIR is saved-networks/)")
     ap.add_argument("-train", action="store_true")
     ap.add_argument("--synthetic", type=int, default=1024, help="number of synthetic frames")
     ap.add_argument("--batch", type=int, default=P.batch_size)
@@ -258,6 +283,9 @@ def main(argv=None):
     torch.cuda.synchronize()
     dt = time.time() - t0
     print(f"{args.epochs * args.synthetic / dt:.1f} images/s over {args.epochs} epoch(s)")
+    if args.save:
+        enc, dec = save_networks(vae, args.save)
+        print(f"saved {enc} and {dec}")
     return hist
 
 

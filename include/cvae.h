@@ -10,6 +10,9 @@
  *     boundary is fp32 (precision mode 1 keeps bf16 tensors only inside the workspace it is handed).
  *   - The caller owns every buffer (parameters, gradients, inputs, outputs, workspace); the
  *     library owns only the opaque handle.  No allocation, no device synchronisation inside.
+ *   - Process-wide state is limited to two caches that never change results: a THREAD-LOCAL error string
+ *     (cvae_last_error() reports the calling thread's last failure) and a per-device compute-unit count queried
+ *     once (it sizes persistent grids).  Everything else lives in the handle; distinct handles are independent.
  *   - All work is enqueued on the caller's hipStream_t (passed as void*).
  *   - Return: 0 = OK, <0 = library error (cvae_last_error()), >0 = hipError_t passthrough.
  *   - Layouts: frames x / recon / d_recon are NCHW (B,3,W,W) exactly as the reference holds
@@ -104,6 +107,10 @@ int cvae_loss(cvae_handle h, int32_t batch, const float* x, const float* mu, con
  * Backward: loss.backward() (vae.py:57) for everything cvae_forward computed, given the loss
  * gradients w.r.t. its outputs (and logvar/recon as returned by cvae_forward).  Overwrites the
  * flat gradient buffer `grads` (same layout as `params`).
+ * `x`, `params` and `ws` MUST be the ones the matching cvae_forward ran on, bit for bit (no optimizer step, no other
+ * forward on the same workspace in between): in precision mode 1 the first conv's output y0 is not stored — the E1
+ * weight-gradient kernel recomputes it from `x` and the enc0.w / enc0.b of `params` and re-derives block 0's max-pool
+ * decisions from those values — and every mode reads the saved activations of that forward from `ws`.
  */
 int cvae_backward(cvae_handle h, int32_t batch, const float* x, const float* pred, const float* eps,
                   const float* params, const float* logvar, const float* recon, const float* d_recon,
@@ -170,7 +177,10 @@ int cvae_diff_grey(cvae_handle h, int32_t batch, const float* recon_one, const f
                    float* diff, void* stream);
 
 /* float offset of a named saved tensor in the workspace ("y0".."y3", "a0".."a3", "o0".."o3",
- * "zcat", "h", "d_*" ...) for tests; -1 if unknown */
+ * "zcat", "h", "d_*" ...) for tests; -1 if unknown OR not allocated in this configuration: "d_y0" does not exist
+ * (block 0's BatchNorm backward runs inside the E1 weight-gradient kernel; CVAE_FUSE_E1=0 restores it), and in
+ * precision mode 1 "dout4" has no storage and the "y0" slot is STALE unless a block-0 |gamma| is < 1e-2 (the device
+ * decides per step) or CVAE_FUSE_E1=0 — do not read it otherwise.  Slots hold bf16 elements in precision mode 1. */
 int64_t cvae_ws_offset(cvae_handle h, int32_t batch, const char* name);
 
 /*

@@ -232,6 +232,41 @@ def test_state_dict_round_trip_reference_layout():
     assert torch.equal(vae2.theta, vae.theta)
 
 
+def test_train_main_save_writes_the_two_reference_files(tmp_path):
+    """vae.py:162-163: `-train` ends with torch.save(vae.encoder.state_dict(), ENCODER_PATH) / the decoder's.  `train.main
+    --save DIR` writes DIR/vae_encoder.pt and DIR/vae_decoder.pt in the reference's key names, shapes and dtypes; loaded
+    back (load_networks = load_vae_network, vae_utility.py:345-361) they reproduce the trained flat parameter and the
+    BatchNorm running statistics bit for bit."""
+    from critic_vae_amd import train as T
+    T.main(["-train", "--synthetic", "64", "--batch", "16", "--epochs", "1", "--save", str(tmp_path)])
+    enc = torch.load(tmp_path / "vae_encoder.pt")
+    dec = torch.load(tmp_path / "vae_decoder.pt")
+    ref = synth.make_params(0)
+    assert sorted(enc) == sorted(k.split(".", 1)[1] for k in _ref_keys("encoder"))
+    assert sorted(dec) == sorted(k.split(".", 1)[1] for k in _ref_keys("decoder"))
+    for k, v in ref.items():                       # reference shapes (OIHW conv weights, fc (32, 4096), decoder_input (4096, 33))
+        part, key = k.split(".", 1)
+        got = (enc if part == "encoder" else dec)[key]
+        assert tuple(got.shape) == v.shape and got.dtype == torch.float32 and not got.is_cuda, k
+    assert enc["model.1.num_batches_tracked"].item() == 4 and enc["model.1.num_batches_tracked"].dtype == torch.int64
+    assert not np.array_equal(enc["model.0.weight"].numpy(), ref["encoder.model.0.weight"])       # it trained
+    # the same run again, in-process, and the files loaded into a fresh model: identical parameters and statistics
+    torch.manual_seed(0); np.random.seed(0)
+    vae = VariationalAutoencoder(max_batch=16, seed=0).cuda()
+    T.train(vae, T.synthetic_dataset(64), lambda im: torch.rand(im.shape[0], 1, device=im.device), "cuda:0",
+            epochs=1, batch_size=16, log_n=16 * 8, log=lambda m: None)
+    vae2 = T.load_networks(VariationalAutoencoder(max_batch=16, seed=5).cuda(), str(tmp_path))
+    assert torch.equal(vae2.theta, vae.theta) and torch.equal(vae2.bn_state, vae.bn_state)
+    assert int(vae2.num_batches_tracked) == 4
+
+
+def _ref_keys(part):
+    keys = [k for k in synth.make_params(0) if k.startswith(part + ".")]
+    if part == "encoder":
+        keys += [f"encoder.model.{i}.{s}" for i in (1, 5, 9, 13) for s in ("running_mean", "running_var", "num_batches_tracked")]
+    return keys
+
+
 def test_inference_path_eval_mode(golden_dir):
     """evaluate / inject / diff-mask (vae_nets.py:31-46, vae_utility.py:256-277) in
     eval mode (BatchNorm running statistics, mu instead of a sample), batched, vs the oracle AND vs the

@@ -141,7 +141,7 @@ def compact(r):
     """A sub-workload's nested object without the per-kernel tables and the long description strings (those go to the
     detail file): what stays is what the flat keys summarise, in structured form."""
     r = dict(r)
-    for k in ("workload", "dtype", "frame", "n_gpus", "global_batch", "loss_finite"):
+    for k in ("workload", "dtype", "frame", "n_gpus"):
         r.pop(k, None)
     for k in ("roofline", "roofline_hbm"):
         if k in r:

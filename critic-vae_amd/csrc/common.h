@@ -82,6 +82,12 @@ struct Tile {
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// `s_waitcnt vmcnt(0)` the compiler can SEE (the builtin, not inline asm), placed where a register-prefetch loop ends and nothing
+// is in flight any more.  The loop's staging registers are load destinations; without this the compiler protects their reuse in the
+// epilogue with counted waits (vmcnt(3), (2), (1) ...) that it derives from the loop body — and since vmcnt counts stores too and
+// retires in order, such a wait placed after the epilogue's first global stores waits for THOSE (profiles/experiments/vm_after_store.py).
+__device__ __forceinline__ void vm_drained() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // gfx9 encoding: vmcnt = 0, expcnt / lgkmcnt untouched
+
 // Workgroups are dealt to the 8 XCDs round-robin by linear id, and every XCD has its own L2.  Map
 // workgroup x of a grid of G (G % 8 == 0) to tile (x % 8) * (G / 8) + x / 8: each XCD then owns a
 // contiguous range of tiles — neighbouring tiles share their halo rows in ONE L2, and the workgroups of

@@ -91,6 +91,9 @@ template <int H, int OCT> struct Bf16Geom {
 // MT = 128-pixel tiles per workgroup (bf16 mode: 2): one weight slab staged into LDS — and one weight fragment read
 // from LDS — serves MT times as many MFMAs; the K chunk shrinks to 32 channels so that the LDS footprint (and with
 // it the number of resident workgroups) stays where it was.
+#ifdef EPI_TIMING
+extern "C" int cvae_epi_dbg_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(epi_dbg), sizeof(epi_dbg)); }
+#endif
 #ifdef CONV_TIMING     // experiment builds only: where a wave of ONE instantiation (-DCONV_TIMING_KCH/NCH/H) spends its stages
 __device__ long long conv_dbg[16 * 4 * 10];
 extern "C" int cvae_conv_dbg_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(conv_dbg), sizeof(conv_dbg)); }
@@ -101,8 +104,14 @@ extern "C" int cvae_conv_dbg_read(long long* out) { return (int)hipMemcpyFromSym
 #define CT_STAMP(v)
 #endif
 
+#ifndef BF16_WAVES_ATTR
+#define BF16_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+#ifndef BF16_WAVES_PER_SIMD
+#define BF16_WAVES_PER_SIMD 1      // experiment: 3 = cap the kernel at 168 VGPRs so that three workgroups fit a CU where the LDS allows it
+#endif
 template <int KCH, int NCH, int H, int NT, int EPI, int KSPLIT, int KS = 5, int MODE = MODE_STD, int NS = 1, int DMAX = 4, int MT = 1>
-__global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
+__global__ __launch_bounds__(256, BF16_WAVES_PER_SIMD) BF16_WAVES_ATTR void conv5x5_bf16_kernel(ConvBf16Args a) {
     using T = Tile<H>;
     static_assert(NS == 1 || NS == 3, "operand splits: 1 (bf16) or 3 (fp32 emulation, 9 MFMAs per product block)");
     static_assert(MT == 1 || NS == 1, "multi-tile workgroups are a bf16-mode feature");
@@ -122,6 +131,11 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int mt0 = xcd_tile(blockIdx.x, gridDim.x) * MT, n0 = blockIdx.y * NT;
+#ifdef CONV_STAGGER        // timing experiment: the workgroups of the second residency slot start CONV_STAGGER x 4 k cycles late
+    if (blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+        for (int i = 0; i < CONV_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);
+    }
+#endif
     int img0v[MT], ty0v[MT], tx0v[MT];
 #pragma unroll
     for (int tl = 0; tl < MT; ++tl) {          // a tile index past the end maps to images >= B: loads give 0, stores are skipped
@@ -273,6 +287,39 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
     static_assert(KCH % KCB == 0 && (KCH / KCB) % KSPLIT == 0, "channel chunking");
     constexpr int NST = (KCH / KCB) / KSPLIT * KS;
     const int st0 = blockIdx.z * NST, st1 = st0 + NST;
+    // Every value the epilogue needs from memory is requested HERE, ahead of all other loads, and consumed before the first global
+    // store (conv_epilogue.h, load_bias): the bias of this lane's output columns, and for the up-conv input gradient the producer's
+    // forward activations (ReLU mask) of exactly the units this lane will store.
+    constexpr bool HAS_BIAS = (MODE == MODE_STD && KSPLIT == 1 && (EPI == EPI_BIAS_BNSTAT || EPI == EPI_BIAS_RELU)) || MODE == MODE_UP_FWD;
+    constexpr bool BNSTAT = MODE == MODE_STD && KSPLIT == 1 && EPI == EPI_BIAS_BNSTAT;
+    // bf16 mode (NS == 1): channel-major accumulators.  Behind the staging buffers: [NT bias][MT][2][4 waves][NT] BatchNorm rows
+    float* lds_x = reinterpret_cast<float*>(smem_raw) + (size_t)(MT * NS * A_UNITS + (WDMA ? 2 : 1) * NS * W_UNITS) * 4;
+    [[maybe_unused]] float biasv[NB] = {};
+    [[maybe_unused]] float bias_stash = 0.f;    // requested first, written to LDS with the first weight slab (no wait of its own)
+    if constexpr (HAS_BIAS && NS == 1) {
+        if (tid < NT) bias_stash = a.bias[MODE == MODE_UP_FWD ? (n0 + tid) % COUT_UP : n0 + tid];
+    } else if constexpr (HAS_BIAS) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int n = n0 + nb * 32;
+            biasv[nb] = a.bias[(MODE == MODE_UP_FWD ? n % COUT_UP : n) + li];
+        }
+    }
+    // up-conv input gradient, bf16 tensors: the ReLU-mask units this lane will store (pixel = its MFMA column, unit k = channels
+    // 16k + 8lh .. +7 of block nb), all tiles, requested ahead of every other load
+    [[maybe_unused]] bf16x8 mkv[(MODE == MODE_UP_DGRAD && NS == 1) ? MT * NB * 2 : 1];
+    if constexpr (MODE == MODE_UP_DGRAD && NS == 1) {
+#pragma unroll
+        for (int tl = 0; tl < MT; ++tl) {
+            const int im = m / (T::TH * T::TW), rem = m % (T::TH * T::TW);
+            const int gy = ty0v[tl] + rem / T::TW, gx = tx0v[tl] + rem % T::TW, ib = img0v[tl] + im;
+            const size_t base = ((size_t)(ib * H + gy) * H + gx) * NCH + n0 + 8 * lh;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) mkv[(tl * NB + nb) * 2 + k] = Act<__bf16>::ld8(a.aux, ib < a.B ? base + nb * 32 + 16 * k : 0);
+        }
+    }
     if constexpr (WDMA) dma_w(st0, 0); else load_w(st0);
     load_input(st0 / KS);
     [[maybe_unused]] long long ct0 = 0, ct1 = 0, ct2 = 0, ct3 = 0, ct4 = 0, cd[6] = {0, 0, 0, 0, 0, 0}, ctb = 0, cta = 0, ctw = 0;      // CONV_TIMING builds
@@ -301,6 +348,7 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
         if (r == 0) store_input();
         CT_STAMP(cta);
         store_w();
+        if constexpr (HAS_BIAS && NS == 1) { if (st == st0 && tid < NT) lds_x[tid] = bias_stash; }
         CT_STAMP(ctw);
         // issue order: vmcnt retires in order, so the (older) halo loads must not sit between a weight
         // load and the store_w that waits for it (see conv_mfma.hip)
@@ -312,12 +360,15 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
         }
         const bf16x8* ap = lds_a + lh * PSP + aPix + (r + OFF) * T::HTW + OFF;
         const bf16x8* bp = lds_w + wbuf * W_UNITS + lh * NT + li;
-        if (NS == 1) __builtin_amdgcn_iglp_opt(0);         // interleave the LDS fragment reads with the MFMAs
+#ifndef BF16_LOOP
+#define BF16_LOOP 0       // timing experiments (results WRONG unless 0): bit 0 = compiler-scheduled loop (iglp_opt) instead of the pinned pipeline, bit 1 = operands not swapped
+#endif
+        if constexpr (NS == 1 && (BF16_LOOP & 1)) {
+            __builtin_amdgcn_iglp_opt(0);
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
+            for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                if (NS == 1) {
+                for (int kb = 0; kb < KB; ++kb) {
                     bf16x8 bv[NB];
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) bv[nb] = bp[((s * KB + kb) * 2) * NT + nb * 32];
@@ -326,8 +377,51 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
                         const bf16x8 av = ap[tl * A_UNITS + (kb * 2) * PSP + s];
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb)
-                            acc[tl][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[nb], acc[tl][nb], 0, 0, 0);
+                            acc[tl][nb] = (BF16_LOOP & 2) ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[nb], acc[tl][nb], 0, 0, 0)
+                                                          : __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[nb], av, acc[tl][nb], 0, 0, 0);
                     }
+                }
+        } else if constexpr (NS == 1) {
+            // Software pipeline, written out: the fragments of step i + PF are requested before the MFMAs of step i (a step = one tap x one
+            // 16-channel block: NB weight + MT pixel fragments, MT x NB MFMAs), three register sets in rotation, and the order is PINNED with
+            // sched_group_barrier — left to itself (iglp_opt) the scheduler of hipcc 7.2 serialised `ds_read -> s_waitcnt lgkmcnt(0) -> MFMA`
+            // on one reused register quad as soon as the operand roles were swapped (E2 forward: MFMA phase 7.7 k -> 10.1 k cycles).
+            constexpr int NSTEP = KS * KB, PF = 2, NSET = 3;
+            bf16x8 wf[NSET][NB], xf[NSET][MT];
+            auto ld = [&](int i, int b) {
+                const int s = i / KB, kb = i % KB;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wf[b][nb] = bp[((s * KB + kb) * 2) * NT + nb * 32];
+#pragma unroll
+                for (int tl = 0; tl < MT; ++tl) xf[b][tl] = ap[tl * A_UNITS + (kb * 2) * PSP + s];
+            };
+#pragma unroll
+            for (int i = 0; i < PF && i < NSTEP; ++i) ld(i, i % NSET);
+            __builtin_amdgcn_sched_group_barrier(0x100, (PF < NSTEP ? PF : NSTEP) * (NB + MT), 0);
+#pragma unroll
+            for (int i = 0; i < NSTEP; ++i) {
+                if (i + PF < NSTEP) ld(i + PF, (i + PF) % NSET);
+#pragma unroll
+                for (int tl = 0; tl < MT; ++tl)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)      // weights as the A operand: D[channel][pixel], see conv_epilogue.h (channel-major)
+                        acc[tl][nb] = (BF16_LOOP & 2) ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[i % NSET][tl], wf[i % NSET][nb], acc[tl][nb], 0, 0, 0)
+                                                      : __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i % NSET][nb], xf[i % NSET][tl], acc[tl][nb], 0, 0, 0);
+                // one fragment read behind each MFMA while there are reads left in this step, then the remaining MFMAs back to back
+                constexpr int NM = MT * NB, NR = NB + MT;
+#pragma unroll
+                for (int k = 0; k < NM; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i + PF < NSTEP && k < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                if constexpr (NR > NM) { if (i + PF < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, NR - NM, 0); }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < (NS == 1 ? 0 : KS); ++s)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                if (NS == 1) {
                 } else {
                     bf16x8 av[3];
 #pragma unroll
@@ -357,11 +451,101 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
         }
 #endif
     }
+    vm_drained();
     float* smem = reinterpret_cast<float*>(smem_raw);
     const int numTiles = cdiv(a.B, T::IMGS) * T::TILES_PER_IMG;
 #ifdef CONV_TIMING
     if (CT_ON) { CT_STAMP(ct4); cd[0] += 0; }
 #endif
+    if constexpr (NS == 1) {
+        // ---- channel-major epilogue (conv_epilogue.h): every wave on its own, straight from the accumulators ----
+        [[maybe_unused]] f32x4 bq[NB][4];                 // bias of the lane's 16 channels per block: quads 8g + 4lh .. +3
+        if constexpr (HAS_BIAS) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bq[nb][g] = *reinterpret_cast<const f32x4*>(lds_x + nb * 32 + 8 * g + 4 * lh);
+        }
+        [[maybe_unused]] float* red = lds_x + NT;
+        const int e16 = li >> 1, chE = (e16 & 3) + 8 * (e16 >> 2) + 4 * lh;       // the element half_wave_colsum16 leaves in this lane
+#pragma unroll
+        for (int tl = 0; tl < MT; ++tl) {
+            const int im = m / (T::TH * T::TW), rem = m % (T::TH * T::TW);
+            const int gy = ty0v[tl] + rem / T::TW, gx = tx0v[tl] + rem % T::TW, ib = img0v[tl] + im;
+            const bool valid = ib < a.B;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                f32x16& c = acc[tl][nb];
+                if constexpr (HAS_BIAS) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const float x = c[v] + bq[nb][v >> 2][v & 3];
+                        c[v] = (MODE == MODE_UP_FWD || EPI == EPI_BIAS_RELU) ? fmaxf(x, 0.f) : x;
+                    }
+                }
+                if constexpr (MODE == MODE_STD && KSPLIT > 1) {                   // fp32 partial sums to slab z: 4 channels = 16 bytes per quad
+                    float* out = a.out + (size_t)blockIdx.z * a.sliceFloats + ((size_t)(ib * H + gy) * H + gx) * NCH + n0 + nb * 32 + 4 * lh;
+                    if (valid) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(out + 8 * g) = f32x4{c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
+                    }
+                } else {
+                    bf16x8 u[2];
+                    cm_pack_units(c, u);
+                    size_t base;
+                    if constexpr (MODE == MODE_UP_FWD) {                          // column block nb = phase p, channels c0..c0+31 of the upsampled layer
+                        const int n = n0 + nb * 32, p = n / COUT_UP, c0 = n % COUT_UP;
+                        base = ((size_t)(ib * 2 * H + 2 * gy + (p >> 1)) * (2 * H) + 2 * gx + (p & 1)) * COUT_UP + c0 + 8 * lh;
+                    } else {
+                        base = ((size_t)(ib * H + gy) * H + gx) * NCH + n0 + nb * 32 + 8 * lh;
+                    }
+                    if constexpr (MODE == MODE_UP_DGRAD) {
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const bf16x8 mk = mkv[(tl * NB + nb) * 2 + k];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) u[k][e] = (float)mk[e] > 0.f ? u[k][e] : (__bf16)0.f;
+                        }
+                    }
+                    if (valid && !(EPI_EXPERIMENT & 1)) { Act<__bf16>::st8(a.out, base, u[0]); Act<__bf16>::st8(a.out, base + 16, u[1]); }
+                    if ((EPI_EXPERIMENT & 1) && u[0][0] == (__bf16)123.f && u[1][7] == (__bf16)77.f) Act<__bf16>::st8(a.out, base, u[0]);     // timing builds: keeps the values alive
+                }
+                if constexpr (BNSTAT && !(EPI_EXPERIMENT & 2)) {          // per-wave column sums of y and y*y over its 32 pixels (pixels past the batch count as 0)
+                    float sv[16], qv[16];
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) { sv[v] = valid ? c[v] : 0.f; qv[v] = sv[v] * sv[v]; }
+                    const float S = half_wave_colsum16(sv), Q = half_wave_colsum16(qv);
+                    if ((lane & 1) == 0) {
+                        red[((tl * 2 + 0) * 4 + wave) * NT + nb * 32 + chE] = S;
+                        red[((tl * 2 + 1) * 4 + wave) * NT + nb * 32 + chE] = Q;
+                    }
+                }
+            }
+        }
+        if constexpr (BNSTAT && !(EPI_EXPERIMENT & 2)) {
+            // the four waves' rows meet once: per tile and channel (sum, M2 about the tile mean) as bn_fwd_finalize merges them
+            // (nn.BatchNorm2d train-mode statistics, vae_nets.py:70,75,80,85); M2 = Q - S*S/n in double
+            __syncthreads();
+            for (int idx = tid; idx < MT * NT; idx += 256) {
+                const int tl = idx / NT, cc = idx % NT, mt = mt0 + tl;
+                if (mt >= numTiles) continue;
+                float S = 0.f, Q = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { S += red[((tl * 2 + 0) * 4 + w) * NT + cc]; Q += red[((tl * 2 + 1) * 4 + w) * NT + cc]; }
+                int nvalid_img = a.B - img0v[tl];
+                if (nvalid_img > T::IMGS) nvalid_img = T::IMGS;
+                const double cnt = (double)(nvalid_img * T::TH * T::TW);
+                const double m2 = (double)Q - (double)S * (double)S / cnt;
+                a.bnpart[(size_t)mt * NCH + n0 + cc] = S;
+                a.bnpart[((size_t)numTiles + mt) * NCH + n0 + cc] = (float)(m2 > 0.0 ? m2 : 0.0);
+            }
+        }
+    } else {
+    if constexpr (HAS_BIAS) {                    // bias (+ ReLU) of EVERY tile in registers before the first store of any of them
+#pragma unroll
+        for (int tl = 0; tl < MT; ++tl) apply_bias<NT, (MODE == MODE_UP_FWD ? EPI_BIAS_RELU : EPI)>(acc[tl], biasv);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tl = 0; tl < MT; ++tl) {
     const int mt = mt0 + tl, img0 = img0v[tl], ty0 = ty0v[tl], tx0 = tx0v[tl];
@@ -373,13 +557,8 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
         for (int nb = 0; nb < NB; ++nb) {
             const int n = n0 + nb * 32;                               // 32 columns of one phase (COUT >= 32)
             const int p = MODE == MODE_UP_FWD ? n / COUT_UP : 0, c0 = MODE == MODE_UP_FWD ? n % COUT_UP : n;
-            const float bv = MODE == MODE_UP_FWD ? a.bias[c0 + li] : 0.f;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                float x = acc[tl][nb][v] + bv;
-                if (MODE == MODE_UP_FWD) x = fmaxf(x, 0.f);
-                patch[((v & 3) + 8 * (v >> 2) + 4 * lh) * 36 + li] = x;
-            }
+            for (int v = 0; v < 16; ++v) patch[((v & 3) + 8 * (v >> 2) + 4 * lh) * 36 + li] = acc[tl][nb][v];     // bias + ReLU applied above
             if constexpr (NS == 1) {          // bf16 tensors: 8 channels = one 16-byte unit per lane
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
@@ -398,7 +577,7 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
                         Act<__bf16>::st8(a.out, oo, o);
                     } else {
                         const size_t oo = ((size_t)(ib * H + gy) * H + gx) * NCH + c0 + c8 * 8;
-                        const bf16x8 mk = Act<__bf16>::ld8(a.aux, oo);
+                        const bf16x8 mk = mkv[(tl * NB + nb) * 2 + it];            // fetched before the first store
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = (float)mk[e] > 0.f ? o[e] : (__bf16)0.f;
                         Act<__bf16>::st8(a.out, oo, o);
@@ -427,11 +606,12 @@ __global__ __launch_bounds__(256) void conv5x5_bf16_kernel(ConvBf16Args a) {
             }
         }
     } else if (KSPLIT > 1) {
-        epilogue_store<H, NT, NCH, EPI_PLAIN, float, NS == 1>(acc[tl], nullptr, a.out + (size_t)blockIdx.z * a.sliceFloats, nullptr, smem, a.B,
+        epilogue_store<H, NT, NCH, EPI_PLAIN, float, NS == 1>(acc[tl], a.out + (size_t)blockIdx.z * a.sliceFloats, nullptr, smem, a.B,
                                                               mt, n0, img0, ty0, tx0, numTiles);
     } else {
-        if constexpr (NS == 1) epilogue_store<H, NT, NCH, EPI, __bf16, true>(acc[tl], a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0, numTiles);
-        else epilogue_store<H, NT, NCH, EPI>(acc[tl], a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0, numTiles);
+        if constexpr (NS == 1) epilogue_store<H, NT, NCH, EPI, __bf16, true>(acc[tl], a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0, numTiles, CT_ON ? tl * 12 : 32);
+        else epilogue_store<H, NT, NCH, EPI>(acc[tl], a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0, numTiles);
+    }
     }
     }
 #ifdef CONV_TIMING
@@ -533,7 +713,8 @@ static int run_bf16_ns(const ConvBf16Args& a, hipStream_t st) {
     constexpr int WBUF = (NS == 1 && BF16_WDMA != 0) ? 2 : 1;          // LDS-DMA weight slabs are double-buffered
     constexpr int STAGE = (MT * NS * (KCB / 8) * Bf16Geom<H, KCB / 8>::PSP + WBUF * NS * KS * (KCB / 16) * 2 * NT) * 16;
     constexpr int EPI_BYTES = (8 * NT > 4 * 32 * 36 ? 8 * NT : 4 * 32 * 36) * 4;
-    constexpr int SMEM = STAGE > EPI_BYTES ? STAGE : EPI_BYTES;
+    // bf16 mode: no transpose patch; bias row + BatchNorm rows of the channel-major epilogue sit behind the staging buffers
+    constexpr int SMEM = NS == 1 ? STAGE + (NT + MT * 8 * NT) * 4 : (STAGE > EPI_BYTES ? STAGE : EPI_BYTES);
     auto kern = conv5x5_bf16_kernel<KCH, NCH, H, NT, EPI, KSPLIT, KS, MODE, NS, DMAX, MT>;
     static DeviceOnce once;
     { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(kern), SMEM); if (rc) return rc; }
@@ -657,6 +838,7 @@ __global__ __launch_bounds__(256) void conv4x4_row_bf16_kernel(ConvBf16Args a) {
         }
     // KSPLIT > 1: fp32 partial sums to slab z (the callers' finish kernels add them, add the bias, round);  KSPLIT == 1: the plain
     // result straight to the bf16 tensor (input gradient at large batches: no slab, no finish launch)
+    vm_drained();
     float* out = a.out + (size_t)blockIdx.z * a.sliceFloats;
     __bf16* out16 = reinterpret_cast<__bf16*>(a.out);
 #pragma unroll

@@ -151,6 +151,8 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
     static_assert((KCH / KC) % KSPLIT == 0, "split-K must divide the channel chunks");
     constexpr int NST = (KCH / KC) / KSPLIT * 5;
     const int st0 = blockIdx.z * NST, st1 = st0 + NST;
+    [[maybe_unused]] float biasv[NB];              // fetched here, ahead of every other load: consumed before the first store
+    if constexpr (KSPLIT == 1 && (EPI == EPI_BIAS_BNSTAT || EPI == EPI_BIAS_RELU)) load_bias<NT, EPI>(biasv, a.bias, n0);
     load_w(st0);
     load_input(st0 / 5);
     [[maybe_unused]] long long ct0 = 0, ct1 = 0, ct2 = 0, ct3 = 0, ct4 = 0, cd[6] = {0, 0, 0, 0, 0, 0}, ctb = 0, cta = 0, ctw = 0;      // CONVF_TIMING builds
@@ -195,13 +197,16 @@ __global__ __launch_bounds__(256) void conv5x5_mfma_kernel(ConvArgs a) {
 #endif
     }
     CF_STAMP(ct4);
+    vm_drained();
 
     // ------------------------------- epilogue -------------------------------
     if (KSPLIT > 1) {
-        epilogue_store<H, NT, NCH, EPI_PLAIN>(acc, nullptr, a.out + (size_t)blockIdx.z * a.sliceFloats, nullptr, smem, a.B,
+        epilogue_store<H, NT, NCH, EPI_PLAIN>(acc, a.out + (size_t)blockIdx.z * a.sliceFloats, nullptr, smem, a.B,
                                               mt, n0, img0, ty0, tx0);
     } else if (EPI == EPI_BIAS_BNSTAT || EPI == EPI_BIAS_RELU || EPI == EPI_PLAIN) {
-        epilogue_store<H, NT, NCH, EPI>(acc, a.bias, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0);
+        apply_bias<NT, EPI>(acc, biasv);           // both channel blocks before the first store (conv_epilogue.h)
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue_store<H, NT, NCH, EPI>(acc, a.out, a.bnpart, smem, a.B, mt, n0, img0, ty0, tx0);
     } else {   // EPI_POOLSUM_MASK: 2x2 sum (upsample backward) then ReLU mask of the producer
         __syncthreads();
         float* lo = smem;                            // [128][NT+1]
@@ -381,6 +386,7 @@ __global__ __launch_bounds__(256) void conv4x4_row_kernel(ConvArgs a) {
             }
         }
     // raw partial sums of slab z: row (image) (v&3) + 8 (v>>2) + 4 lh of the wave's 32, pixel (ya + t, wave ^ t), channel n0 + 32 nb + li
+    vm_drained();
     float* out = a.out + (size_t)blockIdx.z * a.sliceFloats;
 #pragma unroll
     for (int t = 0; t < 2; ++t)

@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void conv_up_fwd_kernel(UpArgs a) {
     static_assert((CIN / KC) % KSPLIT == 0, "split-K must divide the channel chunks");
     constexpr int NST = (CIN / KC) / KSPLIT * 3;
     const int st0 = blockIdx.z * NST, st1 = st0 + NST;
+    const float bv = KSPLIT > 1 ? 0.f : a.bias[n0 + li];          // requested ahead of every other load (conv_epilogue.h, load_bias)
     load_w(st0);
     load_input(st0 / 3);
     for (int st = st0; st < st1; ++st) {
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void conv_up_fwd_kernel(UpArgs a) {
             }
     }
     // epilogue: phase p of low-res pixel (y,x) -> output pixel (2y+py, 2x+px)
-    const float bv = KSPLIT > 1 ? 0.f : a.bias[n0 + li];
+    vm_drained();
     float* out = KSPLIT > 1 ? a.out + (size_t)blockIdx.z * a.sliceFloats : a.out;
 #pragma unroll
     for (int p = 0; p < 4; ++p)
@@ -300,29 +301,32 @@ __global__ __launch_bounds__(256) void conv_up_dgrad_kernel(UpArgs a) {
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, lds_w[bBase + (t * NT + nb * 32) * KCP + 2 * j], acc[nb], 0, 0, 0);
             }
     }
+    vm_drained();
     float* out = KSPLIT > 1 ? a.out + (size_t)blockIdx.z * a.sliceFloats : a.out;
-    // the ReLU mask values of one 32-channel block are all requested before the first store: `out` and `aux`
-    // may alias as far as the compiler knows, and a load behind each store is one memory round trip per element
+    // the ReLU mask values of ALL channel blocks are requested before the first store: vmcnt retires loads and stores together in
+    // issue order, so a mask load issued behind a store waits for that store's write acknowledgement (and `out` / `aux` may alias
+    // as far as the compiler knows: a load behind each store would be one memory round trip per element)
+    size_t o[NB][16];
+    float mk[NB][16];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        size_t o[16];
-        float mk[16];
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int mm = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
             const int im = mm / (T::TH * T::TW), rem = mm % (T::TH * T::TW), ib = img0 + im;
-            o[v] = ((size_t)(ib * HS + ty0 + rem / T::TW) * HS + tx0 + rem % T::TW) * CIN + n0 + nb * 32 + li;
-            if (KSPLIT == 1) mk[v] = a.aux[ib < a.B ? o[v] : 0];
+            o[nb][v] = ((size_t)(ib * HS + ty0 + rem / T::TW) * HS + tx0 + rem % T::TW) * CIN + n0 + nb * 32 + li;
+            if (KSPLIT == 1) mk[nb][v] = a.aux[ib < a.B ? o[nb][v] : 0];
         }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int mm = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
             if (img0 + mm / (T::TH * T::TW) >= a.B) continue;
             float x = acc[nb][v];
-            if (KSPLIT == 1) x = mk[v] > 0.f ? x : 0.f;
-            out[o[v]] = x;
+            if (KSPLIT == 1) x = mk[nb][v] > 0.f ? x : 0.f;
+            out[o[nb][v]] = x;
         }
-    }
 }
 
 // split-K finish kernels

@@ -21,21 +21,10 @@
 // Results differ from the fp32 path at the bf16 rounding level (~3e-3 relative per product);
 // tests/test_gpu_bf16.py states the tolerances.
 #include "common.h"
+#include <stdlib.h>
 #include "conv_epilogue.h"
+#include "conv_bf16.h"
 
-
-struct ConvBf16Args {
-    const float* in;        // NHWC, KCH channels: bf16 when NS == 1 (opaque pointer), fp32 when NS == 3
-    const bf16x8* wp;       // packed weights [25][KCH/16][2][NCH] units of 8 bf16
-    const float* bias;
-    float* out;
-    float* bnpart;
-    int B;
-    int64_t sliceFloats;    // KSPLIT > 1: out = slab [KSPLIT][sliceFloats]
-    const float* aux;       // MODE_UP_DGRAD: forward output of the producing layer (ReLU mask), layout of `out`
-    int64_t splitStride;    // NS == 3: units between the hi / mid / lo copies of the packed weights
-    int products;           // NS == 3: 9 (all partial products) or 6
-};
 
 // Exact 3-way bf16 split of an fp32 value: x == hi + mid + lo (each difference is exact in fp32, RNE
 // leaves at most 8 significant bits per step), used by the fp32-emulation mode (NS == 3): the nine
@@ -81,13 +70,6 @@ template <int KCH, int NS, int MT> struct Bf16Chunk {
     static constexpr int KCB = KCH < CAP ? KCH : CAP;
 };
 
-template <int H, int OCT> struct Bf16Geom {
-    // halo plane stride in 16-byte units: >= HP and == 16/OCT (mod 16) so that the 16 lanes of one b128
-    // write phase (OCT octets x 16/OCT pixels) land in 16 different 16-byte bank groups
-    static constexpr int PAD = OCT >= 8 ? 2 : (OCT == 4 ? 4 : 8);
-    static constexpr int PSP = ((Tile<H>::HP + 15 - PAD) / 16) * 16 + PAD;
-};
-
 // MT = 128-pixel tiles per workgroup (bf16 mode: 2): one weight slab staged into LDS — and one weight fragment read
 // from LDS — serves MT times as many MFMAs; the K chunk shrinks to 32 channels so that the LDS footprint (and with
 // it the number of resident workgroups) stays where it was.
@@ -95,7 +77,7 @@ template <int H, int OCT> struct Bf16Geom {
 extern "C" int cvae_epi_dbg_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(epi_dbg), sizeof(epi_dbg)); }
 #endif
 #ifdef CONV_TIMING     // experiment builds only: where a wave of ONE instantiation (-DCONV_TIMING_KCH/NCH/H) spends its stages
-__device__ long long conv_dbg[16 * 4 * 10];
+__device__ long long conv_dbg[16 * 4 * 12];
 extern "C" int cvae_conv_dbg_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(conv_dbg), sizeof(conv_dbg)); }
 #define CT_ON (KCH == CONV_TIMING_KCH && NCH == CONV_TIMING_NCH && H == CONV_TIMING_H && NS == 1 && MODE == MODE_STD)
 #define CT_STAMP(v) do { if (CT_ON) v = clock64(); } while (0)
@@ -324,6 +306,7 @@ __global__ __launch_bounds__(256, BF16_WAVES_PER_SIMD) BF16_WAVES_ATTR void conv
     load_input(st0 / KS);
     [[maybe_unused]] long long ct0 = 0, ct1 = 0, ct2 = 0, ct3 = 0, ct4 = 0, cd[6] = {0, 0, 0, 0, 0, 0}, ctb = 0, cta = 0, ctw = 0;      // CONV_TIMING builds
     CT_STAMP(ctb);
+    [[maybe_unused]] const long long crt0 = CT_ON ? (long long)wall_clock64() : 0;
     for (int st = st0; st < st1; ++st) {
         const int r = st % KS;
         int wbuf = 0;
@@ -617,8 +600,9 @@ __global__ __launch_bounds__(256, BF16_WAVES_PER_SIMD) BF16_WAVES_ATTR void conv
 #ifdef CONV_TIMING
     if (CT_ON && (blockIdx.x & 63) == 0 && blockIdx.x < 1024 && blockIdx.y == 0 && lane == 0) {
         long long tend = clock64();
-        long long* o = conv_dbg + ((blockIdx.x >> 6) * 4 + wave) * 10;
+        long long* o = conv_dbg + ((blockIdx.x >> 6) * 4 + wave) * 12;
         o[0] = cd[0]; o[1] = cd[1]; o[2] = cd[2]; o[3] = cd[3]; o[4] = ct4 - ctb; o[5] = tend - ct4; o[6] = st1 - st0; o[7] = tend - ctb; o[8] = cd[4]; o[9] = cd[5];
+        o[10] = (long long)wall_clock64() - crt0;        // 100 MHz ticks over the same span: in-kernel clock = o[7] / o[10] * 100 MHz
     }
 #endif
 }
@@ -865,9 +849,21 @@ static int run4x4_bf16(const ConvBf16Args& a, hipStream_t st) {
 
 bool conv_bf16_supported(int layer, int width) { return (width == 64 || width == 128) && layer >= 1 && layer <= 7; }
 
+// bf16 mode: E2..E4 forward / input gradient run on the persistent kernel of conv_bf16_ps.hip (CVAE_CONV_PS=0: the per-tile kernel, for A/B runs)
+// CVAE_CONV_PS = bit mask of the layers that run on it: bit (layer - 1) forward, bit (3 + layer - 1) input gradient (0 = none: A/B runs)
+#ifndef CONV_PS_DEFAULT
+#define CONV_PS_DEFAULT 7        // forward E2..E4 on the persistent kernel; the input gradients measured level or slower on it
+#endif
+static bool use_ps_kernel(int layer, bool dgrad) {
+    static const int mask = [] { const char* e = getenv("CVAE_CONV_PS"); return e ? atoi(e) : CONV_PS_DEFAULT; }();
+    const int bit = (dgrad ? 3 : 0) + (layer >= 4 ? 2 : layer - 1);       // layer 4 (128-wide frames only) shares E4's bit
+    return ((mask >> bit) & 1) != 0;
+}
+
 int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, const float* packed, const float* bias, float* out,
                          float* bnpart, float* ws, hipStream_t st) {
     ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0, ns >= 3 ? 3 : 1), bias, out, bnpart, B, 0, nullptr, ns >= 3 ? pack_units(layer) : 0, ns == 6 ? 6 : 9};
+    if (ns == 1 && use_ps_kernel(layer, false)) { const int rc = launch_conv_bf16_ps(layer, width, false, a, st); if (rc != -100) return rc; }
     if (width == 64) {
         switch (layer) {
             case 1: return run_bf16<32, 64, 32, 64, EPI_BIAS_BNSTAT>(a, st);
@@ -898,6 +894,7 @@ int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, c
 
 int launch_conv_dgrad_bf16(int layer, int width, int ns, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st) {
     ConvBf16Args a{dout, pack_ptr(const_cast<float*>(packed), layer, 1, ns >= 3 ? 3 : 1), nullptr, din, nullptr, B, 0, nullptr, ns >= 3 ? pack_units(layer) : 0, ns == 6 ? 6 : 9};
+    if (ns == 1 && use_ps_kernel(layer, true)) { const int rc = launch_conv_bf16_ps(layer, width, true, a, st); if (rc != -100) return rc; }
     if (width == 64) {
         switch (layer) {
             case 1: return run_bf16<64, 32, 32, 32, EPI_PLAIN>(a, st);

@@ -764,8 +764,16 @@ __global__ __launch_bounds__(256) void msssim_finalize_kernel(MsFinArgs a) {
         if (lane < 5) a.scalars[3 + lane] = meanf;
         else if (lane < 10) a.scalars[8 + l] = meanf;
         else if (lane < 13) a.scalars[13 + lane - 10] = 0.f;
-        if (lane >= 5 && lane < 9) a.coef[l] = (float)((double)(-out * wts[l] / meanf) / cnt);
-        if (lane == 4) a.coef[4] = (float)((double)(-out * 4.0f * wts[4] / meanf) / cnt);
+        // autograd of the reference also differentiates the terms `prod(pow1[:-1] * pow2[-1])` never uses — mssim ** weights and
+        // mcs ** weights are evaluated for all five levels (vae_nets.py:243-244) — with an incoming gradient of exactly 0:
+        // 0 * w * x^(w-1), which is 0 for x > 0 but NaN for x < 0 (fractional power) and for x == 0 (0 * inf).  A negative
+        // ssim level 0..3 (dark real frames against an untrained decoder) or cs level 4 therefore turns EVERY gradient that passes
+        // through recon into NaN while the loss itself stays finite (tests/golden/step_real_b68.npz, "seed0/").  Same arithmetic
+        // here: the poison term is added to the level's coefficient.
+        const float poison = 0.0f * (wts[l] * powf(meanf, wts[l] - 1.0f));          // lanes 0-4: ssim_l, lanes 5-9: cs_l
+        const float p_ssim = __shfl(poison, l, 64), p_cs4 = __shfl(poison, 9, 64);
+        if (lane >= 5 && lane < 9) a.coef[l] = (float)((double)(-out * wts[l] / meanf) / cnt) + p_ssim;
+        if (lane == 4) a.coef[4] = (float)((double)(-out * 4.0f * wts[4] / meanf) / cnt) + p_cs4;
     }
 }
 

@@ -25,12 +25,13 @@ eps = torch.randn(B, 32, device=dev)
 for _ in range(5):
     tr.step(x, pred, eps)
 torch.cuda.synchronize()
-buf = (ctypes.c_longlong * 640)()
+buf = (ctypes.c_longlong * 768)()
 (vae.handle.lib.cvae_conv_dbg_read if PREC == "bf16" else vae.handle.lib.cvae_convf_dbg_read)(buf)
 names = ["barrier1", "stage", "barrier2", "mfma"]
+ST = 12 if PREC == "bf16" else 10          # the bf16 build also records s_memrealtime ticks (slot 10) for the in-kernel clock
 for g in range(16):
     for w in range(4):
-        t = list(buf[(g * 4 + w) * 10:(g * 4 + w) * 10 + 10])
+        t = list(buf[(g * 4 + w) * ST:(g * 4 + w) * ST + ST]) + [0, 0]
         if t[7] == 0:
             continue
-        print(f"wg {64 * g:4d} wave {w}: " + "  ".join(f"{n} {t[i]}" for i, n in enumerate(names)) + f" (store_input {t[8]} store_w {t[9]})  mainloop {t[4]}  epilogue {t[5]}  stages {t[6]}  total {t[7]}")
+        print(f"wg {64 * g:4d} wave {w}: " + "  ".join(f"{n} {t[i]}" for i, n in enumerate(names)) + f" (store_input {t[8]} store_w {t[9]})  mainloop {t[4]}  epilogue {t[5]}  stages {t[6]}  total {t[7]}  clock {t[7] / max(t[10], 1) * 0.1:.2f} GHz")

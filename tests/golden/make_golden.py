@@ -99,10 +99,15 @@ def sample_idx(name, n):
     return np.minimum((u.astype(np.float64) * n).astype(np.int64), n - 1)
 
 
-def step_case(tag, batch, wseed=0, dseed=1234, step=0, width=64):
-    params_np = synth.make_params(wseed, width)
+def step_case(tag, batch, wseed=0, dseed=1234, step=0, width=64, real=None, params_np=None):
+    """real = (x, pred, extra fixture entries): frames / critic predictions given instead of generated (real_frames_case);
+    params_np: explicit parameters instead of the generator's seed-`wseed` ones."""
+    if params_np is None:
+        params_np = synth.make_params(wseed, width)
     x_np, pred_np, eps_np = synth.make_batch(dseed, step, batch, width)
     x, pred, eps = map(torch.from_numpy, (x_np, pred_np, eps_np))
+    if real is not None:
+        x, pred = real[0], real[1]
 
     v = load_reference(params_np, width)
     out, losses = run_reference_step(v, x, pred, eps)
@@ -124,6 +129,8 @@ def step_case(tag, batch, wseed=0, dseed=1234, step=0, width=64):
                               losses["KLD"].item()], np.float32)}
     if batch <= 2:
         fx["recon"] = recon.detach().numpy()
+    if real is not None:
+        fx.update(real[2])
 
     worst = 0.0
     rp = ref_named_params(v)
@@ -154,6 +161,61 @@ def step_case(tag, batch, wseed=0, dseed=1234, step=0, width=64):
     assert all(np.isfinite(fx["losses"])), "pick a finite seed"
     assert max(d["mu"], d["logvar"], d["recon"], d["loss"]) < 1e-6 and worst < 1e-5, d
     np.savez_compressed(os.path.join(HERE, f"step_{tag}.npz"), **fx)
+
+
+REAL_BIAS_SHIFT = 0.2      # added to decoder.model.12.bias (the last conv, vae_nets.py:133) for the real-frames fixture
+
+
+def real_frames_case():
+    """The reference's own evaluation frames (source-images/*.jpg, 68 MineRL frames of 64x64x3, vae.py:80-88) through its own
+    pre-processing (adjust_values + HWC -> CHW, vae_utility.py:324-343), critic predictions from the reference's Critic with its
+    REAL checkpoint (critic_net.py:66-69), then the reference's forward + vae_loss + backward.
+    Two parameter sets:
+      * the generator's seed-0 weights: the loss is finite (0.8214) but EVERY gradient that passes through `recon` is NaN —
+        ssim level 0 is negative (-0.0166), `mssim ** weights` (vae_nets.py:244) is evaluated for all five levels although only
+        the last one is used, and autograd's 0 * d(x^w)/dx at x < 0 is 0 * NaN = NaN.  Recorded under "seed0/": the scalars and,
+        per tensor, whether its gradient is finite (a reference quirk the HIP path must reproduce, not paper over);
+      * the same weights with the last decoder conv's bias raised by REAL_BIAS_SHIFT = 0.2 (the frames' mean brightness is 0.186;
+        an untrained decoder paints ~0, and against dark real frames that is what makes the level-0 luminance term negative):
+        all five ssim levels positive, finite gradients — the main fixture (usual contents of step_case).  An exactly
+        reproducible parameter set on both sides; weights "after k reference Adam steps" are not (Adam turns round-off level
+        gradient differences between thread counts into O(lr) parameter differences, SURVEY A.5: 5.5e-6 after 10 steps).
+    Stored once: the 68 uint8 frames (data) and the predictions.  Real frames have flat regions: max-pool ties and ReLU
+    inputs at zero are common, which white-noise fixtures never exercise."""
+    import critic_net
+    from PIL import Image
+    d = "/root/reference/source-images"
+    files = sorted(f for f in os.listdir(d) if f.endswith(".jpg"))
+    u8 = np.stack([np.array(Image.open(os.path.join(d, f))) for f in files])
+    assert u8.shape == (68, 64, 64, 3) and u8.dtype == np.uint8
+    x = torch.from_numpy((u8.astype(np.float32) / 255).transpose(0, 3, 1, 2).copy())         # adjust_values + transpose(2, 0, 1)
+    cd = "/root/reference/saved-networks"
+    ck = sorted(f for f in os.listdir(cd) if f.startswith("critic"))[0]
+    c = critic_net.Critic(); c.load_state_dict(torch.load(os.path.join(cd, ck), map_location="cpu")); c.eval()
+    pred = c.evaluate(x)
+    assert (orc.preprocess_frames(torch.from_numpy(u8)) - x).abs().max().item() == 0.0
+    extra = {"u8": u8, "pred": pred.numpy(), "critic_checkpoint": ck, "files": np.array(files),
+             "last_bias_shift": np.float32(REAL_BIAS_SHIFT)}
+    # (1) seed-0 weights: finite loss, NaN gradients
+    eps = torch.from_numpy(synth.make_batch(1234, 0, 68)[2])
+    v0 = load_reference(synth.make_params(0))
+    out0, l0 = run_reference_step(v0, x, pred, eps)
+    s0, c0 = ref_levels(v0, out0[3], x)
+    extra["seed0/losses"] = np.array([l0["total_loss"].item(), l0["recon_loss"].item(), l0["KLD"].item()], np.float32)
+    extra["seed0/ssim_levels"], extra["seed0/cs_levels"] = s0, c0
+    extra["seed0/mu"] = out0[1].detach().numpy()
+    names = sorted(ref_named_params(v0))
+    extra["seed0/grad_names"] = np.array(names)
+    extra["seed0/grad_finite"] = np.array([bool(torch.isfinite(ref_named_params(v0)[k].grad).all()) for k in names])
+    assert np.isfinite(extra["seed0/losses"]).all() and s0[0] < 0 and not extra["seed0/grad_finite"].all()
+    op = orc.to_torch(synth.make_params(0), requires_grad=True)
+    orc.train_step(op, x, pred, eps)
+    assert [bool(torch.isfinite(op[k].grad).all()) for k in names] == list(extra["seed0/grad_finite"]), "oracle NaN pattern != reference"
+    print("[real seed0] loss", extra["seed0/losses"], "ssim", s0, "finite-gradient tensors:", [k for k, f in zip(names, extra["seed0/grad_finite"]) if f])
+    # (2) last bias raised: the main fixture
+    wp = synth.make_params(0)
+    wp["decoder.model.12.bias"] = wp["decoder.model.12.bias"] + np.float32(REAL_BIAS_SHIFT)
+    step_case("real_b68", 68, real=(x, pred, extra), params_np=wp)
 
 
 def trajectory_case(n_frames=1024, batch=32, wseed=0, dseed=1234):
@@ -312,6 +374,7 @@ if __name__ == "__main__":
     step_case("b2", 2)
     step_case("b32", 32)
     step_case("w128_b2", 2, width=128)
+    real_frames_case()
     msssim_cases()
     critic_case()
     critic_real_case()

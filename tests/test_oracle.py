@@ -46,6 +46,54 @@ def test_step_matches_reference_fixture(golden_dir, tag):
         assert np.abs(bn[f"encoder.model.{bi}.running_var"].numpy() - fx[f"bn_running_var/{bi}"]).max() < TOL
 
 
+def real_frames_inputs(fx, cw):
+    """(x, pred, eps) of tests/golden/step_real_b68.npz through the oracle's pre-processing and critic."""
+    x = orc.preprocess_frames(torch.from_numpy(fx["u8"]))
+    sd = {k[2:]: torch.from_numpy(cw[k]) for k in cw.files if k.startswith("w/")}
+    pred = orc.critic_forward(sd, x)
+    eps = torch.from_numpy(synth.make_batch(int(fx["dseed"]), int(fx["step"]), int(fx["batch"]))[2])
+    return x, pred, eps
+
+
+def real_frames_params(fx):
+    """The parameters the real-frames fixture was written on: the generator's seed-`wseed` weights with the last decoder conv's
+    bias raised by fx["last_bias_shift"] (make_golden.real_frames_case says why)."""
+    pn = synth.make_params(int(fx["wseed"]))
+    pn["decoder.model.12.bias"] = pn["decoder.model.12.bias"] + np.float32(fx["last_bias_shift"])
+    return pn
+
+
+def test_step_on_the_references_real_frames(golden_dir):
+    """tests/golden/step_real_b68.npz: the reference's own 68 evaluation frames (source-images/*.jpg) through its own
+    pre-processing, predictions of its Critic with the real checkpoint, its forward / vae_loss / backward
+    (make_golden.real_frames_case).  The oracle — uint8 frames -> preprocess_frames -> critic_forward (weights from
+    critic_real_b8.npz) -> train_step — must reproduce every stored number: on the weights with the raised last bias (finite
+    gradients) and on the plain seed-0 weights, where the reference's loss is finite but every gradient is NaN (0 * d(x^w)/dx at a negative ssim level)."""
+    fx = np.load(os.path.join(golden_dir, "step_real_b68.npz"))
+    cw = np.load(os.path.join(golden_dir, "critic_real_b8.npz"))
+    assert str(fx["critic_checkpoint"]) == str(cw["checkpoint"])
+    x, pred, eps = real_frames_inputs(fx, cw)
+    assert np.abs(pred.numpy() - fx["pred"]).max() < 1e-6
+    # seed-0 weights: finite loss, NaN gradients
+    p0 = orc.to_torch(synth.make_params(int(fx["wseed"])), requires_grad=True)
+    o0 = orc.train_step(p0, x, pred, eps)
+    assert np.isfinite(fx["seed0/losses"]).all() and abs(o0["total_loss"].item() - fx["seed0/losses"][0]) < TOL
+    assert fx["seed0/ssim_levels"][0] < 0 and np.abs(o0["ssim_levels"].numpy() - fx["seed0/ssim_levels"]).max() < TOL
+    for k, fin in zip(fx["seed0/grad_names"], fx["seed0/grad_finite"]):
+        assert bool(torch.isfinite(p0[str(k)].grad).all()) == bool(fin), k
+    # last bias raised: the usual step parity
+    p = orc.to_torch(real_frames_params(fx), requires_grad=True)
+    o = orc.train_step(p, x, pred, eps, bn_state=orc.new_bn_state(p))
+    assert np.isfinite(fx["losses"]).all() and (fx["ssim_levels"] > 0).all()
+    assert np.abs(o["mu"].detach().numpy() - fx["mu"]).max() < TOL and np.abs(o["logvar"].detach().numpy() - fx["logvar"]).max() < TOL
+    assert np.abs(o["recon"].detach().numpy().reshape(-1)[::16] - fx["recon_sample"]).max() < TOL
+    assert np.abs(o["cs_levels"].numpy() - fx["cs_levels"]).max() < TOL and np.abs(o["ssim_levels"].numpy() - fx["ssim_levels"]).max() < TOL
+    assert abs(o["total_loss"].item() - fx["losses"][0]) < TOL
+    for name, t in p.items():
+        g = t.grad.numpy().reshape(-1)
+        assert np.abs(g[fx["grad_idx/" + name]] - fx["grad_val/" + name]).max() <= 1e-4 * max(float(fx["grad_max/" + name]), 1e-30) + 1e-9, name
+
+
 def test_msssim_ops_incl_nan(golden_dir):
     fx = np.load(os.path.join(golden_dir, "msssim_ops.npz"))
     assert np.abs(orc.ms_window_1d().numpy() - fx["window_1d"]).max() < 1e-7

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256, THIN_F32_OCC) void e1_fwd_kernel(const float* 
     __shared__ __attribute__((aligned(16))) float patch_all[4 * 32 * 36];
     __shared__ float red[2][4][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int ib = blockIdx.x / (SX * SY), t = blockIdx.x % (SX * SY);
+    const int strip = xcd_tile(blockIdx.x, gridDim.x);      // each XCD owns a contiguous range of strips: shared halo rows meet in ONE L2
+    const int ib = strip / (SX * SY), t = strip % (SX * SY);
     const int ty0 = (t / SX) * SR, tx0 = (t % SX) * SW;
     float bw[38];
 #pragma unroll
@@ -109,8 +110,8 @@ __global__ __launch_bounds__(256, THIN_F32_OCC) void e1_fwd_kernel(const float* 
     __syncthreads();
     if (tid < 32) {
         const size_t nt = gridDim.x;
-        bnpart[(size_t)blockIdx.x * 32 + tid] = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
-        bnpart[(nt + blockIdx.x) * 32 + tid] = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+        bnpart[(size_t)strip * 32 + tid] = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
+        bnpart[(nt + strip) * 32 + tid] = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
     }
     (void)B;
 }
@@ -211,8 +212,15 @@ __global__ __launch_bounds__(256, PASS == 1 ? 3 : 2) void e1_fwd_bf16_kernel(   
             okm = ok ? (okm | (1u << i)) : (okm & ~(1u << i));
         }
     };
-    if ((int)blockIdx.x < numStrips) fetch(blockIdx.x);
-    for (int strip = blockIdx.x; strip < numStrips; strip += gridDim.x) {
+    // XCD-aware strip order (round 4): workgroups are dealt to the 8 XCDs round-robin, and with strip = workgroup + k * grid the
+    // neighbouring strips of a frame — which share 4 of their 20 halo rows and 8 of their 40 columns — ran on different XCDs:
+    // every L2 fetched its own copy.  Measured with the kernel's exact loads (profiles/experiments/e1_fetch_probe.hip,
+    // FETCH_SIZE): 246.6 MB for the 100.7 MB tensor, 100.7 MB once each XCD owns a contiguous range of strips.
+    const int G = gridDim.x, b = blockIdx.x;
+    const bool xcd = !((G & 7) || (numStrips & 7));
+    const int sbase = xcd ? (b & 7) * (numStrips >> 3) + (b >> 3) : b, sstep = xcd ? G >> 3 : G;      // strip of turn k = sbase + k * sstep
+    if (b < numStrips) fetch(sbase);
+    for (int n = b, strip = sbase; n < numStrips; n += G, strip += sstep) {
         const int ib = strip / (SX * SY), t = strip % (SX * SY);
         const int ty0 = (t / SX) * SR, tx0 = (t % SX) * SW;
         __syncthreads();                         // every wave is done with the previous strip's LDS image
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(256, PASS == 1 ? 3 : 2) void e1_fwd_bf16_kernel(   
             if (q < HR_ * HWX) { bf16x4 u; u[0] = (__bf16)(ok ? v0[i] : 0.f); u[1] = (__bf16)(ok ? v1[i] : 0.f); u[2] = (__bf16)(ok ? v2[i] : 0.f); u[3] = (__bf16)0.f; lds_x[q] = u; }
         }
         __syncthreads();
-        if (strip + (int)gridDim.x < numStrips) fetch(strip + gridDim.x);
+        if (n + G < numStrips) fetch(strip + sstep);
         f32x16 acc[4];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) acc[rr] = e1_wk_conv<HWX>(lds_x + (wave * 4 + rr) * HWX + li, lh, bw);

@@ -502,8 +502,6 @@ __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
     const int pl = grp * PPW + sub;
     const bool valid = pl < a.P;                          // planes past the end: same work on the last plane, no stores
     const int plane = valid ? pl : a.P - 1;
-    const float* px = a.x + (size_t)plane * S * S;
-    const float* py = a.y + (size_t)plane * S * S;
     MS_T(0);
     // ---- stage the plane, (x, y) interleaved per pixel (the zero columns either side are already there) ----
     {
@@ -571,6 +569,7 @@ __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
     const int vr = (tid / H) * 2, vc = (tid % H) * 2;
     float* dA = lin; float* dC = lin + 2 * S * T::DAS;
     float s_ssim = 0.f, s_cs = 0.f;
+    f32x4 xy_keep[2];                     // (x0, y0, x1, y1) of rows vr, vr + 1 at columns vc, vc + 1
     {
         constexpr int VR = 2;
         f32x2 mu[VR][2], aa[VR][2], a12[VR];
@@ -600,6 +599,10 @@ __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
             ms_point2<LAST>(f32x2{mu[o][0].x, mu[o][1].x}, f32x2{mu[o][0].y, mu[o][1].y}, f32x2{aa[o][0].x, aa[o][1].x},
                             f32x2{aa[o][0].y, aa[o][1].y}, a12[o], &ss, &cs, &dmv, &d11v, &d12v);
             s_ssim += ss.x + ss.y; s_cs += cs.x + cs.y;
+            // the derivative pair overwrites exactly this thread's own (x, y) pixels of row r: keep them for the last pass (F = f0 +
+            // 2 x f1 + y f2) instead of fetching them again from global memory, where — 19 k cycles and 1.8 MB of other planes per
+            // XCD later — 70 % of the lines had left L2 (round 3: 490 MB of HBM traffic for 352 MB algorithmic)
+            xy_keep[o] = *reinterpret_cast<const f32x4*>(dA + (r * T::DAS + 6 + vc) * 2);
             *reinterpret_cast<f32x4*>(dA + (r * T::DAS + 6 + vc) * 2) = f32x4{dmv.x, d11v.x, dmv.y, d11v.y};
             *reinterpret_cast<f32x2*>(dC + r * T::DCS + 6 + vc) = d12v;
         }
@@ -664,11 +667,11 @@ __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
     {
         constexpr int VR = 2;
         const size_t g = (size_t)vr * S + vc;
-        float2 xv[VR], yv[VR];               // L2 hits, issued ahead of the filter
+        float2 xv[VR], yv[VR];               // kept from the staged image (see the vertical pass above)
 #pragma unroll
         for (int o = 0; o < VR; ++o) {
-            xv[o] = *reinterpret_cast<const float2*>(px + g + (size_t)o * S);
-            yv[o] = *reinterpret_cast<const float2*>(py + g + (size_t)o * S);
+            xv[o] = make_float2(xy_keep[o][0], xy_keep[o][2]);
+            yv[o] = make_float2(xy_keep[o][1], xy_keep[o][3]);
         }
         f32x2 f01[VR][2], f2[VR];
 #pragma unroll

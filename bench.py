@@ -536,8 +536,8 @@ def main():
                             label=f"BASELINE.json configs[1] workload with fp32 EMULATED on the bf16 MFMA ({what}; forward + input gradients of E2-E4 / D0)")
                 full = time_workload(cx, spec, args.steps, args.warmup, probing)
                 detail[f"fp32_emulated_{prec}"] = full
-                cfgd.update(flat_summary(prec, full))
-                cfgd[f"fp32_emulated_{prec}"] = compact(full)
+                keep = ("images_per_s", "ms_per_step", "steps", "final_loss", "roofline_kernel", "roofline_frac", "roofline_avg_launch_us")
+                cfgd.update({k: v for k, v in flat_summary(prec, full).items() if k[len(prec) + 1:] in keep})       # nested form: detail file only
             dr = dropin_rate(cx)
             detail["dropin"] = dr
             cfgd["dropin_images_per_s"] = dr["value"]

@@ -16,6 +16,7 @@
 // src=(y>>1,x>>1) into the halo gather; its backward (2x2 sum) and the ReLU mask are the
 // POOLSUM epilogue of dgrad.
 #include "common.h"
+#include <stdlib.h>
 #include "conv_epilogue.h"
 
 
@@ -446,8 +447,20 @@ int64_t conv_fwd_ws_floats(int layer, int width, int B) {
     return (int64_t)D0_KSPLIT * B * h * h * kLayers[4].cout;
 }
 
+// conv_mfma_ps.hip: persistent form of E2..E4 forward / input gradient.  CVAE_CONVF_PS = bit mask of the layers that run on it
+// (bit layer-1 forward, bit 3+layer-1 input gradient; 0 = none, for A/B runs).
+int launch_conv_mfma_ps(int layer, int width, bool dgrad, int B, const float* in, const float* w, const float* bias, float* out, float* bnpart, hipStream_t st);
+#ifndef CONVF_PS_DEFAULT
+#define CONVF_PS_DEFAULT 19      // the 64-channel-tile layers (E2, E3 forward, E3 input gradient: -2.5 % each); the 32-channel-tile instantiations spill and lose
+#endif
+static bool use_f32_ps(int layer, bool dgrad) {
+    static const int mask = [] { const char* e = getenv("CVAE_CONVF_PS"); return e ? atoi(e) : CONVF_PS_DEFAULT; }();
+    return ((mask >> ((dgrad ? 3 : 0) + (layer >= 4 ? 2 : layer - 1))) & 1) != 0;
+}
+
 int launch_conv_fwd(int layer, int width, int B, const float* in, const float* w, const float* bias,
                     float* out, float* bnpart, float* ws, hipStream_t st) {
+    if (use_f32_ps(layer, false)) { const int rc = launch_conv_mfma_ps(layer, width, false, B, in, w, bias, out, bnpart, st); if (rc != -100) return rc; }
     ConvArgs a{in, w, bias, nullptr, out, bnpart, B, 0};
     if (width == 64) {
         switch (layer) {
@@ -489,6 +502,7 @@ int64_t conv_dgrad_ws_floats(int layer, int width, int B) {
 int launch_conv_dgrad(int layer, int width, int B, const float* dout, const float* w,
                       const float* mask_src, float* din, float* ws, hipStream_t st) {
     // KCH = layer Cout (channels of dout), NCH = layer Cin (channels of din)
+    if (!mask_src && use_f32_ps(layer, true)) { const int rc = launch_conv_mfma_ps(layer, width, true, B, dout, w, nullptr, din, nullptr, st); if (rc != -100) return rc; }
     ConvArgs a{dout, w, nullptr, mask_src, din, nullptr, B, 0};
     if (width == 64 && layer == 4 && ws != nullptr) {
         const int64_t slice = (int64_t)B * 16 * 256;

@@ -338,18 +338,26 @@ def test_two_pass_e1_forward_is_bit_identical(monkeypatch):
             assert torch.equal(a, b)
 
 
-def test_bf16_step_never_stores_y0_unless_a_block0_gamma_is_tiny():
+@pytest.mark.parametrize("B,vec_bound,tiny_bound", [(8, 0.35, 0.25), (512, 0.20, 0.10)])
+def test_bf16_step_never_stores_y0_unless_a_block0_gamma_is_tiny(B, vec_bound, tiny_bound):
     """Round 3: in bf16 mode the forward's second E1 pass writes only a0; E1's weight-gradient kernel recomputes the
     75-tap conv on its tiles.  (1) With ordinary gammas the y0 slot of the workspace is never touched (NaN-prefilled
     here) and the step is finite.  (2) With |gamma| < 1e-2 channels in block 0 (0, 1e-3, -5e-3) the forward keeps y0 —
     decided on the device — because the backward's statistics take xhat of such channels from it (a0 cannot be
-    inverted through a vanishing gamma): dgamma / dbeta / dW1 then still track the fp32 oracle."""
+    inverted through a vanishing gamma): dgamma / dbeta / dW1 then still track the fp32 oracle.
+
+    The bounds on the three tiny channels are read against max|dgamma| of the layer, not against the channel's own
+    value: profiles/r04_c_tiny_gamma_sweep.txt (bf16 mode against fp32 mode, same inputs, B = 8 ... 2048) shows their
+    error to be the bf16 noise every channel of the layer carries — at B = 8 0.11 / 0.08 of the scale beside 0.24 max /
+    0.07 median over the 29 ordinary channels, falling with the batch like theirs (B = 512: 0.03 / 0.06 beside 0.08 /
+    0.02; B = 2048: 0.005 / 0.02 beside 0.04 / 0.01).  A tiny-gamma channel's own dgamma can be a small fraction of the
+    scale (B = 8, gamma = 1e-3: -5.5e-5 of 3.9e-4), which is all the "87 % of its own value" of round 3's red run was."""
     from critic_vae_amd.nets import VariationalAutoencoder
     from critic_vae_amd.train import FusedTrainer
     from critic_vae_amd import layout as L
     from oracle import cvae_oracle as orc
     dev = torch.device("cuda:0")
-    B, W = 8, 64
+    W = 64
     x, pred, eps = synth.make_batch(1234, 0, B, W)
     xs, ps, es = (torch.from_numpy(v).to(dev) for v in (x, pred, eps))
     for tiny in (False, True):
@@ -375,11 +383,12 @@ def test_bf16_step_never_stores_y0_unless_a_block0_gamma_is_tiny():
         orc.train_step(p, torch.from_numpy(x), torch.from_numpy(pred), torch.from_numpy(eps), bn_state=orc.new_bn_state(p))
         got = L.native_to_ref(h.layout, tr.grads.cpu())
         for k in ("encoder.model.0.weight", "encoder.model.1.weight", "encoder.model.1.bias"):
-            assert _rel_l2(got[k], p[k].grad) < 0.35, (tiny, k, _rel_l2(got[k], p[k].grad))     # B = 8: bf16 noise (0.23 on dW1; 0.10 at B = 2048)
+            assert _rel_l2(got[k], p[k].grad) < vec_bound, (tiny, k, _rel_l2(got[k], p[k].grad))     # bf16 noise: dW1 0.23 / dgamma 0.25 / dbeta 0.18 at B = 8, 0.17 / 0.09 / 0.07 at B = 512
         if tiny:          # the tiny channels themselves: dgamma = sum(g * xhat[argmax]) must come out, not 0 / inf
             gk, rk = got["encoder.model.1.weight"][[3, 7, 20]], p["encoder.model.1.weight"].grad[[3, 7, 20]]
             scale = p["encoder.model.1.weight"].grad.abs().max()
-            assert torch.isfinite(gk).all() and (gk - rk).abs().max() < 0.5 * rk.abs().max() + 0.02 * scale, (gk, rk, scale)
+            assert torch.isfinite(gk).all() and (gk - rk).abs().max() < tiny_bound * scale, (gk, rk, scale)
+            assert gk[0] == 0 and rk[0] == 0          # gamma = 0, beta = 0: the channel's output is 0 everywhere and ReLU'(0) = 0 blocks its gradient
 
 
 @pytest.mark.parametrize("B", [8, 5])          # 5: ragged tile counts (the persistent D4 / MS-SSIM / E1 loops end unevenly)

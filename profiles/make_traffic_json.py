@@ -37,8 +37,9 @@ def patterns(prec, width):
                 p[f"conv_dgrad_L{l}"] = rf"conv4x4_row_kernel<{cout}, {cin}, true"
                 p[f"conv_wgrad_L{l}"] = rf"conv5x5_wgrad_kernel<{cin}, {cout}, {h},"
             elif l <= 4:
-                p[f"conv_fwd_L{l}"] = rf"conv5x5_mfma_kernel<{cin}, {cout}, {h}, false, false"
-                p[f"conv_dgrad_L{l}"] = rf"conv5x5_mfma_kernel<{cout}, {cin}, {h}, false, true"
+                # round 4: the 64-channel-tile layers run on the persistent kernel (conv_mfma_ps.hip, <KCH, NCH, H, DGRAD, NT, EPI>)
+                p[f"conv_fwd_L{l}"] = rf"conv5x5_mfma_kernel<{cin}, {cout}, {h}, false, false|conv5x5_mfma_ps_kernel<{cin}, {cout}, {h}, false"
+                p[f"conv_dgrad_L{l}"] = rf"conv5x5_mfma_kernel<{cout}, {cin}, {h}, false, true|conv5x5_mfma_ps_kernel<{cout}, {cin}, {h}, true"
                 p[f"conv_wgrad_L{l}"] = rf"conv5x5_wgrad_kernel<{cin}, {cout}, {h},"
             else:                                      # phase-collapsed up-convs run at the stored (low) resolution
                 p[f"conv_fwd_L{l}"] = rf"conv_up_fwd_kernel<{cin}, {cout}, {h // 2},"

@@ -155,6 +155,7 @@ static WsLayout carve(const cvae_handle_s* h, int B) {
     auto mx = [&](int64_t v) { if (v > sc) sc = v; };
     for (int l = 1; l <= 4; ++l) { if (wgrad_ws_floats(l, W, B) > scw) scw = wgrad_ws_floats(l, W, B);
         if (h->cfg.precision == 1 && conv_bf16_supported(l, W) && wgrad_bf16_ws_floats(l, W, B) > scw) scw = wgrad_bf16_ws_floats(l, W, B);
+        if (h->cfg.precision >= 2 && conv_bf16_supported(l, W) && wgrad_split_ws_floats(l, W, B) > scw) scw = wgrad_split_ws_floats(l, W, B);
         mx(conv_fwd_ws_floats(l, W, B)); mx(conv_dgrad_ws_floats(l, W, B)); }
     for (int l = 5; l <= 7; ++l) { if (conv_up_wgrad_ws_floats(l, W, B) > scw) scw = conv_up_wgrad_ws_floats(l, W, B); mx(conv_up_ws_floats(l, W, B)); }
     if (e1_wgrad_ws_floats(W, B) > scw) scw = e1_wgrad_ws_floats(W, B);
@@ -271,6 +272,14 @@ static bool use_bf16(cvae_handle h, int layer) {
 // precision 1: activations and activation gradients are bf16 IN HBM (every kernel that touches them is told so)
 static bool io_bf16(cvae_handle h) { return h->cfg.precision == 1; }
 static bool use_bf16_wgrad(cvae_handle h, int layer) { return h->cfg.precision == 1 && conv_bf16_supported(layer, h->cfg.width); }
+// fp32-emulation modes: weight gradients of E2..E4 / D0 on the bf16 MFMA with exact 3-way operand splits (conv_bf16.hip);
+// CVAE_SPLIT_WGRAD = bit mask of the layers (bit l-1 = layer l), for A/B runs against the fp32-MFMA kernels
+static bool use_split_wgrad(cvae_handle h, int layer) {
+    if (h->cfg.precision < 2 || layer < 1 || layer > 4 || !conv_bf16_supported(layer, h->cfg.width)) return false;
+    if (!conv_wgrad_split_supported(h->cfg.precision == 3 ? 6 : 9)) return false;          // precision 2: fp32-MFMA weight gradients (the nine-product form does not beat them)
+    static const int mask = [] { const char* e = getenv("CVAE_SPLIT_WGRAD"); return e ? atoi(e) : 15; }();
+    return ((mask >> (layer - 1)) & 1) != 0;
+}
 static int bf16_splits(cvae_handle h) { return h->cfg.precision >= 2 ? 3 : 1; }          // packed weight copies
 static int bf16_mode(cvae_handle h) { return h->cfg.precision == 2 ? 3 : (h->cfg.precision == 3 ? 6 : 1); }   // launcher code: 1 bf16, 3 x9, 6 x6
 static int pack_bf16_weights(cvae_handle h, const float* params, float* ws, const WsLayout& w, hipStream_t st) {
@@ -466,6 +475,7 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
         if (i == 0) {
             { ProbeArm pa(h, 2, l); RedArm ra(h, side_red, &red_pending, st); ra.arm(&sred);
               if (use_bf16_wgrad(h, 4)) RC(launch_conv_wgrad_bf16(4, W, B, in, ws + w.d_o[0], G_(h->dec_w[0]), G_(h->dec_b[0]), scw, sd));
+              else if (use_split_wgrad(h, 4)) RC(launch_conv_wgrad_split(4, W, bf16_mode(h) == 6 ? 6 : 9, B, in, ws + w.d_o[0], G_(h->dec_w[0]), G_(h->dec_b[0]), scw, sd));
               else RC(launch_conv_wgrad(l, W, B, in, ws + w.d_o[0], G_(h->dec_w[0]), G_(h->dec_b[0]), scw, sd)); }
             { ProbeArm pa(h, 1, l);
               if (use_bf16(h, 4)) RC(launch_conv_dgrad_bf16(4, W, bf16_mode(h), B, ws + w.d_o[0], ws + w.wpack, ws + w.d_h, ws + w.scratch, st));
@@ -503,6 +513,7 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
         } else {
             { ProbeArm pa(h, 2, l); RedArm ra(h, side_red, &red_pending, st); ra.arm(&sred);
               if (use_bf16_wgrad(h, l)) RC(launch_conv_wgrad_bf16(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd));
+              else if (use_split_wgrad(h, l)) RC(launch_conv_wgrad_split(l, W, bf16_mode(h) == 6 ? 6 : 9, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd));
               else RC(launch_conv_wgrad(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd)); }
             { ProbeArm pa(h, 1, l);
               if (use_bf16(h, l)) RC(launch_conv_dgrad_bf16(l, W, bf16_mode(h), B, ws + w.d_y[l], ws + w.wpack, ws + w.d_a[l - 1], ws + w.scratch, st));

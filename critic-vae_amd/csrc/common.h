@@ -191,6 +191,10 @@ int launch_conv_up_fwd_bf16(int layer, int width, int ns, int B, const float* in
 int launch_conv_up_dgrad_bf16(int layer, int width, int ns, int B, const float* dout, const float* packed, const float* aux, float* din, hipStream_t st);
 int64_t wgrad_bf16_ws_floats(int layer, int width, int B);
 int launch_conv_wgrad_bf16(int layer, int width, int B, const float* in, const float* dout, float* dw, float* dbias, float* ws, hipStream_t st);
+bool conv_wgrad_split_supported(int products);
+int64_t wgrad_split_ws_floats(int layer, int width, int B);        // fp32-emulation modes: exact 3-way operand splits on the bf16 MFMA
+int launch_conv_wgrad_split(int layer, int width, int products, int B, const float* in, const float* dout, float* dw, float* dbias,
+                            float* ws, hipStream_t st);
 int launch_splitk_bias_relu(const float* slab, const float* bias, float* out, int64_t slice, int KS, int C, hipStream_t st, bool out_bf16 = false);
 // conv_wgrad.hip
 int64_t wgrad_ws_floats(int layer, int width, int B);

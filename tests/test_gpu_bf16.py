@@ -271,6 +271,32 @@ def test_bf16x9_emulation_meets_the_fp32_parity_bar(B, mode):
     assert (mu - res["f32"][0]).abs().max() < 2e-5 and (recon - res["f32"][1]).abs().max() < 2e-5
 
 
+def test_bf16x6_step_at_128x128_frames_meets_the_fp32_parity_bar():
+    """Round 4: in the fp32-emulation mode "bf16x6" the weight gradients of E2..E4 / D0 run on the bf16 MFMA too
+    (conv_wgrad_split.hip: both fp32 operands split exactly into three bf16 parts while staged, the six leading partial
+    products per 16-pixel block).  The 64x64 instantiations are covered by the B = 4 / 32 / 256 parity tests; this is the
+    128x128 set (64 / 32 / 16 / 8-pixel layers, other tile geometries) at a ragged batch: same bar as the fp32 mode —
+    1e-4 absolute on outputs and loss, every gradient element within 1e-4 of its tensor's max with the decisions imposed."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from decisions import check_step_against_oracle
+    from critic_vae_amd.nets import VariationalAutoencoder
+    dev = torch.device("cuda:0")
+    W, B, DSEED = 128, 3, 7          # (data seed 1234 has one block-3 pool window 1.007e-5 from a tie: decisions.TIE_TOL = 1e-5 rejects it; 7 and 11 have none)
+    x, pred, eps = (torch.from_numpy(v) for v in synth.make_batch(DSEED, 0, B, W))
+    vae = VariationalAutoencoder(width=W, max_batch=B, seed=0, precision="bf16x6").to(dev)
+    vae.load_reference_params(synth.make_params(0, W))
+    out = vae(x.to(dev), pred.to(dev), eps=eps.to(dev))
+    losses = vae.vae_loss(*out)
+    losses["total_loss"].backward()
+    torch.cuda.synchronize()
+    rep, o = check_step_against_oracle(vae, x, pred, eps, B)
+    assert rep is not None and rep["rel_forced"] <= 1e-4, rep
+    assert (out[1].detach().cpu() - o["mu"].detach()).abs().max() < 1e-4
+    assert (out[3].detach().cpu() - o["recon"].detach()).abs().max() < 1e-4
+    assert abs(float(losses["total_loss"].item()) - float(o["total_loss"].detach())) < 1e-4
+
+
 def test_bn_pool_ops_follow_the_handle_storage_type():
     """The stand-alone BatchNorm/pool ops of a bf16-storage handle read and write bf16 tensors (as the step does):
     eval-mode forward (coefficients from the running statistics) and the backward apply pass against a torch

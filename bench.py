@@ -327,9 +327,8 @@ def time_workload(cx, spec, steps, warmup, probing, allreduce_dtype=None, overla
                 sec = sum(ms) / len(ms) * 1e-3
                 fl = conv_flops(dominant % 9, B, Wd)
                 # fp32 emulation: forward / dgrad of E2..E4, D0 run 9 (or 6) bf16 MFMAs per fp32 product block -> peak / 9 (/ 6);
-                # so do their weight gradients in bf16x6 mode (round 4, conv_wgrad_split.hip; bf16x9 keeps them on the fp32 MFMA,
-                # where every other kernel stays too)
-                emu = prec in ("bf16x9", "bf16x6") and 1 <= dominant % 9 <= 4 and (dominant // 9 < 2 or (dominant // 9 == 2 and prec == "bf16x6"))
+                # so do their weight gradients (round 4, conv_wgrad_split.hip); every other kernel stays on the fp32 MFMA
+                emu = prec in ("bf16x9", "bf16x6") and 1 <= dominant % 9 <= 4
                 peak = PEAK_BF16_MFMA_TFLOPS if prec == "bf16" else (PEAK_BF16_MFMA_TFLOPS / (9 if prec == "bf16x9" else 6) if emu
                                                                     else PEAK_FP32_MFMA_TFLOPS)
                 r["roofline"] = {

@@ -276,7 +276,7 @@ static bool use_bf16_wgrad(cvae_handle h, int layer) { return h->cfg.precision =
 // CVAE_SPLIT_WGRAD = bit mask of the layers (bit l-1 = layer l), for A/B runs against the fp32-MFMA kernels
 static bool use_split_wgrad(cvae_handle h, int layer) {
     if (h->cfg.precision < 2 || layer < 1 || layer > 4 || !conv_bf16_supported(layer, h->cfg.width)) return false;
-    if (!conv_wgrad_split_supported(h->cfg.precision == 3 ? 6 : 9)) return false;          // precision 2: fp32-MFMA weight gradients (the nine-product form does not beat them)
+    if (!conv_wgrad_split_supported(h->cfg.precision == 3 ? 6 : 9)) return false;
     static const int mask = [] { const char* e = getenv("CVAE_SPLIT_WGRAD"); return e ? atoi(e) : 15; }();
     return ((mask >> (layer - 1)) & 1) != 0;
 }

@@ -4,16 +4,19 @@
 #include "conv_bf16.h"
 
 // ---------------------------------------------------------------------------------------------
-// Weight gradients of E2..E4 / D0 in the fp32-EMULATION modes (precision 2 / 3; round 4): the transposed-read kernel above with
-// both fp32 operands split exactly into three bf16 parts while they are staged (x = hi + mid + lo, split3), three LDS images per
+// Weight gradients of E2..E4 / D0 in the fp32-EMULATION modes (precision 2 / 3; round 4): the transposed-read kernel of conv_bf16.hip
+// (conv5x5_wgrad_tr_kernel) with both fp32 operands split exactly into three bf16 parts while they are staged (x = hi + mid + lo, split3), three LDS images per
 // operand, and 9 (DMAX = 4) or the 6 leading (DMAX = 2) bf16 x bf16 partial products per 16-pixel block, smallest first, into one
-// fp32 accumulator — exactly what conv5x5_bf16_kernel<NS = 3> does for the forward / input-gradient passes, so the whole step of
-// these modes now runs on the bf16 MFMA.  Every partial product is exact in the accumulator; what differs from the fp32-MFMA
+// fp32 accumulator — exactly what conv5x5_bf16_kernel<NS = 3> does for the forward / input-gradient passes, so all
+// three passes of these layers run on the bf16 MFMA in those modes (E1, D1..D3 and D4 keep their fp32 kernels).  Every partial product is exact in the accumulator; what differs from the fp32-MFMA
 // weight-gradient kernel (conv_wgrad.hip) is the order of the additions.  The bias gradient is ones x (hi + mid + lo).
 // 128-pixel tiles (64 on 4x4 images): 3 x (halo + tile) x 64 B = 62-80 KB of LDS, two workgroups per CU; four waves, wave w owns taps
 // w, w+4, .., w+20 and every 4th pixel group of tap 24 and of the bias row (8 accumulator tiles).  One staged fragment triple serves
 // 6 / 9 MFMAs: 0.6 / 0.4 KB of LDS reads per MFMA where the plain bf16 kernel needs 2 KB — this kernel is MFMA-bound.
 // ---------------------------------------------------------------------------------------------
+#ifndef SPLIT_PIPE
+#define SPLIT_PIPE 0      // 1 (experiment): the next tap's fragment triple is requested before this tap's MFMAs — 12 more live registers, 20-76 B of
+#endif                    // spills at the 256-register budget, 131 / 127.5 / 127 -> 140 / 130 / 131 us (E2 / E3 / E4, six products, B = 256)
 template <int H> using SplitTile = WtTile<H, 2, (H == 4 ? 64 : 128)>;
 
 // W = wave index as a RUNTIME (wave-uniform) value: the six tap offsets of the wave sit in registers, everything else of an LDS
@@ -28,10 +31,11 @@ __device__ __forceinline__ void wgrad_split_body(f32x16 (&acc)[8], const __bf16*
 #pragma unroll
     for (int j = 0; j < JT; ++j) { const int tap = 4 * j + W; tapp[j] = lds_in + ibase + ((tap / 5) * T::HTW + tap % 5) * 32; }
     const __bf16* tap24 = lds_in + ibase + (4 * T::HTW + 4) * 32;
-    auto tap_mfmas = [&](f32x16& c, const __bf16* q0, const bf16x8 (&bv)[3]) {
-        bf16x8 av[3];
+    auto load_a = [&](bf16x8 (&av)[3], const __bf16* q0) {
 #pragma unroll
         for (int sp = 0; sp < 3; ++sp) av[sp] = tr_frag(q0 + sp * IN_IMG, q0 + sp * IN_IMG + T::IT * 32);
+    };
+    auto mfmas = [&](f32x16& c, const bf16x8 (&av)[3], const bf16x8 (&bv)[3]) {
 #pragma unroll
         for (int d = DMAX; d >= 0; --d)               // 0 = hi, 1 = mid, 2 = lo; d = ia + ib: smallest products first
 #pragma unroll
@@ -42,15 +46,33 @@ __device__ __forceinline__ void wgrad_split_body(f32x16 (&acc)[8], const __bf16*
     };
 #pragma unroll
     for (int kg = 0; kg < T::KG; ++kg) {
-        bf16x8 bv[3];
+        bf16x8 bv[3], av[2][3];
 #pragma unroll
         for (int sp = 0; sp < 3; ++sp) {
             const __bf16* dp = lds_d + sp * D_IMG + dbase + T::pixbase(kg) * 32;
             bv[sp] = tr_frag(dp, dp + T::DT * 32);
         }
+        load_a(av[0], tapp[0] + T::halobase(kg) * 32);
+        // the compiler's own order is read -> wait -> 6 / 9 MFMAs per tap; the co-resident workgroup's wave covers the LDS latency
 #pragma unroll
-        for (int j = 0; j < JT; ++j) tap_mfmas(acc[j], tapp[j] + T::halobase(kg) * 32, bv);
-        if ((kg % 4) == W) tap_mfmas(acc[JT], tap24 + T::halobase(kg) * 32, bv);
+        for (int j = 0; j < JT; ++j) {
+#if SPLIT_PIPE
+            if (j + 1 < JT) load_a(av[(j + 1) & 1], tapp[j + 1] + T::halobase(kg) * 32);
+            else if ((kg % 4) == W) load_a(av[(j + 1) & 1], tap24 + T::halobase(kg) * 32);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(acc[j], av[j & 1], bv);
+            __builtin_amdgcn_sched_barrier(0);
+#else
+            if (j > 0) load_a(av[j & 1], tapp[j] + T::halobase(kg) * 32);
+            mfmas(acc[j], av[j & 1], bv);
+#endif
+        }
+        if ((kg % 4) == W) {
+#if !SPLIT_PIPE
+            load_a(av[JT & 1], tap24 + T::halobase(kg) * 32);
+#endif
+            mfmas(acc[JT], av[JT & 1], bv);
+        }
         if ((kg % 4) == ((W + 1) & 3)) {
 #pragma unroll
             for (int sp = 2; sp >= 0; --sp) acc[JT + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bv[sp], acc[JT + 1], 0, 0, 0);
@@ -193,12 +215,7 @@ static int run_wgrad_split(int products, int B, const float* in, const float* do
     constexpr int STAGE = 3 * (T::HP + T::NPX) * 64, RED = (3 * 16 * 64 + 4 * 32) * 4;
     constexpr int SMEM = STAGE > RED ? STAGE : RED;
     static_assert(2 * SMEM <= 160 * 1024, "two workgroups per CU");
-#ifdef SPLIT_WGRAD_X9          // the nine-product form is built for A/B runs only: it does not beat the fp32-MFMA kernels
     void (*kern)(WgradBf16Args) = products == 6 ? conv5x5_wgrad_split_kernel<CIN, COUT, H, 2> : conv5x5_wgrad_split_kernel<CIN, COUT, H, 4>;
-#else
-    if (products != 6) { cvae_set_error("conv_wgrad_split: nine-product kernels are not built (-DSPLIT_WGRAD_X9)"); return -2; }
-    void (*kern)(WgradBf16Args) = conv5x5_wgrad_split_kernel<CIN, COUT, H, 2>;
-#endif
     static DeviceOnce once[2];
     { int rc = cvae_grant_lds(once[products == 6], reinterpret_cast<const void*>(kern), SMEM); if (rc) return rc; }
     cvae_probe_begin(st);
@@ -233,14 +250,7 @@ static int dispatch_wgrad_split(int layer, int width, int products, int B, const
     cvae_set_error("conv_wgrad_split: unsupported layer %d at width %d", layer, width);
     return -2;
 }
-// which product counts this build serves (9 only with -DSPLIT_WGRAD_X9)
-bool conv_wgrad_split_supported(int products) {
-#ifdef SPLIT_WGRAD_X9
-    return products == 6 || products == 9;
-#else
-    return products == 6;
-#endif
-}
+bool conv_wgrad_split_supported(int products) { return products == 6 || products == 9; }
 int64_t wgrad_split_ws_floats(int layer, int width, int B) {
     int64_t need = 0;
     if (dispatch_wgrad_split(layer, width, 6, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &need) != 0) return 0;

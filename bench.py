@@ -198,7 +198,7 @@ def cpu_baseline(B, steps=None, width=64):
     from critic_vae_amd import synth
     from oracle import cvae_oracle as orc
     if steps is None:                                   # about 10-30 s of CPU work whatever the batch
-        steps = max(1, min(5, 1280 * 64 * 64 // (B * width * width)))
+        steps = max(1, min(10, 2560 * 64 * 64 // (B * width * width)))        # B = 256: 10 steps = 2560 images, ~12 s on 16 cores
     threads = min(len(os.sched_getaffinity(0)), 16)     # the 1-GPU box's CPU share is 16 cores
     torch.set_num_threads(threads)
     p = orc.to_torch(synth.make_params(0, width), requires_grad=True)

@@ -73,7 +73,7 @@ extern "C" int cvae_conv_dbg_read(long long* out) { return (int)hipMemcpyFromSym
 #endif
 
 #ifndef BF16_WAVES_ATTR
-#define BF16_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#define BF16_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(MT > 2 ? 1 : 2, MT > 2 ? 1 : 2)))      // MT = 4 (big-tile experiment): one wave per SIMD, 512 registers
 #endif
 #ifndef BF16_WAVES_PER_SIMD
 #define BF16_WAVES_PER_SIMD 1      // experiment: 3 = cap the kernel at 168 VGPRs so that three workgroups fit a CU where the LDS allows it
@@ -849,6 +849,14 @@ static bool use_ps_kernel(int layer, bool dgrad) {
 int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, const float* packed, const float* bias, float* out,
                          float* bnpart, float* ws, hipStream_t st) {
     ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0, ns >= 3 ? 3 : 1), bias, out, bnpart, B, 0, nullptr, ns >= 3 ? pack_units(layer) : 0, ns == 6 ? 6 : 9};
+    // CVAE_BF16_BIG (experiment, round 4; default off): 4 tiles x 128 channels per workgroup = 16 accumulator tiles per wave (0.5 fragment
+    // reads per MFMA instead of 1.0), one workgroup per CU, one wave per SIMD.  bit 0 = E3 forward, bit 1 = E4 forward.  Correct; the MFMA
+    // loop then runs at 0.94 of the matrix pipe (54.3 k cycles for 51.2 k of MFMAs, E3 forward: the fragment-bandwidth bound is gone), but
+    // with nothing else resident the staging (17 k) and the 16-tile epilogue (21-30 k) are fully exposed: 224 us against 197 / 191 us
+    // on the persistent two-workgroup kernel (profiles/r04_e_big_tile.txt).
+    static const int big = [] { const char* e = getenv("CVAE_BF16_BIG"); return e ? atoi(e) : 0; }();
+    if (ns == 1 && width == 64 && layer == 2 && (big & 1)) return run_bf16_ns<64, 128, 16, 128, EPI_BIAS_BNSTAT, 1, 5, MODE_STD, 1, 4, 4>(a, st);
+    if (ns == 1 && width == 64 && layer == 3 && (big & 2)) return run_bf16_ns<128, 256, 8, 128, EPI_BIAS_BNSTAT, 1, 5, MODE_STD, 1, 4, 4>(a, st);
     if (ns == 1 && use_ps_kernel(layer, false)) { const int rc = launch_conv_bf16_ps(layer, width, false, a, st); if (rc != -100) return rc; }
     if (width == 64) {
         switch (layer) {

@@ -22,6 +22,7 @@
 // HBM traffic: forward reads x, y once and writes F (+ 1/4-size pyramids); backward reads the F pyramid and
 // writes dx — 1.2x the algorithmic bytes (was 3.2x / 2.5x with the derivative maps stored).
 #include "common.h"
+#include <stdlib.h>
 #include <math.h>
 
 // The 11 normalised taps travel BY VALUE in every kernel's argument struct (scalar registers): no
@@ -704,6 +705,287 @@ __global__ __launch_bounds__(MsP<S>::NT) void msssim_plane_kernel(MsFwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// the 128-wide level (level 0 of BASELINE config 5's frames): one workgroup per plane, the plane STREAMED through LDS in bands
+// ------------------------------------------------------------------------------------------------
+// A whole 128 x 128 plane needs 4x the LDS of the 64-wide plane kernel, and strips with a halo pay for the halo in every one of the four
+// filter passes (a 16 x 128 strip filters 36 / 26 / 26 / 16 rows: 6.5 units of work per output row against the 16 x 64 tile kernel's 7.2
+// and the plane kernel's 4.0).  Streaming pays 4.5: the workgroup walks down its plane in bands of R = 16 rows and keeps, in LDS, the
+// last R + 10 rows of every ROW-FILTERED field — {hx, hy, hxx, hyy, hxy} of the input (t1) and {g0, g1, g2} of the derivative maps (t2).
+// Per band (image rows b0 .. b0 + R - 1 arrive; b0 = 0, R, .., S, the last band carries zero rows to flush the two 5-row lags):
+//   stage the band's (x, y) rows                                    -> lin rows 0..R-1
+//   h1: row-filter them                                            -> t1 rows 10..R+9        (t1 row j = image row b0 - 10 + j)
+//   v1: column-filter t1 rows i..i+10, SSIM / CS point function    -> maps of image rows b0 - 5 + i; derivative maps over lin
+//   h2: row-filter the derivative maps                              -> t2 rows 10..R+9        (t2 row j = map row b0 - 15 + j)
+//   v2: column-filter t2 rows i..i+10, F = f0 + 2 x f1 + y f2       -> F rows b0 - 10 + i      (x, y of those rows: fetched again, L2)
+//   the last 10 rows of t1 / t2 move to the top (rows outside the image are zero: conv2d's padding, never computed as maps).
+// Every pass has exactly R * S / 4 = 512 items = threads, with the plane kernel's item shapes and fma chains (values are the tile
+// kernel's: same t = 0..10 order over the same products; only the order of a plane's partial sums differs).  9 bands x 4 passes of 16
+// rows = 4.5 units; 135 KB of LDS, one workgroup (8 waves) per CU, persistent over planes, the next band's pixels in flight in
+// registers during the passes.
+template <int S, int R>
+struct MsS {
+    static constexpr int NT = R * S / 4;                 // threads = items of every pass
+    static constexpr int NBAND = S / R + 1;
+    static constexpr int DAS = S + 14, DCS = S + 12, TAS = S + 2, TR = R + 10;       // strides as in MsP; TR = rows of the t images
+    static constexpr int LIN = R * (2 * DAS + DCS);      // (x, y) [R][DAS][2], later (d_mu, d_11) | d_12 [R][DCS]
+    static constexpr int TA = 2 * TR * TAS;              // one pair image
+    static constexpr int T1 = 2 * TA + TR * S;           // (hx, hy) | (hxx, hyy) | hxy
+    static constexpr int T2 = TA + TR * S;               // (g0, g1) | g2
+    static constexpr int SMEM = (LIN + T1 + T2) * 4;
+    static constexpr int HA4 = 10 * TAS * 2 / 4, HC4 = 10 * S / 4;                  // 16-byte units of 10 history rows (pair image / single plane)
+    static_assert((DAS / 2) % 2 == 1 && DCS % 4 == 0 && TAS % 2 == 0 && LIN % 4 == 0 && TA % 4 == 0 && (TR * S) % 4 == 0, "strides");
+    static_assert(R >= 10 && R % 2 == 0 && S % R == 0 && NT % 64 == 0 && NT <= 1024 && (R * TAS * 2) % 4 == 0, "band geometry");
+    static_assert(SMEM <= 160 * 1024 - 256, "LDS");
+};
+
+template <int S, int R>
+__global__ __launch_bounds__((MsS<S, R>::NT)) void msssim_stream_kernel(MsFwdArgs a) {
+    using T = MsS<S, R>;
+    constexpr int NT = T::NT, J = S / 4, H = S / 2, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float red[2 * NW];
+    const int tid = threadIdx.x;
+    float* lin = smem;
+    float* t1A = lin + T::LIN; float* t1B = t1A + T::TA; float* t1C = t1B + T::TA;
+    float* t2A = t1C + T::TR * S; float* t2C = t2A + T::TA;
+    float* dA = lin; float* dC = lin + 2 * R * T::DAS;
+    if (blockIdx.x == 0 && tid == 0 && a.ticket) *a.ticket = 0u;
+    float w[11];
+#pragma unroll
+    for (int t = 0; t < 11; ++t) w[t] = a.win.w[t];
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    // the zero columns either side of the input / derivative rows: written once, no pass ever stores there (as in the plane kernel)
+    for (int q = tid; q < R * 16; q += NT) {
+        const int zr = q >> 4, k = q & 15;
+        float* ra = dA + zr * T::DAS * 2; float* rc = dC + zr * T::DCS;
+        if (k < 3) *reinterpret_cast<f32x4*>(ra + 4 * k) = z4;
+        else if (k < 7) *reinterpret_cast<f32x4*>(ra + (S + 6) * 2 + 4 * (k - 3)) = z4;
+        else if (k == 7) *reinterpret_cast<f32x4*>(rc) = z4;
+        else if (k == 8) *reinterpret_cast<f32x2*>(rc + 4) = splat2(0.f);
+        else if (k == 9) *reinterpret_cast<f32x2*>(rc + S + 6) = splat2(0.f);
+        else if (k == 10) *reinterpret_cast<f32x4*>(rc + S + 8) = z4;
+    }
+    // item shapes of the plane kernel: horizontal = 4 adjacent outputs of one row (neighbouring lanes: the two rows of a pair), vertical = 2 x 2
+    const int hr = 2 * (tid / (2 * J)) + (tid & 1), hc = ((tid % (2 * J)) >> 1) * 4;
+    const int vr = (tid / H) * 2, vc = (tid % H) * 2;
+    const int sr = tid / H, sc = (tid % H) * 2;              // staging: pixels (sr, sc), (sr, sc + 1) and the same of row sr + R / 2
+    float2 vx[2], vy[2];                                     // the band to be staged next
+    auto fetch_band = [&](int plane, int b0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool in = b0 + sr + k * (R / 2) < S;       // rows past the image: the flush band
+            const size_t e = (size_t)plane * S * S + (in ? (size_t)b0 * S + 2 * (tid + k * NT) : 0);
+            const float2 lx = *reinterpret_cast<const float2*>(a.x + e), ly = *reinterpret_cast<const float2*>(a.y + e);
+            vx[k] = in ? lx : make_float2(0.f, 0.f);
+            vy[k] = in ? ly : make_float2(0.f, 0.f);
+        }
+    };
+    if ((int)blockIdx.x < a.P) fetch_band(blockIdx.x, 0);
+    for (int plane = blockIdx.x; plane < a.P; plane += gridDim.x) {
+        float s_ssim = 0.f, s_cs = 0.f;
+        for (int kb = 0; kb < T::NBAND; ++kb) {
+            const int b0 = kb * R;
+            // ---- history rows of the row-filtered images: zero at the top of a plane, else the last 10 rows of the previous band ----
+            for (int q = tid; q < T::HA4; q += NT) {
+                f32x4* A1 = reinterpret_cast<f32x4*>(t1A); f32x4* B1 = reinterpret_cast<f32x4*>(t1B); f32x4* A2 = reinterpret_cast<f32x4*>(t2A);
+                constexpr int SRC = R * T::TAS * 2 / 4;
+                A1[q] = kb ? A1[q + SRC] : z4; B1[q] = kb ? B1[q + SRC] : z4; A2[q] = kb ? A2[q + SRC] : z4;
+            }
+            for (int q = tid; q < T::HC4; q += NT) {
+                f32x4* C1 = reinterpret_cast<f32x4*>(t1C); f32x4* C2 = reinterpret_cast<f32x4*>(t2C);
+                constexpr int SRC = R * S / 4;
+                C1[q] = kb ? C1[q + SRC] : z4; C2[q] = kb ? C2[q + SRC] : z4;
+            }
+            // ---- stage the band, (x, y) interleaved per pixel; the next band (or the next plane's first) goes in flight ----
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                *reinterpret_cast<f32x4*>(lin + ((sr + k * (R / 2)) * T::DAS + 6 + sc) * 2) = f32x4{vx[k].x, vy[k].x, vx[k].y, vy[k].y};
+            if (kb + 1 < T::NBAND) fetch_band(plane, b0 + R);
+            else if (plane + (int)gridDim.x < a.P) fetch_band(plane + gridDim.x, 0);
+            // x, y of the F rows this band completes (rows b0 - 10 + vr, + 1): both inside the image or both outside
+            const int f0 = b0 - 10 + vr;
+            const bool fvalid = (unsigned)f0 < (unsigned)S;
+            float2 fx[2], fy[2];
+            if (a.F) {
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    const size_t e = (size_t)plane * S * S + (fvalid ? (size_t)(f0 + o) * S + vc : 0);
+                    fx[o] = *reinterpret_cast<const float2*>(a.x + e); fy[o] = *reinterpret_cast<const float2*>(a.y + e);
+                }
+            }
+            __syncthreads();
+            // ---- 2x2 average for the next level: one output per thread (R / 2 rows of S / 2) ----
+            if (a.nx && b0 < S) {
+                const int pr = tid / H, pc = tid % H;
+                const float* p = lin + ((2 * pr) * T::DAS + 6 + 2 * pc) * 2;
+                const f32x4 u = *reinterpret_cast<const f32x4*>(p), d = *reinterpret_cast<const f32x4*>(p + 2 * T::DAS);
+                const f32x2 o = ((f32x2{u[0], u[1]} + f32x2{u[2], u[3]}) + (f32x2{d[0], d[1]} + f32x2{d[2], d[3]})) * splat2(0.25f);
+                const size_t e = (size_t)plane * H * H + (size_t)(b0 / 2 + pr) * H + pc;
+                a.nx[e] = o.x; a.ny[e] = o.y;
+            }
+            // ---- horizontal pass of {x, y, x^2, y^2, xy} (the flush band's rows are zero: so are their filtered values) ----
+            if (b0 >= S) {
+                const int d = ((hr + 10) * T::TAS + hc) * 2;
+                *reinterpret_cast<f32x4*>(t1A + d) = z4; *reinterpret_cast<f32x4*>(t1A + d + 4) = z4;
+                *reinterpret_cast<f32x4*>(t1B + d) = z4; *reinterpret_cast<f32x4*>(t1B + d + 4) = z4;
+                *reinterpret_cast<f32x4*>(t1C + (hr + 10) * S + hc) = z4;
+            } else {
+                const float* p = lin + (hr * T::DAS + hc) * 2;
+                f32x2 xy[16];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(p + 4 * i);
+                    xy[2 * i] = f32x2{u[0], u[1]}; xy[2 * i + 1] = f32x2{u[2], u[3]};
+                }
+                f32x2 hA[4], hB[4];
+                float hC[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    f32x2 sA = splat2(0.f), sB = splat2(0.f);
+                    float sC = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 11; ++t) {
+                        const f32x2 v = xy[o + t + 1];
+                        sA = pk_fma(splat2(w[t]), v, sA);
+                        sB = pk_fma(splat2(w[t]), v * v, sB);
+                        sC = fmaf(w[t], v.x * v.y, sC);
+                    }
+                    hA[o] = sA; hB[o] = sB; hC[o] = sC;
+                }
+                const int d = ((hr + 10) * T::TAS + hc) * 2;
+                *reinterpret_cast<f32x4*>(t1A + d) = f32x4{hA[0].x, hA[0].y, hA[1].x, hA[1].y};
+                *reinterpret_cast<f32x4*>(t1A + d + 4) = f32x4{hA[2].x, hA[2].y, hA[3].x, hA[3].y};
+                *reinterpret_cast<f32x4*>(t1B + d) = f32x4{hB[0].x, hB[0].y, hB[1].x, hB[1].y};
+                *reinterpret_cast<f32x4*>(t1B + d + 4) = f32x4{hB[2].x, hB[2].y, hB[3].x, hB[3].y};
+                *reinterpret_cast<f32x4*>(t1C + (hr + 10) * S + hc) = f32x4{hC[0], hC[1], hC[2], hC[3]};
+            }
+            __syncthreads();
+            // ---- vertical pass + SSIM / CS maps of image rows b0 - 5 + vr (+ 1); derivative maps over the input rows ----
+            if ((unsigned)(b0 - 5 + vr) >= (unsigned)S && (unsigned)(b0 - 4 + vr) >= (unsigned)S) {      // wave-uniform: vr = 2 x wave
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    *reinterpret_cast<f32x4*>(dA + ((vr + o) * T::DAS + 6 + vc) * 2) = z4;
+                    *reinterpret_cast<f32x2*>(dC + (vr + o) * T::DCS + 6 + vc) = splat2(0.f);
+                }
+            } else {
+                constexpr int VR = 2;
+                f32x2 mu[VR][2], aa[VR][2], a12[VR];
+#pragma unroll
+                for (int o = 0; o < VR; ++o) { mu[o][0] = mu[o][1] = aa[o][0] = aa[o][1] = a12[o] = splat2(0.f); }
+                const float* pA = t1A + (vr * T::TAS + vc) * 2;
+                const float* pC = t1C + vr * S + vc;
+#pragma unroll
+                for (int i = 0; i < VR + 10; ++i) {               // t1 row vr + i = image row b0 - 10 + vr + i
+                    const f32x4 vA = *reinterpret_cast<const f32x4*>(pA + i * (T::TAS * 2));
+                    const f32x4 vB = *reinterpret_cast<const f32x4*>(pA + T::TA + i * (T::TAS * 2));
+                    const f32x2 vC = *reinterpret_cast<const f32x2*>(pC + i * S);
+#pragma unroll
+                    for (int o = 0; o < VR; ++o) {
+                        if (i - o < 0 || i - o > 10) continue;
+                        const f32x2 wt = splat2(w[i - o]);
+                        mu[o][0] = pk_fma(wt, f32x2{vA[0], vA[1]}, mu[o][0]);
+                        mu[o][1] = pk_fma(wt, f32x2{vA[2], vA[3]}, mu[o][1]);
+                        aa[o][0] = pk_fma(wt, f32x2{vB[0], vB[1]}, aa[o][0]);
+                        aa[o][1] = pk_fma(wt, f32x2{vB[2], vB[3]}, aa[o][1]);
+                        a12[o] = pk_fma(wt, vC, a12[o]);
+                    }
+                    if (i < 10) continue;
+                    const int o = i - 10, r = vr + o;
+                    const bool mvalid = (unsigned)(b0 - 5 + r) < (unsigned)S;      // map rows outside the image: zero (conv2d's padding of the derivative maps)
+                    f32x2 ss, cs, dmv, d11v, d12v;
+                    ms_point2<false>(f32x2{mu[o][0].x, mu[o][1].x}, f32x2{mu[o][0].y, mu[o][1].y}, f32x2{aa[o][0].x, aa[o][1].x},
+                                     f32x2{aa[o][0].y, aa[o][1].y}, a12[o], &ss, &cs, &dmv, &d11v, &d12v);
+                    if (mvalid) { s_ssim += ss.x + ss.y; s_cs += cs.x + cs.y; }
+                    else { dmv = d11v = d12v = splat2(0.f); }
+                    *reinterpret_cast<f32x4*>(dA + (r * T::DAS + 6 + vc) * 2) = f32x4{dmv.x, d11v.x, dmv.y, d11v.y};
+                    *reinterpret_cast<f32x2*>(dC + r * T::DCS + 6 + vc) = d12v;
+                }
+            }
+            __syncthreads();
+            if (a.F) {
+                // ---- the same separable filter over the three derivative maps: horizontal (zero map rows filter to zero) ... ----
+                const int hw = hr & ~1;           // the wave's two rows
+                if ((unsigned)(b0 - 5 + hw) >= (unsigned)S && (unsigned)(b0 - 4 + hw) >= (unsigned)S) {
+                    const int d = ((hr + 10) * T::TAS + hc) * 2;
+                    *reinterpret_cast<f32x4*>(t2A + d) = z4; *reinterpret_cast<f32x4*>(t2A + d + 4) = z4;
+                    *reinterpret_cast<f32x4*>(t2C + (hr + 10) * S + hc) = z4;
+                } else {
+                    f32x2 va[16];
+                    float vc4[16];
+                    const float* pa = dA + (hr * T::DAS + hc) * 2;
+                    const float* pc = dC + hr * T::DCS + hc;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(pa + 4 * i);
+                        va[2 * i] = f32x2{u[0], u[1]}; va[2 * i + 1] = f32x2{u[2], u[3]};
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(pc + 4 * i);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vc4[4 * i + e] = u[e];
+                    }
+                    f32x2 gAo[4];
+                    f32x4 gCo;
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        f32x2 sA = splat2(0.f);
+                        float sC = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 11; ++t) { sA = pk_fma(splat2(w[t]), va[o + t + 1], sA); sC = fmaf(w[t], vc4[o + t + 1], sC); }
+                        gAo[o] = sA; gCo[o] = sC;
+                    }
+                    const int d = ((hr + 10) * T::TAS + hc) * 2;
+                    *reinterpret_cast<f32x4*>(t2A + d) = f32x4{gAo[0].x, gAo[0].y, gAo[1].x, gAo[1].y};
+                    *reinterpret_cast<f32x4*>(t2A + d + 4) = f32x4{gAo[2].x, gAo[2].y, gAo[3].x, gAo[3].y};
+                    *reinterpret_cast<f32x4*>(t2C + (hr + 10) * S + hc) = gCo;
+                }
+                __syncthreads();
+                // ---- ... vertical, then F = f0 + 2 x f1 + y f2 for image rows b0 - 10 + vr (+ 1) ----
+                if (fvalid) {
+                    constexpr int VR = 2;
+                    f32x2 f01[VR][2], f2[VR];
+#pragma unroll
+                    for (int o = 0; o < VR; ++o) { f01[o][0] = f01[o][1] = f2[o] = splat2(0.f); }
+                    const float* pA = t2A + (vr * T::TAS + vc) * 2;
+                    const float* pC = t2C + vr * S + vc;
+#pragma unroll
+                    for (int i = 0; i < VR + 10; ++i) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(pA + i * (T::TAS * 2));
+                        const f32x2 u = *reinterpret_cast<const f32x2*>(pC + i * S);
+#pragma unroll
+                        for (int o = 0; o < VR; ++o) {
+                            if (i - o < 0 || i - o > 10) continue;
+                            f01[o][0] = pk_fma(splat2(w[i - o]), f32x2{v[0], v[1]}, f01[o][0]);
+                            f01[o][1] = pk_fma(splat2(w[i - o]), f32x2{v[2], v[3]}, f01[o][1]);
+                            f2[o] = pk_fma(splat2(w[i - o]), u, f2[o]);
+                        }
+                    }
+                    float* pf = a.F + (size_t)plane * S * S + (size_t)f0 * S + vc;
+#pragma unroll
+                    for (int o = 0; o < VR; ++o)
+                        *reinterpret_cast<float2*>(pf + (size_t)o * S) =
+                            make_float2(f01[o][0].x + 2.0f * fx[o].x * f01[o][0].y + fy[o].x * f2[o].x,
+                                        f01[o][1].x + 2.0f * fx[o].y * f01[o][1].y + fy[o].y * f2[o].y);
+                }
+            }
+            if (kb == T::NBAND - 1) {             // the plane's partial sums: per wave by DPP, then one thread in wave order
+                const float t0 = seg_sum_dpp<64>(s_ssim), t1 = seg_sum_dpp<64>(s_cs);
+                if ((tid & 63) == 63) { red[(tid >> 6) * 2] = t0; red[(tid >> 6) * 2 + 1] = t1; }
+            }
+            __syncthreads();                      // the next band's history move / staging overwrite what this band's passes read
+        }
+        if (tid == 0) {
+            float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) { t0 += red[2 * k]; t1 += red[2 * k + 1]; }
+            a.part[(size_t)plane * 2] = t0;
+            a.part[(size_t)plane * 2 + 1] = t1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // finalize: MS_NF workgroups reduce the partials / the KLD in fp64, the last arriver finishes
 // ------------------------------------------------------------------------------------------------
 struct MsFinArgs {
@@ -821,6 +1103,8 @@ struct MsWs {
     int nblk[5];
 };
 static int ms_tiles(int S) { return S == 128 ? MsT<128>::TILES : 1; }      // <= 64: msssim_plane_kernel, one partial pair per plane
+// 128-wide level: the band-streaming kernel (one partial pair per plane); CVAE_MS_STREAM=0 keeps the 16 x 64 tile kernel for A/B runs
+static bool ms_stream() { static const int v = [] { const char* e = getenv("CVAE_MS_STREAM"); return e ? atoi(e) : 1; }(); return v != 0; }
 static MsWs ms_carve(int width, int B) {
     MsWs w{};
     const int P = B * 3;
@@ -847,9 +1131,17 @@ static int ms_fwd(const MsFwdArgs& a, hipStream_t st) {
     static DeviceOnce once;
     if (a.ticket) cvae_probe_begin(st);                 // level 0 only (the launch that also zeroes the ticket)
     if constexpr (S == 128) {
-        using T = MsT<S>;
-        { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(msssim_fwd_kernel<S>), T::SMEM); if (rc) return rc; }
-        hipLaunchKernelGGL(msssim_fwd_kernel<S>, dim3(a.P * T::TILES), dim3(MS_NT), T::SMEM, st, a);
+        if (ms_stream()) {
+            using T = MsS<S, 16>;
+            static DeviceOnce once2;
+            { int rc = cvae_grant_lds(once2, reinterpret_cast<const void*>(msssim_stream_kernel<S, 16>), T::SMEM); if (rc) return rc; }
+            const int resident = cvae_num_cus();             // 135 KB of LDS: one workgroup per CU, persistent over the planes
+            hipLaunchKernelGGL((msssim_stream_kernel<S, 16>), dim3(a.P < resident ? a.P : resident), dim3(T::NT), T::SMEM, st, a);
+        } else {
+            using T = MsT<S>;
+            { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(msssim_fwd_kernel<S>), T::SMEM); if (rc) return rc; }
+            hipLaunchKernelGGL(msssim_fwd_kernel<S>, dim3(a.P * T::TILES), dim3(MS_NT), T::SMEM, st, a);
+        }
     } else {
         using T = MsP<S>;
         { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(msssim_plane_kernel<S, LAST>), T::SMEM); if (rc) return rc; }
@@ -890,7 +1182,7 @@ int launch_msssim(int width, int B, const float* img1, const float* img2, const 
     }
     MsFinArgs f{};
     for (int l = 0; l < 5; ++l) {
-        f.part[l] = ws + w.part[l]; f.nblk[l] = w.nblk[l];
+        f.part[l] = ws + w.part[l]; f.nblk[l] = ((width >> l) == 128 && ms_stream()) ? P : w.nblk[l];
         f.count[l] = (double)P * (width >> l) * (width >> l);
     }
     f.mu = mu; f.logvar = logvar; f.B = mu ? B : 0; f.scalars = scalars; f.coef = ws + w.coef;

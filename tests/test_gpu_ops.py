@@ -249,6 +249,55 @@ def test_msssim(H, golden_dir, tag):
     check(d_a.view(4, 3, 64, 64), a_ref.grad, "msssim grad", rel=True)
 
 
+@pytest.mark.parametrize("B", [3, 90])          # 90: 270 planes on 256 persistent workgroups (some walk two planes)
+def test_msssim_128_wide_streamed_level_against_oracle(B):
+    """Round 4: level 0 of 128x128 frames runs on msssim_stream_kernel (the plane streamed through LDS in 16-row bands,
+    msssim.hip).  Loss, the five ssim / cs levels and every element of the gradient against the oracle's MSSIM
+    (vae_nets.py:181-247 restated) on frames with structure (a smooth image against a noisy copy: all levels positive)."""
+    h = cvlib.Handle(128, B)
+    g = torch.Generator().manual_seed(100 + B)
+    b = torch.rand(B, 3, 128, 128, generator=g)
+    a = (0.7 * b + 0.3 * torch.rand(B, 3, 128, 128, generator=g)).clone()
+    a_ref = a.clone().requires_grad_(True)
+    loss, sims, css = orc.msssim(a_ref, b)
+    assert torch.isfinite(loss)
+    ws = torch.empty(h.op_msssim_ws_floats(B), device="cuda")
+    scal = torch.empty(16, device="cuda")
+    d_a = torch.empty(B * 3 * 128 * 128, device="cuda")
+    h.op_msssim(B, dev(a), dev(b), ws, scal, d_a)
+    torch.cuda.synchronize()
+    s = scal.cpu()
+    check(s[3:8], sims, "ssim levels", 2e-5)
+    check(s[8:13], css, "cs levels", 2e-5)
+    check(s[1], loss, "msssim loss", 2e-5)
+    loss.backward()
+    check(d_a.view(B, 3, 128, 128), a_ref.grad, "msssim grad", rel=True)
+
+
+def test_msssim_128_wide_streamed_level_is_the_tile_kernel_bit_for_bit(tmp_path):
+    """The streamed level keeps the tile kernel's item shapes and fma chains: d_recon (the F fields of all five levels through the
+    backward pass) must be bit-identical to the 16 x 64 tile kernel's (CVAE_MS_STREAM=0) and the loss scalars equal to 1e-7 (the order
+    of the per-plane partial sums differs).  The switch is read once per process: two child processes run
+    profiles/experiments/ms_stream_check.py (B = 5 and 64) and the dumps are compared here."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "profiles", "experiments", "ms_stream_check.py")
+    dumps = {}
+    for mode in ("1", "0"):
+        out = str(tmp_path / f"ms{mode}.npz")
+        env = dict(os.environ, CVAE_MS_STREAM=mode)
+        r = subprocess.run([sys.executable, script, out], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        dumps[mode] = np.load(out)
+    for k in dumps["1"].files:
+        if k.startswith("d_recon"):
+            assert np.array_equal(dumps["1"][k], dumps["0"][k]), k
+        else:
+            assert np.abs(dumps["1"][k] - dumps["0"][k]).max() < 1e-7, k
+
+
 def test_adam_matches_torch(H):
     n = 4096
     p0, g = rnd("ap", (n,)), rnd("ag", (n,), -1e-2, 1e-2)

@@ -294,7 +294,9 @@ static int run_mfma_ps(const ConvPsArgs& a, hipStream_t st) {
     return 0;
 }
 
-// returns -100 when the layer has no persistent instantiation (the caller falls back to the per-tile kernel)
+// returns -100 when the layer has no persistent instantiation (the caller falls back to the per-tile kernel).  Built by default: the
+// 64-channel-tile layers the default mask selects (E2 forward, E3 forward, E3 input gradient, both frame sizes).  -DCONVF_PS_ALL adds the
+// others — the 32-channel-tile ones spill and lose (header comment), the rest were never the default — at 8 minutes of compile time.
 int launch_conv_mfma_ps(int layer, int width, bool dgrad, int B, const float* in, const float* w, const float* bias, float* out, float* bnpart, hipStream_t st) {
     const ConvPsArgs a{in, w, bias, out, bnpart, B};
     if (!dgrad) {
@@ -302,29 +304,37 @@ int launch_conv_mfma_ps(int layer, int width, bool dgrad, int B, const float* in
             switch (layer) {
                 case 1: return run_mfma_ps<32, 64, 32, false, 64, EPI_BIAS_BNSTAT>(a, st);
                 case 2: return run_mfma_ps<64, 128, 16, false, 64, EPI_BIAS_BNSTAT>(a, st);
+#ifdef CONVF_PS_ALL
                 case 3: return run_mfma_ps<128, 256, 8, false, 32, EPI_BIAS_BNSTAT>(a, st);
+#endif
             }
         } else if (width == 128) {
             switch (layer) {
                 case 1: return run_mfma_ps<32, 64, 64, false, 64, EPI_BIAS_BNSTAT>(a, st);
                 case 2: return run_mfma_ps<64, 128, 32, false, 64, EPI_BIAS_BNSTAT>(a, st);
+#ifdef CONVF_PS_ALL
                 case 3: return run_mfma_ps<128, 256, 16, false, 64, EPI_BIAS_BNSTAT>(a, st);
                 case 4: return run_mfma_ps<256, 128, 8, false, 64, EPI_BIAS_RELU>(a, st);
+#endif
             }
         }
     } else {
         if (width == 64) {
             switch (layer) {
-                case 1: return run_mfma_ps<64, 32, 32, true, 32, EPI_PLAIN>(a, st);
                 case 2: return run_mfma_ps<128, 64, 16, true, 64, EPI_PLAIN>(a, st);
+#ifdef CONVF_PS_ALL
+                case 1: return run_mfma_ps<64, 32, 32, true, 32, EPI_PLAIN>(a, st);
                 case 3: return run_mfma_ps<256, 128, 8, true, 32, EPI_PLAIN>(a, st);
+#endif
             }
         } else if (width == 128) {
             switch (layer) {
-                case 1: return run_mfma_ps<64, 32, 64, true, 32, EPI_PLAIN>(a, st);
                 case 2: return run_mfma_ps<128, 64, 32, true, 64, EPI_PLAIN>(a, st);
+#ifdef CONVF_PS_ALL
+                case 1: return run_mfma_ps<64, 32, 64, true, 32, EPI_PLAIN>(a, st);
                 case 3: return run_mfma_ps<256, 128, 16, true, 64, EPI_PLAIN>(a, st);
                 case 4: return run_mfma_ps<128, 256, 8, true, 64, EPI_PLAIN>(a, st);
+#endif
             }
         }
     }

@@ -37,6 +37,9 @@ enum { MODE_STD = 0, MODE_UP_FWD = 1, MODE_UP_DGRAD = 2 };
 #ifndef BF16_MT
 #define BF16_MT 2          // 128-pixel tiles per workgroup of the plain bf16 kernels (1 = round-1 structure)
 #endif
+#ifndef BF16_BIG_DEFAULT
+#define BF16_BIG_DEFAULT 4     // CVAE_BF16_BIG default: bit 2 = the 128-channel input gradient on the 4 x 4 wave-tile kernel (conv_bf16_big.hip)
+#endif
 #ifndef BF16_WDMA
 #define BF16_WDMA 0        // 1 (experiment, round 3): weight slabs travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) into a double
 #endif                     // buffer, one barrier per K stage.  Correct (tests green) but SLOWER on the MI355X: E2 fwd 227 -> 237 us, E2 dgrad
@@ -854,7 +857,7 @@ int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, c
     // loop then runs at 0.94 of the matrix pipe (54.3 k cycles for 51.2 k of MFMAs, E3 forward: the fragment-bandwidth bound is gone), but
     // with nothing else resident the staging (17 k) and the 16-tile epilogue (21-30 k) are fully exposed: 224 us against 197 / 191 us
     // on the persistent two-workgroup kernel (profiles/r04_e_big_tile.txt).
-    static const int big = [] { const char* e = getenv("CVAE_BF16_BIG"); return e ? atoi(e) : 0; }();
+    static const int big = [] { const char* e = getenv("CVAE_BF16_BIG"); return e ? atoi(e) : BF16_BIG_DEFAULT; }();
     if (ns == 1 && width == 64 && layer == 2 && (big & 1)) return run_bf16_ns<64, 128, 16, 128, EPI_BIAS_BNSTAT, 1, 5, MODE_STD, 1, 4, 4>(a, st);
     if (ns == 1 && width == 64 && layer == 3 && (big & 2)) return run_bf16_ns<128, 256, 8, 128, EPI_BIAS_BNSTAT, 1, 5, MODE_STD, 1, 4, 4>(a, st);
     if (ns == 1 && use_ps_kernel(layer, false)) { const int rc = launch_conv_bf16_ps(layer, width, false, a, st); if (rc != -100) return rc; }
@@ -888,6 +891,9 @@ int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, c
 
 int launch_conv_dgrad_bf16(int layer, int width, int ns, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st) {
     ConvBf16Args a{dout, pack_ptr(const_cast<float*>(packed), layer, 1, ns >= 3 ? 3 : 1), nullptr, din, nullptr, B, 0, nullptr, ns >= 3 ? pack_units(layer) : 0, ns == 6 ? 6 : 9};
+    // CVAE_BF16_BIG bits 2 / 3: the 4-tile wave-tile kernel of conv_bf16_big.hip for the 128- / 64-channel input gradients
+    { static const int big = [] { const char* e = getenv("CVAE_BF16_BIG"); return e ? atoi(e) : BF16_BIG_DEFAULT; }();
+      if (ns == 1 && (big & 12)) { const int rc = launch_conv_bf16_big(layer, width, true, (big >> 2) & 3, a, st); if (rc != -100) return rc; } }
     if (ns == 1 && use_ps_kernel(layer, true)) { const int rc = launch_conv_bf16_ps(layer, width, true, a, st); if (rc != -100) return rc; }
     if (width == 64) {
         switch (layer) {

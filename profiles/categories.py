@@ -3,7 +3,7 @@ import csv
 import sys
 
 CATS = [
-    ("conv fwd/dgrad", ("conv5x5_mfma_kernel", "conv5x5_mfma_ps_kernel", "conv4x4_row_kernel", "conv4x4_row_bf16_kernel", "conv5x5_bf16_kernel", "conv5x5_bf16_ps_kernel", "conv_up_fwd", "conv_up_dgrad")),
+    ("conv fwd/dgrad", ("conv5x5_mfma_kernel", "conv5x5_mfma_ps_kernel", "conv4x4_row_kernel", "conv4x4_row_bf16_kernel", "conv5x5_bf16_kernel", "conv5x5_bf16_ps_kernel", "conv5x5_bf16_big_kernel", "conv_up_fwd", "conv_up_dgrad")),
     ("conv wgrad", ("conv5x5_wgrad", "conv_up_wgrad")),
     ("BatchNorm/pool", ("bn_",)),
     ("E1/D4", ("e1_", "d4_")),

@@ -322,7 +322,8 @@ int cvae_forward(cvae_handle h, int32_t B, const float* x, const float* pred, co
         else if (use_bf16(h, l)) { ProbeArm pa(h, 0, l); RC(launch_conv_fwd_bf16(l, W, bf16_mode(h), B, ws + w.a[l - 1], ws + w.wpack, P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st)); }
         else { ProbeArm pa(h, 0, l); RC(launch_conv_fwd(l, W, B, ws + w.a[l - 1], P_(h->enc_w[l]), P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st)); }
         RC(launch_bn_fwd_finalize(l, W, B, ws + w.bnpart[l], P_(h->enc_g[l]), P_(h->enc_be[l]), bn_state + kBnOff[l],
-                                  bn_state + 480 + kBnOff[l], ws + w.coef[l], ws + w.scratch, train, st));
+                                  bn_state + 480 + kBnOff[l], ws + w.coef[l], ws + w.scratch, train, st,
+                                  (l > 0 && use_bf16(h, l)) ? conv_bf16_fwd_tiles_per_partial(l, W, bf16_mode(h)) : 1));
         RC(launch_bn_pool_act_fwd(l, W, B, ws + w.y[l], ws + w.coef[l], ws + w.a[l], st, io_bf16(h)));
     }
     RC(launch_fc_fwd(W, B, ws + w.a[3], P_(h->fc_w), P_(h->fc_b), eps, pred, mu, logvar, ws + w.zcat, ws + w.scratch, st, io_bf16(h)));

@@ -462,11 +462,17 @@ static constexpr int BN_RA = 32;
 int64_t bn_fwd_ws_floats(int layer, int width) { (void)width; return (int64_t)2 * BN_RA * 3 * kLayers[layer].cout; }
 
 int launch_bn_fwd_finalize(int layer, int width, int B, const float* bnpart, const float* gamma, const float* beta,
-                           float* run_mean, float* run_var, float* coef, float* ws, int train, hipStream_t st) {
+                           float* run_mean, float* run_var, float* coef, float* ws, int train, hipStream_t st, int tilesPerPartial) {
     const BnGeom g = bn_geom(layer, width);
     int imgs, ppi, tpi;
     part_geom(layer, g.H, &imgs, &ppi, &tpi);
-    const int numTiles = cdiv(B, imgs) * tpi;
+    int numTiles = cdiv(B, imgs) * tpi;
+    if (tilesPerPartial == 4) {          // conv_bf16_big.hip: one partial per four consecutive 128-pixel tiles
+        numTiles = cdiv(numTiles, 4);
+        if (tpi >= 4) { ppi *= 4; tpi /= 4; }                  // a quarter / half of an image
+        else if (tpi == 2) { imgs = 2; ppi *= 2; tpi = 1; }     // two whole images
+        else imgs *= 4;                                         // 4 x imgs whole images
+    }
     double* mid = reinterpret_cast<double*>(ws);
     int RA = 0;
     if (train) {

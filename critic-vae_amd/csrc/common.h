@@ -189,6 +189,7 @@ int launch_conv_dgrad_bf16(int layer, int width, int ns, int B, const float* dou
 int launch_pack_up_bf16(const float* const wc[3], float* packed, int ns, hipStream_t st);
 int launch_conv_up_fwd_bf16(int layer, int width, int ns, int B, const float* in, const float* packed, const float* bias, float* out, hipStream_t st);
 int launch_conv_up_dgrad_bf16(int layer, int width, int ns, int B, const float* dout, const float* packed, const float* aux, float* din, hipStream_t st);
+int conv_bf16_fwd_tiles_per_partial(int layer, int width, int ns);     // 4: BatchNorm partials of four tiles each (conv_bf16_big.hip)
 int64_t wgrad_bf16_ws_floats(int layer, int width, int B);
 int launch_conv_wgrad_bf16(int layer, int width, int B, const float* in, const float* dout, float* dw, float* dbias, float* ws, hipStream_t st);
 bool conv_wgrad_split_supported(int products);
@@ -243,7 +244,7 @@ int launch_up_wgrad_bf16_main(int layer, int width, int B, const float* in, cons
 int bn_num_tiles(int layer, int width, int B);
 int launch_bn_fwd_finalize(int layer, int width, int B, const float* bnpart, const float* gamma,
                            const float* beta, float* run_mean, float* run_var, float* coef,
-                           float* ws, int train, hipStream_t st);
+                           float* ws, int train, hipStream_t st, int tilesPerPartial = 1);
 int64_t bn_fwd_ws_floats(int layer, int width);
 int launch_bn_pool_act_fwd(int layer, int width, int B, const float* y, const float* coef, float* a,
                            hipStream_t st, bool bf16io = false);

@@ -28,6 +28,7 @@ template <int H, int OCT> struct Bf16Geom {
 int launch_conv_bf16_ps(int layer, int width, bool dgrad, const ConvBf16Args& a, hipStream_t st);
 // conv_bf16_big.hip: 4 x 4 wave-tile kernel (experiment, CVAE_BF16_BIG bit 2: E4 input gradient); -100 if the layer has no instantiation
 int launch_conv_bf16_big(int layer, int width, bool dgrad, int mask, const ConvBf16Args& a, hipStream_t st);
+bool conv_bf16_big_has(int layer, int width, bool dgrad, int mask);
 
 // Exact 3-way bf16 split of an fp32 value: x == hi + mid + lo (each difference is exact in fp32, RNE
 // leaves at most 8 significant bits per step), used by the fp32-emulation mode (NS == 3): the nine

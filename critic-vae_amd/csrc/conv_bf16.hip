@@ -38,7 +38,9 @@ enum { MODE_STD = 0, MODE_UP_FWD = 1, MODE_UP_DGRAD = 2 };
 #define BF16_MT 2          // 128-pixel tiles per workgroup of the plain bf16 kernels (1 = round-1 structure)
 #endif
 #ifndef BF16_BIG_DEFAULT
-#define BF16_BIG_DEFAULT 4     // CVAE_BF16_BIG default: bit 2 = the 128-channel input gradient on the 4 x 4 wave-tile kernel (conv_bf16_big.hip)
+#define BF16_BIG_DEFAULT 36    // CVAE_BF16_BIG default: the 4 x 4 wave-tile kernel (conv_bf16_big.hip) for E4 — bit 2 = its input gradient (178 -> 164 us at B = 2048),
+                               // bit 5 = its forward (186 -> 180 us; BatchNorm partials of four tiles each).  Bit 4 = E3 forward (191 -> 204 us), bit 3 = E3 input gradient
+                               // (179 -> 191 us): off.  Bits 0 / 1: the first big-tile experiment (per-tile kernel instantiated with MT = 4), off.
 #endif
 #ifndef BF16_WDMA
 #define BF16_WDMA 0        // 1 (experiment, round 3): weight slabs travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) into a double
@@ -849,6 +851,11 @@ static bool use_ps_kernel(int layer, bool dgrad) {
     return ((mask >> bit) & 1) != 0;
 }
 
+// 4 when the forward conv of `layer` emits one BatchNorm partial per FOUR tiles (conv_bf16_big.hip), else 1
+int conv_bf16_fwd_tiles_per_partial(int layer, int width, int ns) {
+    static const int big = [] { const char* e = getenv("CVAE_BF16_BIG"); return e ? atoi(e) : BF16_BIG_DEFAULT; }();
+    return (ns == 1 && (big & 48) && conv_bf16_big_has(layer, width, false, (big >> 4) & 3)) ? 4 : 1;
+}
 int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, const float* packed, const float* bias, float* out,
                          float* bnpart, float* ws, hipStream_t st) {
     ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0, ns >= 3 ? 3 : 1), bias, out, bnpart, B, 0, nullptr, ns >= 3 ? pack_units(layer) : 0, ns == 6 ? 6 : 9};
@@ -858,6 +865,7 @@ int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, c
     // with nothing else resident the staging (17 k) and the 16-tile epilogue (21-30 k) are fully exposed: 224 us against 197 / 191 us
     // on the persistent two-workgroup kernel (profiles/r04_e_big_tile.txt).
     static const int big = [] { const char* e = getenv("CVAE_BF16_BIG"); return e ? atoi(e) : BF16_BIG_DEFAULT; }();
+    if (ns == 1 && (big & 48)) { const int rc = launch_conv_bf16_big(layer, width, false, (big >> 4) & 3, a, st); if (rc != -100) return rc; }       // bits 4 / 5: conv_bf16_big.hip forward (E3 / E4)
     if (ns == 1 && width == 64 && layer == 2 && (big & 1)) return run_bf16_ns<64, 128, 16, 128, EPI_BIAS_BNSTAT, 1, 5, MODE_STD, 1, 4, 4>(a, st);
     if (ns == 1 && width == 64 && layer == 3 && (big & 2)) return run_bf16_ns<128, 256, 8, 128, EPI_BIAS_BNSTAT, 1, 5, MODE_STD, 1, 4, 4>(a, st);
     if (ns == 1 && use_ps_kernel(layer, false)) { const int rc = launch_conv_bf16_ps(layer, width, false, a, st); if (rc != -100) return rc; }

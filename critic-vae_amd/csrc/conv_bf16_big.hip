@@ -1,6 +1,6 @@
-// conv_bf16_big.hip — bf16-MFMA 5x5 conv input-gradient kernel on a 4 x 4 WAVE TILE (round 4, experiment; CVAE_BF16_BIG bit 2).
+// conv_bf16_big.hip — bf16-MFMA 5x5 conv forward / input-gradient kernel on a 4 x 4 WAVE TILE (round 4; CVAE_BF16_BIG bits 2..5).
 //
-// Same call site as conv5x5_bf16_kernel<.., MODE_STD, NS = 1> for the input gradient of nn.Conv2d E4 (vae_nets.py:84 under
+// Same call sites as conv5x5_bf16_kernel<.., MODE_STD, NS = 1> (nn.Conv2d E3 / E4, vae_nets.py:79,84, and their input gradients under
 // loss.backward(), vae.py:57), same packed weights, same LDS images, same k order.  What differs is the register tile: a workgroup
 // owns FOUR 128-pixel tiles x 128 channels, every wave 32 pixels of each tile x all 128 channels = 16 accumulator tiles (256 AGPRs),
 // so one k-step reads 4 + 4 fragments for 16 MFMAs — 0.5 KB of LDS per MFMA where the two-tile / 64-channel kernels read 1 KB and
@@ -11,7 +11,9 @@
 //   * the next chunk's input tiles are requested in the last stage of a chunk and written behind a barrier at its end (the tiles
 //     are single-buffered: 4 x 19 KB + 2 x 41 KB = 157 KB of LDS);
 //   * fragments of step i + 1 are requested at the top of step i (two register sets).
-// Plain epilogue (input gradient): channel-major accumulators, v_cvt_pk + two 16-byte stores per tile, no LDS.
+// Epilogues, both from channel-major accumulators (v_cvt_pk + two 16-byte stores per tile, no transpose): plain (input gradient), or
+// bias + ONE BatchNorm partial per workgroup (its four tiles summed in the lane first).  Shipped for E4 (forward and input gradient);
+// the E3 instantiations are slower than the two-workgroup kernels and stay off (conv_bf16.hip, BF16_BIG_DEFAULT).
 #include "common.h"
 #include <stdlib.h>
 #include "conv_epilogue.h"
@@ -23,9 +25,11 @@
 #define BIG_FENCE 1       // a scheduling fence after every step
 #endif
 
-template <int KCH, int NCH, int H, int NT>
+template <int KCH, int NCH, int H, int NT, int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv5x5_bf16_big_kernel(ConvBf16Args a) {
     using T = Tile<H>;
+    static_assert(EPI == EPI_PLAIN || EPI == EPI_BIAS_BNSTAT, "epilogues: plain (input gradient) or bias + BatchNorm partials (forward)");
+    constexpr bool BN = EPI == EPI_BIAS_BNSTAT;
     constexpr int MT = 4, NB = NT / 32, KS = 5, KCB = 32, KB = KCB / 16, OCT = KCB / 8;
     constexpr int PSP = Bf16Geom<H, OCT>::PSP, A_UNITS = OCT * PSP, W_UNITS = KS * KB * 2 * NT;
     constexpr int NCHUNK = KCH / KCB, NST = NCHUNK * KS, NSTEP = KS * KB;
@@ -78,6 +82,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const bool ok = (NQ % 256 == 0 || q < NQ) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B;
             ebase[tl * IPT + i] = ok ? ((ib * H + gy) * H + gx) * KCH + oct * 8 : -1;
         }
+    // forward: the bias of this thread's channel, requested ahead of every other load (consumed after the loop, before the first store)
+    [[maybe_unused]] float bias_stash = 0.f;
+    if constexpr (BN) { if (tid < NT) bias_stash = a.bias[n0 + tid]; }
     bf16x8 wreg[WPT], breg[MT * IPT];
     bf16x8 z8;
 #pragma unroll
@@ -154,27 +161,80 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     vm_drained();
 
-    // plain epilogue: lane = pixel m of each tile, u[k] = channels 16 k + 8 lh .. + 7 of a 32-channel block
+    // epilogue: lane = pixel m of each tile, element v of block nb = channel 32 nb + (v & 3) + 8 (v >> 2) + 4 lh (channel-major accumulators);
+    // u[k] = channels 16 k + 8 lh .. + 7 of a 32-channel block.  Forward: bias, then ONE BatchNorm partial per workgroup and channel —
+    // (sum, M2 about the mean) of its four tiles' valid pixels, which launch_bn_fwd_finalize(.., tilesPerPartial = 4) merges
+    // (nn.BatchNorm2d train-mode statistics, vae_nets.py:75,80,85): the four tiles are added up in the lane first, so the cross-lane
+    // column sums (half_wave_colsum16) run once per channel block instead of once per accumulator tile.
+    bool validv[MT];
+    int gyv[MT], gxv[MT], ibv[MT];
 #pragma unroll
     for (int tl = 0; tl < MT; ++tl) {
-        const int gy = ty0v[tl] + prem / T::TW, gx = tx0v[tl] + prem % T::TW, ib = img0v[tl] + pimg;
-        const bool valid = ib < a.B;
+        gyv[tl] = ty0v[tl] + prem / T::TW; gxv[tl] = tx0v[tl] + prem % T::TW; ibv[tl] = img0v[tl] + pimg;
+        validv[tl] = ibv[tl] < a.B;
+    }
+    [[maybe_unused]] float* lds_x = reinterpret_cast<float*>(lds_w);      // [NT bias][S | Q][4 waves][NT] over the weight slabs (every wave is past the last barrier)
+    if constexpr (BN) {
+        if (tid < NT) lds_x[tid] = bias_stash;
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            f32x4 bq[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(lds_x + nb * 32 + 8 * g + 4 * lh);
+#pragma unroll
+            for (int tl = 0; tl < MT; ++tl)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[tl][nb][v] += bq[v >> 2][v & 3];
+        }
+    }
+#pragma unroll
+    for (int tl = 0; tl < MT; ++tl) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             bf16x8 u[2];
             cm_pack_units(acc[tl][nb], u);
-            const size_t base = ((size_t)(ib * H + gy) * H + gx) * NCH + n0 + nb * 32 + 8 * lh;
-            if (valid) { Act<__bf16>::st8(a.out, base, u[0]); Act<__bf16>::st8(a.out, base + 16, u[1]); }
+            const size_t base = ((size_t)(ibv[tl] * H + gyv[tl]) * H + gxv[tl]) * NCH + n0 + nb * 32 + 8 * lh;
+            if (validv[tl]) { Act<__bf16>::st8(a.out, base, u[0]); Act<__bf16>::st8(a.out, base + 16, u[1]); }
+        }
+    }
+    if constexpr (BN) {
+        float* red = lds_x + NT;
+        const int e16 = li >> 1, chE = (e16 & 3) + 8 * (e16 >> 2) + 4 * lh;       // the element half_wave_colsum16 leaves in this lane
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            float sv[16], qv[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { sv[v] = 0.f; qv[v] = 0.f; }
+#pragma unroll
+            for (int tl = 0; tl < MT; ++tl)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) { const float x = validv[tl] ? acc[tl][nb][v] : 0.f; sv[v] += x; qv[v] = fmaf(x, x, qv[v]); }
+            const float S = half_wave_colsum16(sv), Q = half_wave_colsum16(qv);
+            if ((lane & 1) == 0) { red[(0 * 4 + wave) * NT + nb * 32 + chE] = S; red[(1 * 4 + wave) * NT + nb * 32 + chE] = Q; }
+        }
+        __syncthreads();
+        if (tid < NT) {
+            float S = 0.f, Q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { S += red[(0 * 4 + w) * NT + tid]; Q += red[(1 * 4 + w) * NT + tid]; }
+            int cnt = 0;
+#pragma unroll
+            for (int tl = 0; tl < MT; ++tl) { int ni = a.B - img0v[tl]; ni = ni < 0 ? 0 : (ni > T::IMGS ? T::IMGS : ni); cnt += ni * T::TH * T::TW; }
+            const int numBig = gridDim.x, big = mt0 / MT;
+            const double m2 = cnt > 0 ? (double)Q - (double)S * (double)S / (double)cnt : 0.0;
+            a.bnpart[(size_t)big * NCH + n0 + tid] = S;
+            a.bnpart[((size_t)numBig + big) * NCH + n0 + tid] = (float)(m2 > 0.0 ? m2 : 0.0);
         }
     }
 }
 
-template <int KCH, int NCH, int H, int NT>
+template <int KCH, int NCH, int H, int NT, int EPI>
 static int run_big(const ConvBf16Args& a, hipStream_t st) {
     using T = Tile<H>;
     constexpr int SMEM = (4 * 4 * Bf16Geom<H, 4>::PSP + 2 * 5 * 2 * 2 * NT) * 16;
     static_assert(SMEM <= 160 * 1024, "LDS");
-    auto kern = conv5x5_bf16_big_kernel<KCH, NCH, H, NT>;
+    auto kern = conv5x5_bf16_big_kernel<KCH, NCH, H, NT, EPI>;
     static DeviceOnce once;
     { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(kern), SMEM); if (rc) return rc; }
     dim3 grid(cdiv(cdiv(a.B, T::IMGS) * T::TILES_PER_IMG, 4), NCH / NT);
@@ -185,13 +245,26 @@ static int run_big(const ConvBf16Args& a, hipStream_t st) {
     return 0;
 }
 
-// returns -100 when the layer has no instantiation.  mask: bit 0 = the 128-channel input gradient (E4 at 64 x 64 frames, E4 at 128 x 128),
-// bit 1 = the 64-channel one (E3)
+// which layers this file serves.  Input gradients: mask bit 0 = the 128-channel one (E4), bit 1 = the 64-channel one (E3).  Forward (bias +
+// BatchNorm partials of FOUR tiles each — the caller must tell launch_bn_fwd_finalize): mask bit 0 = E3 (64 -> 128), bit 1 = E4 (128 -> 256)
+bool conv_bf16_big_has(int layer, int width, bool dgrad, int mask) {
+    if (width != 64 && width != 128) return false;
+    if (dgrad) return (layer == 3 && (mask & 1)) || (layer == 2 && (mask & 2));
+    return (layer == 2 && (mask & 1)) || (layer == 3 && (mask & 2));
+}
+// returns -100 when the layer has no instantiation
 int launch_conv_bf16_big(int layer, int width, bool dgrad, int mask, const ConvBf16Args& a, hipStream_t st) {
-    if (!dgrad) return -100;
-    if (width == 64 && layer == 3 && (mask & 1)) return run_big<256, 128, 8, 128>(a, st);
-    if (width == 64 && layer == 2 && (mask & 2)) return run_big<128, 64, 16, 64>(a, st);
-    if (width == 128 && layer == 3 && (mask & 1)) return run_big<256, 128, 16, 128>(a, st);
-    if (width == 128 && layer == 2 && (mask & 2)) return run_big<128, 64, 32, 64>(a, st);
+    if (!conv_bf16_big_has(layer, width, dgrad, mask)) return -100;
+    if (dgrad) {
+        if (width == 64 && layer == 3) return run_big<256, 128, 8, 128, EPI_PLAIN>(a, st);
+        if (width == 64 && layer == 2) return run_big<128, 64, 16, 64, EPI_PLAIN>(a, st);
+        if (width == 128 && layer == 3) return run_big<256, 128, 16, 128, EPI_PLAIN>(a, st);
+        if (width == 128 && layer == 2) return run_big<128, 64, 32, 64, EPI_PLAIN>(a, st);
+    } else {
+        if (width == 64 && layer == 2) return run_big<64, 128, 16, 128, EPI_BIAS_BNSTAT>(a, st);
+        if (width == 64 && layer == 3) return run_big<128, 256, 8, 128, EPI_BIAS_BNSTAT>(a, st);
+        if (width == 128 && layer == 2) return run_big<64, 128, 32, 128, EPI_BIAS_BNSTAT>(a, st);
+        if (width == 128 && layer == 3) return run_big<128, 256, 16, 128, EPI_BIAS_BNSTAT>(a, st);
+    }
     return -100;
 }

@@ -52,7 +52,7 @@ def patterns(prec, width):
                 p[f"conv_wgrad_L{l}"] = rf"conv5x5_wgrad_tr_kernel<{cin}, {cout}, {h},"
             elif l <= 4:
                 # round 4: E2..E4 forward run on the persistent kernel (conv_bf16_ps.hip); either name matches, whichever ran
-                p[f"conv_fwd_L{l}"] = rf"conv5x5_bf16(_ps)?_kernel<{cin}, {cout}, {h}, \d+, [012](, \d+, 5, 0,|>)"
+                p[f"conv_fwd_L{l}"] = rf"conv5x5_bf16(_ps)?_kernel<{cin}, {cout}, {h}, \d+, [012](, \d+, 5, 0,|>)|conv5x5_bf16_big_kernel<{cin}, {cout}, {h},"
                 p[f"conv_dgrad_L{l}"] = rf"conv5x5_bf16(_ps)?_kernel<{cout}, {cin}, {h}, \d+, 2(, \d+, 5, 0,|>)|conv5x5_bf16_big_kernel<{cout}, {cin}, {h},"
                 p[f"conv_wgrad_L{l}"] = rf"conv5x5_wgrad_tr_kernel<{cin}, {cout}, {h},"
             else:

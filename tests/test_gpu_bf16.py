@@ -297,6 +297,23 @@ def test_bf16x6_step_at_128x128_frames_meets_the_fp32_parity_bar():
     assert abs(float(losses["total_loss"].item()) - float(o["total_loss"].detach())) < 1e-4
 
 
+def test_big_tile_conv_kernels_every_instantiation_exact_on_their_stored_operands():
+    """conv_bf16_big.hip (round 4: 4 x 4 wave tile, staging inside the MFMA stream) runs E4's forward and input gradient by
+    default; its E3 instantiations (forward, and the 64-channel input gradient) are compiled but off (slower).  The switch
+    (CVAE_BF16_BIG) is read once per process, so a child process runs the stored-operand test of this file — every conv
+    output recomputed on the CPU from the bf16 operands the kernels consumed, B = 8 and the ragged B = 5 — with all four
+    instantiations on (bits 2..5), including the forward ones' four-tile BatchNorm partials."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CVAE_BF16_BIG="60")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_bf16.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "kernels_exact_on_their_stored_operands or two_pass_e1"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 def test_bn_pool_ops_follow_the_handle_storage_type():
     """The stand-alone BatchNorm/pool ops of a bf16-storage handle read and write bf16 tensors (as the step does):
     eval-mode forward (coefficients from the running statistics) and the backward apply pass against a torch

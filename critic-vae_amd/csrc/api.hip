@@ -305,6 +305,7 @@ int cvae_forward(cvae_handle h, int32_t B, const float* x, const float* pred, co
     const int W = h->cfg.width;
     RC(pack_bf16_weights(h, params, ws, w, st));
     for (int l = 0; l < 4; ++l) {
+        int tpp = 1;                            // 128-pixel tiles per BatchNorm partial row, as reported by the conv kernel that ran
         if (l == 0 && h->e1_two_pass) {
             // bf16 mode, block 0: conv (statistics only) -> merged statistics -> conv again with BatchNorm/pool/ReLU in its
             // epilogue (writes y0 for the backward and a0); bn_pool_act_fwd's read of y0 is replaced by a second read of x
@@ -319,11 +320,11 @@ int cvae_forward(cvae_handle h, int32_t B, const float* x, const float* pred, co
             continue;
         }
         if (l == 0) { ProbeArm pa(h, 0, 0); RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], ws + w.bnpart[0], st, h->cfg.precision == 1)); }
-        else if (use_bf16(h, l)) { ProbeArm pa(h, 0, l); RC(launch_conv_fwd_bf16(l, W, bf16_mode(h), B, ws + w.a[l - 1], ws + w.wpack, P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st)); }
+        else if (use_bf16(h, l)) { ProbeArm pa(h, 0, l); RC(launch_conv_fwd_bf16(l, W, bf16_mode(h), B, ws + w.a[l - 1], ws + w.wpack, P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st, &tpp)); }
         else { ProbeArm pa(h, 0, l); RC(launch_conv_fwd(l, W, B, ws + w.a[l - 1], P_(h->enc_w[l]), P_(h->enc_b[l]), ws + w.y[l], ws + w.bnpart[l], ws + w.scratch, st)); }
         RC(launch_bn_fwd_finalize(l, W, B, ws + w.bnpart[l], P_(h->enc_g[l]), P_(h->enc_be[l]), bn_state + kBnOff[l],
                                   bn_state + 480 + kBnOff[l], ws + w.coef[l], ws + w.scratch, train, st,
-                                  (l > 0 && use_bf16(h, l)) ? conv_bf16_fwd_tiles_per_partial(l, W, bf16_mode(h)) : 1));
+                                  tpp));
         RC(launch_bn_pool_act_fwd(l, W, B, ws + w.y[l], ws + w.coef[l], ws + w.a[l], st, io_bf16(h)));
     }
     RC(launch_fc_fwd(W, B, ws + w.a[3], P_(h->fc_w), P_(h->fc_b), eps, pred, mu, logvar, ws + w.zcat, ws + w.scratch, st, io_bf16(h)));

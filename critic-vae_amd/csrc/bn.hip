@@ -467,11 +467,12 @@ int launch_bn_fwd_finalize(int layer, int width, int B, const float* bnpart, con
     int imgs, ppi, tpi;
     part_geom(layer, g.H, &imgs, &ppi, &tpi);
     int numTiles = cdiv(B, imgs) * tpi;
-    if (tilesPerPartial == 4) {          // conv_bf16_big.hip: one partial per four consecutive 128-pixel tiles
-        numTiles = cdiv(numTiles, 4);
-        if (tpi >= 4) { ppi *= 4; tpi /= 4; }                  // a quarter / half of an image
-        else if (tpi == 2) { imgs = 2; ppi *= 2; tpi = 1; }     // two whole images
-        else imgs *= 4;                                         // 4 x imgs whole images
+    if (tilesPerPartial > 1) {           // conv_bf16_big.hip: one partial per T = 4 / 8 consecutive 128-pixel tiles (T a power of two)
+        const int T = tilesPerPartial;
+        numTiles = cdiv(numTiles, T);
+        if (tpi >= T) { ppi *= T; tpi /= T; }                          // a part of an image
+        else if (tpi > 1) { imgs = T / tpi; ppi *= tpi; tpi = 1; }      // T / tpi whole images (a tile is at most one image while tpi > 1)
+        else imgs *= T;                                                 // T x imgs whole images
     }
     double* mid = reinterpret_cast<double*>(ws);
     int RA = 0;

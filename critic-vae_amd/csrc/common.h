@@ -184,12 +184,11 @@ bool conv_bf16_supported(int layer, int width);
 int64_t conv_bf16_pack_floats(int ns);
 int launch_pack_w_bf16(const float* const w[4], float* packed, int ns, hipStream_t st);     // ns = 1 (bf16) or 3 (fp32 emulation)
 int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, const float* packed, const float* bias, float* out,
-                         float* bnpart, float* ws, hipStream_t st);
+                         float* bnpart, float* ws, hipStream_t st, int* tilesPerPartial = nullptr);    // out: 128-pixel tiles per BatchNorm partial row
 int launch_conv_dgrad_bf16(int layer, int width, int ns, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st);
 int launch_pack_up_bf16(const float* const wc[3], float* packed, int ns, hipStream_t st);
 int launch_conv_up_fwd_bf16(int layer, int width, int ns, int B, const float* in, const float* packed, const float* bias, float* out, hipStream_t st);
 int launch_conv_up_dgrad_bf16(int layer, int width, int ns, int B, const float* dout, const float* packed, const float* aux, float* din, hipStream_t st);
-int conv_bf16_fwd_tiles_per_partial(int layer, int width, int ns);     // 4: BatchNorm partials of four tiles each (conv_bf16_big.hip)
 int64_t wgrad_bf16_ws_floats(int layer, int width, int B);
 int launch_conv_wgrad_bf16(int layer, int width, int B, const float* in, const float* dout, float* dw, float* dbias, float* ws, hipStream_t st);
 bool conv_wgrad_split_supported(int products);

@@ -29,6 +29,7 @@ int launch_conv_bf16_ps(int layer, int width, bool dgrad, const ConvBf16Args& a,
 // conv_bf16_big.hip: 4 x 4 wave-tile kernel (experiment, CVAE_BF16_BIG bit 2: E4 input gradient); -100 if the layer has no instantiation
 int launch_conv_bf16_big(int layer, int width, bool dgrad, int mask, const ConvBf16Args& a, hipStream_t st);
 bool conv_bf16_big_has(int layer, int width, bool dgrad, int mask);
+int conv_bf16_big_tiles(int layer, int width, bool dgrad);      // 128-pixel tiles per item (= per BatchNorm partial of its forward passes)
 
 // Exact 3-way bf16 split of an fp32 value: x == hi + mid + lo (each difference is exact in fp32, RNE
 // leaves at most 8 significant bits per step), used by the fp32-emulation mode (NS == 3): the nine

@@ -38,9 +38,8 @@ enum { MODE_STD = 0, MODE_UP_FWD = 1, MODE_UP_DGRAD = 2 };
 #define BF16_MT 2          // 128-pixel tiles per workgroup of the plain bf16 kernels (1 = round-1 structure)
 #endif
 #ifndef BF16_BIG_DEFAULT
-#define BF16_BIG_DEFAULT 36    // CVAE_BF16_BIG default: the 4 x 4 wave-tile kernel (conv_bf16_big.hip) for E4 — bit 2 = its input gradient (178 -> 164 us at B = 2048),
-                               // bit 5 = its forward (186 -> 180 us; BatchNorm partials of four tiles each).  Bit 4 = E3 forward (191 -> 204 us), bit 3 = E3 input gradient
-                               // (179 -> 191 us): off.  Bits 0 / 1: the first big-tile experiment (per-tile kernel instantiated with MT = 4), off.
+#define BF16_BIG_DEFAULT 60    // CVAE_BF16_BIG default: the persistent 16-accumulator-tile kernel (conv_bf16_big.hip) — bit 2 = E4 input gradient, bit 3 = E3 input
+                               // gradient, bit 4 = E3 forward, bit 5 = E4 forward (BatchNorm partials of four tiles each).  0 = the two-workgroup kernels (A/B runs).
 #endif
 #ifndef BF16_WDMA
 #define BF16_WDMA 0        // 1 (experiment, round 3): weight slabs travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) into a double
@@ -851,23 +850,23 @@ static bool use_ps_kernel(int layer, bool dgrad) {
     return ((mask >> bit) & 1) != 0;
 }
 
-// 4 when the forward conv of `layer` emits one BatchNorm partial per FOUR tiles (conv_bf16_big.hip), else 1
-int conv_bf16_fwd_tiles_per_partial(int layer, int width, int ns) {
+static int bf16_big_mask() {
     static const int big = [] { const char* e = getenv("CVAE_BF16_BIG"); return e ? atoi(e) : BF16_BIG_DEFAULT; }();
-    return (ns == 1 && (big & 48) && conv_bf16_big_has(layer, width, false, (big >> 4) & 3)) ? 4 : 1;
+    return big;
 }
+// `tilesPerPartial` (out, may be null): how many 128-pixel tiles one BatchNorm partial row of `bnpart` covers — 1 for the per-tile and the
+// two-workgroup persistent kernels, 4 for the items of conv_bf16_big.hip.  The caller hands it to launch_bn_fwd_finalize: the kernel that
+// actually ran decides, not a second reading of the switches.
 int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, const float* packed, const float* bias, float* out,
-                         float* bnpart, float* ws, hipStream_t st) {
+                         float* bnpart, float* ws, hipStream_t st, int* tilesPerPartial) {
     ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0, ns >= 3 ? 3 : 1), bias, out, bnpart, B, 0, nullptr, ns >= 3 ? pack_units(layer) : 0, ns == 6 ? 6 : 9};
-    // CVAE_BF16_BIG (experiment, round 4; default off): 4 tiles x 128 channels per workgroup = 16 accumulator tiles per wave (0.5 fragment
-    // reads per MFMA instead of 1.0), one workgroup per CU, one wave per SIMD.  bit 0 = E3 forward, bit 1 = E4 forward.  Correct; the MFMA
-    // loop then runs at 0.94 of the matrix pipe (54.3 k cycles for 51.2 k of MFMAs, E3 forward: the fragment-bandwidth bound is gone), but
-    // with nothing else resident the staging (17 k) and the 16-tile epilogue (21-30 k) are fully exposed: 224 us against 197 / 191 us
-    // on the persistent two-workgroup kernel (profiles/r04_e_big_tile.txt).
-    static const int big = [] { const char* e = getenv("CVAE_BF16_BIG"); return e ? atoi(e) : BF16_BIG_DEFAULT; }();
-    if (ns == 1 && (big & 48)) { const int rc = launch_conv_bf16_big(layer, width, false, (big >> 4) & 3, a, st); if (rc != -100) return rc; }       // bits 4 / 5: conv_bf16_big.hip forward (E3 / E4)
-    if (ns == 1 && width == 64 && layer == 2 && (big & 1)) return run_bf16_ns<64, 128, 16, 128, EPI_BIAS_BNSTAT, 1, 5, MODE_STD, 1, 4, 4>(a, st);
-    if (ns == 1 && width == 64 && layer == 3 && (big & 2)) return run_bf16_ns<128, 256, 8, 128, EPI_BIAS_BNSTAT, 1, 5, MODE_STD, 1, 4, 4>(a, st);
+    if (tilesPerPartial) *tilesPerPartial = 1;
+    // CVAE_BF16_BIG bits 4 / 5: conv_bf16_big.hip forward (E3 / E4) — persistent workgroups on a 4 x 4 wave tile
+    const int big = bf16_big_mask();
+    if (ns == 1 && (big & 48)) {
+        const int rc = launch_conv_bf16_big(layer, width, false, (big >> 4) & 3, a, st);
+        if (rc != -100) { if (tilesPerPartial) *tilesPerPartial = conv_bf16_big_tiles(layer, width, false); return rc; }
+    }
     if (ns == 1 && use_ps_kernel(layer, false)) { const int rc = launch_conv_bf16_ps(layer, width, false, a, st); if (rc != -100) return rc; }
     if (width == 64) {
         switch (layer) {
@@ -899,8 +898,8 @@ int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, c
 
 int launch_conv_dgrad_bf16(int layer, int width, int ns, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st) {
     ConvBf16Args a{dout, pack_ptr(const_cast<float*>(packed), layer, 1, ns >= 3 ? 3 : 1), nullptr, din, nullptr, B, 0, nullptr, ns >= 3 ? pack_units(layer) : 0, ns == 6 ? 6 : 9};
-    // CVAE_BF16_BIG bits 2 / 3: the 4-tile wave-tile kernel of conv_bf16_big.hip for the 128- / 64-channel input gradients
-    { static const int big = [] { const char* e = getenv("CVAE_BF16_BIG"); return e ? atoi(e) : BF16_BIG_DEFAULT; }();
+    // CVAE_BF16_BIG bits 2 / 3: conv_bf16_big.hip for the 128- / 64-channel input gradients (E4: 4 x 4 wave tile, E3: 8 x 2)
+    { const int big = bf16_big_mask();
       if (ns == 1 && (big & 12)) { const int rc = launch_conv_bf16_big(layer, width, true, (big >> 2) & 3, a, st); if (rc != -100) return rc; } }
     if (ns == 1 && use_ps_kernel(layer, true)) { const int rc = launch_conv_bf16_ps(layer, width, true, a, st); if (rc != -100) return rc; }
     if (width == 64) {

@@ -1,270 +1,451 @@
-// conv_bf16_big.hip — bf16-MFMA 5x5 conv forward / input-gradient kernel on a 4 x 4 WAVE TILE (round 4; CVAE_BF16_BIG bits 2..5).
+// conv_bf16_big.hip — PERSISTENT bf16-MFMA 5x5 conv forward / input-gradient kernel on a 16-accumulator-tile WAVE TILE (rounds 4-5).
 //
-// Same call sites as conv5x5_bf16_kernel<.., MODE_STD, NS = 1> (nn.Conv2d E3 / E4, vae_nets.py:79,84, and their input gradients under
+// Same call sites as conv5x5_bf16_kernel<.., MODE_STD, NS = 1> (nn.Conv2d E2..E4, vae_nets.py:74,79,84, and their input gradients under
 // loss.backward(), vae.py:57), same packed weights, same LDS images, same k order.  What differs is the register tile: a workgroup
-// owns FOUR 128-pixel tiles x 128 channels, every wave 32 pixels of each tile x all 128 channels = 16 accumulator tiles (256 AGPRs),
-// so one k-step reads 4 + 4 fragments for 16 MFMAs — 0.5 KB of LDS per MFMA where the two-tile / 64-channel kernels read 1 KB and
-// are bound by exactly that ("Round 4").  One workgroup per CU, one wave per SIMD: nothing else is resident to hide
-// the staging, so the staging lives INSIDE the MFMA stream, with few registers live at a time:
-//   * the weight slab is double-buffered in LDS; the slab of stage st + 1 is requested at step 0 of stage st and written into the
-//     other buffer at steps 5 .. 9 (two 16-byte units per step), one barrier per stage;
-//   * the next chunk's input tiles are requested in the last stage of a chunk and written behind a barrier at its end (the tiles
-//     are single-buffered: 4 x 19 KB + 2 x 41 KB = 157 KB of LDS);
-//   * fragments of step i + 1 are requested at the top of step i (two register sets).
-// Epilogues, both from channel-major accumulators (v_cvt_pk + two 16-byte stores per tile, no transpose): plain (input gradient), or
-// bias + ONE BatchNorm partial per workgroup (its four tiles summed in the lane first).  Shipped for E4 (forward and input gradient);
-// the E3 instantiations are slower than the two-workgroup kernels and stay off (conv_bf16.hip, BF16_BIG_DEFAULT).
+// owns MT 128-pixel tiles x NT channels, every wave 32 pixels of each tile x all NT channels = MT x NT/32 = 16 accumulator tiles
+// (256 AGPRs), so one k-step reads MT + NT/32 fragments for 16 MFMAs — 0.5 KB (4 x 4) or 0.625 KB (8 x 2) of LDS per MFMA where the
+// two-tile / 64-channel kernels read 1 KB and are bound by exactly that ("Round 4").  One workgroup per CU, one wave per
+// SIMD: nothing else is resident to hide anything, so everything that is not an MFMA lives INSIDE the MFMA stream, in fixed slots:
+//   * fragments of step i + 1 are requested in the first slots of step i — one ds_read_b128 behind each of the first MFMAs, pinned with
+//     sched_group_barrier (round 4 left the placement to the compiler, which sank the reads to three MFMAs in front of their use:
+//     6.3 k cycles per stage for 5.1 k of MFMAs, profiles/r05_a_big_timing_round4_kernel.txt);
+//   * the weight slab is double-buffered in LDS: the slab of stage g + 1 is requested at step 0 of stage g and written into the other
+//     buffer a few steps later; ONE barrier per stage, placed in FRONT of the stage's last step, so that the first fragments of the next
+//     stage are requested behind it and travel under that step's 16 MFMAs;
+//   * the next chunk's input tiles are requested in the chunk's last stage and written — behind the same barrier — between the MFMAs
+//     of its last step (the tiles are single-buffered), a second barrier closes the chunk;
+//   * PERSISTENT workgroups (round 5) walk (tile group, channel block) items in an XCD-contiguous order: the next item's tiles, its
+//     slab 0 AND its slab 1 are requested before the current item's epilogue (vmcnt retires loads and stores in issue order: a load
+//     consumed behind the epilogue's stores would wait for their write acknowledgements), so an item starts without a cold prologue
+//     and the epilogue's stores drain under the next item's MFMAs.
+// Epilogues, both from channel-major accumulators (v_cvt_pk + two 16-byte buffer stores per tile, no transpose, invalid lanes as
+// out-of-range offsets): plain (input gradient), or bias (= the accumulators' initial value) + ONE BatchNorm partial per item — its MT
+// tiles summed in the lane before the cross-lane column sums (launch_bn_fwd_finalize(.., tilesPerPartial = MT)).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 #include "conv_epilogue.h"
 #include "conv_bf16.h"
-#ifndef BIG_PF
-#define BIG_PF 1          // fragment sets requested ahead of the MFMAs that use them
+
+// -DBIG_TIMING (timing builds): cycles of ONE instantiation (-DBIG_T_KCH/NCH/H), wave 0 lane 0 of the sampled workgroups (blockIdx.x a
+// multiple of 16 below 256): [items, prologue, stages (MFMA stream with everything interleaved), chunk-closing barriers + first fragments,
+// epilogue, whole kernel, s_memrealtime ticks of the whole kernel, stages per item, entry tick, exit tick]
+#ifdef BIG_TIMING
+__device__ long long big_dbg[16 * 12];
+extern "C" int cvae_big_dbg_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(big_dbg), sizeof(big_dbg)); }
+#define BT_ON (KCH == BIG_T_KCH && NCH == BIG_T_NCH && H == BIG_T_H)
+#define BT(v) do { if (BT_ON) { __builtin_amdgcn_sched_barrier(0); v = clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define BT_ON false
+#define BT(v)
 #endif
-#ifndef BIG_FENCE
-#define BIG_FENCE 1       // a scheduling fence after every step
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+// Timing experiments (WRONG results, never shipped; profiles/experiments/variant.sh -DBIG_EXP=n): what the stage loop pays for each of its
+// parts.  bit 0: no barrier in front of a stage's last step;  bit 1: no slab writes;  bit 2: no slab requests;  bit 3: no tile requests / writes
+#ifndef BIG_EXP
+#define BIG_EXP 0
 #endif
 
-template <int KCH, int NCH, int H, int NT, int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv5x5_bf16_big_kernel(ConvBf16Args a) {
+// raw buffer descriptor over a whole tensor (gfx9 word 3: DATA_FORMAT_32): a lane whose byte offset is >= bytes is dropped by the
+// bounds check, so "store if valid" needs no branch (tensors of 2 GiB and more do not take this kernel: run_big returns -100)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t big_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+static constexpr unsigned BIG_OOB = 0x80000000u;
+
+template <int KCH, int NCH, int H, int NT, int MT, int KB, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv5x5_bf16_big_kernel(ConvBf16Args a, int numGroups) {
     using T = Tile<H>;
     static_assert(EPI == EPI_PLAIN || EPI == EPI_BIAS_BNSTAT, "epilogues: plain (input gradient) or bias + BatchNorm partials (forward)");
     constexpr bool BN = EPI == EPI_BIAS_BNSTAT;
-    constexpr int MT = 4, NB = NT / 32, KS = 5, KCB = 32, KB = KCB / 16, OCT = KCB / 8;
+    constexpr int NB = NT / 32, KS = 5, KCB = 16 * KB, OCT = KCB / 8, NY = NCH / NT;
     constexpr int PSP = Bf16Geom<H, OCT>::PSP, A_UNITS = OCT * PSP, W_UNITS = KS * KB * 2 * NT;
     constexpr int NCHUNK = KCH / KCB, NST = NCHUNK * KS, NSTEP = KS * KB;
-    static_assert(KCH % KCB == 0 && NCH % NT == 0 && W_UNITS % (5 * 256) == 0 && NSTEP == 10, "tiling");
+    static_assert(KCH % KCB == 0 && NCH % NT == 0 && MT * NB == 16 && (KB == 1 || KB == 2), "tiling");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);       // [tile][octet][halo pixel]
     bf16x8* lds_w = lds_a + MT * A_UNITS;                      // [buffer][tap][kb][half][n]
+    [[maybe_unused]] float* lds_bias = reinterpret_cast<float*>(lds_w + 2 * W_UNITS + 256); // [NCH] (forward only), behind 256 dump units for the staging stores of units that do not exist
+    [[maybe_unused]] float* red = lds_bias + NCH;                                          // [S | Q][wave][NT]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int mt0 = xcd_tile(blockIdx.x, gridDim.x) * MT, n0 = blockIdx.y * NT;
-    int img0v[MT], ty0v[MT], tx0v[MT];
-#pragma unroll
-    for (int tl = 0; tl < MT; ++tl) {          // a tile index past the end maps to images >= B: loads give 0, stores are skipped
-        const int tileInImg = (mt0 + tl) % T::TILES_PER_IMG;
-        img0v[tl] = ((mt0 + tl) / T::TILES_PER_IMG) * T::IMGS;
-        ty0v[tl] = (tileInImg / T::TILES_X) * T::TH; tx0v[tl] = (tileInImg % T::TILES_X) * T::TW;
-    }
-    const int m = wave * 32 + lane_pix<H, true>(li);
+    [[maybe_unused]] long long b0 = 0, b1 = 0, b2 = 0, tpro = 0, tstage = 0, tclose = 0, tepi = 0, nit = 0;
+    [[maybe_unused]] const long long brt0 = BT_ON ? (long long)wall_clock64() : 0;
+    BT(b0);
+    [[maybe_unused]] const long long bt_entry = b0;
+
+    // item -> (tile group, channel block): XCD x (= item & 7 while gridDim.x % 8 == 0) owns the contiguous range of groups
+    // [x PP, (x+1) PP) — neighbouring tiles share halo rows in ONE L2 — and walks it group by group, the NY channel blocks of a group
+    // back to back (the input tiles are re-read from L2, not from HBM); conv_bf16_ps.hip
+    const int G = gridDim.x, PP = cdiv(numGroups, 8), numItems = 8 * PP * NY;
+    auto decode = [&](int it, int& grp, int& n0) { const int x = it & 7, j = it >> 3, jp = j / NY; n0 = (j - jp * NY) * NT; grp = jp < PP ? x * PP + jp : numGroups; };
+    int it = blockIdx.x, grp0, n00;
+    decode(it, grp0, n00);
+    if (it >= numItems || grp0 >= numGroups) return;           // whole workgroup (G % 8 == 0: once past the end, always past the end)
+
+    // ---- per-thread tables that do not depend on the item ----
+    const int m = wave * 32 + lane_pix<H, true>(li);           // pixel (of the 128 of a tile) behind MFMA column li of this wave
     const int pimg = m / (T::TH * T::TW), prem = m % (T::TH * T::TW);
     const int aPix = pimg * T::HPI + (prem / T::TW) * T::HTW + (prem % T::TW);
-
-    f32x16 acc[MT][NB];
-#pragma unroll
-    for (int tl = 0; tl < MT; ++tl)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[tl][nb][v] = 0.f;
-
-    // staging tables (fixed for the launch): weight unit q = tid + 256 i of a slab, input unit q of a tile
-    constexpr int WPT = W_UNITS / 256;
-    int wbase[WPT];
+    const int orel = (pimg * H + prem / T::TW) * H + prem % T::TW;          // output pixel relative to the tile's first pixel
+    constexpr int WPT = (W_UNITS + 255) / 256;
+    unsigned wbase[WPT];                                       // byte offset inside a stage's slab of the packed weights (without n0)
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
-        const int q = tid + i * 256;
-        const int n = q % NT, row = q / NT, half = row & 1, kb = (row >> 1) % KB, s = row / (2 * KB);
-        wbase[i] = ((s * (KCH / 16) + kb) * 2 + half) * NCH + n0 + n;
+        const int q = tid + i * 256, n = q % NT, row = q / NT, half = row & 1, kb = (row >> 1) % KB, s = row / (2 * KB);
+        wbase[i] = (W_UNITS % 256 == 0 || q < W_UNITS) ? (((s * (KCH / 16) + kb) * 2 + half) * NCH + n) * 16 : 0;      // past the slab: unit 0 (never staged)
     }
     constexpr int NQ = T::HP * OCT, IPT = (NQ + 255) / 256;
     static_assert(MT * IPT <= 32, "one validity bit per staged unit");
-    int ebase[MT * IPT];
+    int irel[IPT];                                             // byte offset of the unit relative to the tile's first pixel, chunk 0
+    unsigned ipk[IPT];                                         // halo row | halo column << 8 | image << 16 | unit exists << 31
 #pragma unroll
-    for (int tl = 0; tl < MT; ++tl)
+    for (int i = 0; i < IPT; ++i) {
+        const int q = tid + i * 256, oct = q % OCT, hp = q / OCT, img = hp / T::HPI, rem = hp - img * T::HPI;
+        const int hy = rem / T::HTW, hx = rem % T::HTW;
+        irel[i] = (((img * H + hy - 2) * H + hx - 2) * KCH + oct * 8) * 2;
+        ipk[i] = (unsigned)hy | ((unsigned)hx << 8) | ((unsigned)img << 16) | ((NQ % 256 == 0 || q < NQ) ? 0x80000000u : 0u);
+    }
+    const __amdgpu_buffer_rsrc_t rs_out = big_rsrc(a.out, (unsigned)((size_t)a.B * H * H * NCH * 2));
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_bn = big_rsrc(a.bnpart, BN ? (unsigned)((size_t)2 * numGroups * NCH * 4) : 0u);
+    // Operands travel as buffer loads (uniform descriptor + 32-bit lane offset + uniform SGPR offset: no 64-bit lane addresses, vmcnt only —
+    // the flat loads hipcc emits for a laundered pointer also count in lgkmcnt and so sit in every fragment wait).  The input descriptor
+    // starts IBIAS bytes in front of the tensor so that the halo's negative offsets are non-negative lane offsets (the bounds check of a raw
+    // buffer looks at the lane offset alone); zero padding = a lane offset past the end: the load returns 0 without touching memory.
+    constexpr int IBIAS = (2 * H + 2) * KCH * 2;
+    const __amdgpu_buffer_rsrc_t rs_w = big_rsrc(a.wp, (unsigned)(25 * (KCH / 16) * 2 * NCH * 16));
+    const __amdgpu_buffer_rsrc_t rs_in = big_rsrc(reinterpret_cast<const char*>(a.in) - IBIAS, (unsigned)((size_t)a.B * H * H * KCH * 2 + IBIAS));
+
+    // ---- item state (wave-uniform) ----
+    struct Item { int n0, grp, img0[MT], ty0[MT], tx0[MT], ibase[MT]; };
+    auto setup = [&](int g, int nn0) {
+        Item x; x.n0 = nn0; x.grp = g;
 #pragma unroll
-        for (int i = 0; i < IPT; ++i) {
-            const int q = tid + i * 256;
-            const int oct = q % OCT, hp = q / OCT;
-            const int img = hp / T::HPI, rem = hp - img * T::HPI;
-            const int gy = ty0v[tl] + rem / T::HTW - 2, gx = tx0v[tl] + rem % T::HTW - 2, ib = img0v[tl] + img;
-            const bool ok = (NQ % 256 == 0 || q < NQ) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)H && ib < a.B;
-            ebase[tl * IPT + i] = ok ? ((ib * H + gy) * H + gx) * KCH + oct * 8 : -1;
+        for (int tl = 0; tl < MT; ++tl) {                      // a tile index past the end maps to images >= B: loads give 0, stores are dropped
+            const int mt = g * MT + tl, tin = mt % T::TILES_PER_IMG;
+            x.img0[tl] = (mt / T::TILES_PER_IMG) * T::IMGS;
+            x.ty0[tl] = (tin / T::TILES_X) * T::TH; x.tx0[tl] = (tin % T::TILES_X) * T::TW;
+            x.ibase[tl] = ((x.img0[tl] * H + x.ty0[tl]) * H + x.tx0[tl]) * KCH * 2;    // bytes
         }
-    // forward: the bias of this thread's channel, requested ahead of every other load (consumed after the loop, before the first store)
-    [[maybe_unused]] float bias_stash = 0.f;
-    if constexpr (BN) { if (tid < NT) bias_stash = a.bias[n0 + tid]; }
+        return x;
+    };
     bf16x8 wreg[WPT], breg[MT * IPT];
-    bf16x8 z8;
+    unsigned voff[MT * IPT];                                   // lane offsets of the staged units of the item whose tiles are being requested (padding: out of range)
+    auto slab_soff = [&](int n0, int st) {                     // byte offset of the slab of stage st = (chunk st / 5, kernel row st % 5), channel block n0
+        const int cc = st / KS, r = st - cc * KS;
+        return (unsigned)(((r * KS * (KCH / 16) + cc * KB) * 2 * NCH + n0) * 16);
+    };
+    auto load_w = [&](unsigned soff) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) z8[k] = (__bf16)0.f;
-    auto ldw = [&](int i, int st) {
-        const int cc = st / KS, r = st % KS;
-        wreg[i] = a.wp[(size_t)(r * KS * (KCH / 16) + cc * KB) * 2 * NCH + wbase[i]];
+        for (int i = 0; i < WPT; ++i) wreg[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wbase[i], soff, 0));
     };
-    auto stw = [&](int i, int buf) { lds_w[buf * W_UNITS + tid + i * 256] = wreg[i]; };
-    auto ldin = [&](int j, int cc) {            // raw value from a clamped address; the zero padding is selected at the LDS store
-        const int e = ebase[j];
-        breg[j] = Act<__bf16>::ld8(a.in, e >= 0 ? (size_t)(e + cc * KCB) : 0);
+    auto store_w = [&](int i0, int i1, int buf) {                // units past the slab land in the dump slots behind the slabs (no branch around a store)
+#pragma unroll
+        for (int i = i0; i < i1; ++i)
+            if (i < WPT) lds_w[(W_UNITS % 256 == 0 || tid + i * 256 < W_UNITS) ? buf * W_UNITS + tid + i * 256 : 2 * W_UNITS + tid] = wreg[i < WPT ? i : 0];
     };
-    auto stin = [&](int j) {
-        const int tl = j / IPT, i = j % IPT, q = tid + i * 256;
-        if (NQ % 256 == 0 || q < NQ) lds_a[tl * A_UNITS + (q % OCT) * PSP + q / OCT] = ebase[j] >= 0 ? breg[j] : z8;
+    auto set_voff = [&](const Item& x) {
+#pragma unroll
+        for (int tl = 0; tl < MT; ++tl)
+#pragma unroll
+            for (int i = 0; i < IPT; ++i) {
+                const int hy = ipk[i] & 255, hx = (ipk[i] >> 8) & 255, img = (ipk[i] >> 16) & 255;
+                const bool ok = (ipk[i] >> 31) && (unsigned)(x.ty0[tl] + hy - 2) < (unsigned)H && (unsigned)(x.tx0[tl] + hx - 2) < (unsigned)H && x.img0[tl] + img < a.B;
+                voff[tl * IPT + i] = ok ? (unsigned)(irel[i] + IBIAS) : BIG_OOB;
+            }
+    };
+    auto load_input = [&](const unsigned (&tsoff)[MT]) {       // tsoff[tl] = byte offset of tile tl's first pixel, chunk included
+#pragma unroll
+        for (int tl = 0; tl < MT; ++tl)
+#pragma unroll
+            for (int i = 0; i < IPT; ++i)
+                breg[tl * IPT + i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[tl * IPT + i], tsoff[tl], 0));
+    };
+    auto store_input = [&]() {
+#pragma unroll
+        for (int tl = 0; tl < MT; ++tl)
+#pragma unroll
+            for (int i = 0; i < IPT; ++i) {
+                const int q = tid + i * 256;
+                lds_a[(NQ % 256 == 0 || q < NQ) ? tl * A_UNITS + (q % OCT) * PSP + q / OCT : MT * A_UNITS + 2 * W_UNITS + tid] = breg[tl * IPT + i];
+            }
     };
 
-    // prologue: chunk 0's tiles and slab 0
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) ldw(i, 0);
-#pragma unroll
-    for (int j = 0; j < MT * IPT; ++j) ldin(j, 0);
-#pragma unroll
-    for (int j = 0; j < MT * IPT; ++j) stin(j);
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) stw(i, 0);
-    __syncthreads();
-
-    for (int st = 0; st < NST; ++st) {
-        const int r = st % KS, buf = st & 1;
-        const bool nextw = st + 1 < NST, nextin = r == KS - 1 && nextw;
+    f32x16 acc[MT][NB];
+    bf16x8 wf[2][NB], xf[2][MT];                               // two fragment sets, alternating per step (they live across stages)
+    auto ldf = [&](int set, int i, int r, int buf) {           // fragments of step i of a stage (kernel row r, slab buffer buf)
+        const int s = i / KB, kb = i % KB;
         const bf16x8* ap = lds_a + lh * PSP + aPix + r * T::HTW;
         const bf16x8* bp = lds_w + buf * W_UNITS + lh * NT + li;
-        constexpr int NSET = BIG_PF + 1;
-        bf16x8 wf[NSET][NB], xf[NSET][MT];
-        auto ldf = [&](int i, int b) {
-            const int s = i / KB, kb = i % KB;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) wf[b][nb] = bp[((s * KB + kb) * 2) * NT + nb * 32];
+        for (int nb = 0; nb < NB; ++nb) wf[set][nb] = bp[((s * KB + kb) * 2) * NT + nb * 32];
 #pragma unroll
-            for (int tl = 0; tl < MT; ++tl) xf[b][tl] = ap[tl * A_UNITS + (kb * 2) * PSP + s];
-        };
-#pragma unroll
-        for (int i = 0; i < BIG_PF; ++i) ldf(i, i % NSET);
+        for (int tl = 0; tl < MT; ++tl) xf[set][tl] = ap[tl * A_UNITS + (kb * 2) * PSP + s];
+    };
+
+    // One stage = one kernel row x KCB channels = NSTEP steps of 16 MFMAs, straight-line code (every step is ONE scheduling region: a branch
+    // inside it would cut the pinned MFMA / fragment-read interleave; what is conditional is made harmless instead — a request of a slab
+    // nobody will read, tiles written where no wave looks any more).  P0 = fragment set of step 0 (filled by the previous stage's last step),
+    // R = kernel row; gst = running stage count of the workgroup (slab buffer = gst & 1).  The slab stream runs two stages ahead:
+    //   steps 0 .. WN - 1: the slab travelling in wreg (requested a stage ago) is written into the other buffer;
+    //   step WN:           the slab at `wsoff` is requested into wreg — it is written during the NEXT stage;
+    //   R == KS - 2:       the tiles at tsoff[] are requested at step 0 (the chunk's last but one stage);
+    //   R == KS - 1:       they are written in the last step behind the barrier (chunk / item boundary; the tiles are single-buffered).
+    constexpr int WN = KB == 2 ? 5 : 2, WU = (WPT + WN - 1) / WN;
+    static_assert(WN < NSTEP - 1, "the slab request sits in front of the stage's barrier");
+    auto stage = [&](auto p0c, auto rc, int gst, unsigned wsoff, const unsigned (&tsoff)[MT]) {
+        constexpr int P0 = decltype(p0c)::value, R = decltype(rc)::value;
+        constexpr int RN = R == KS - 1 ? 0 : R + 1;
+        const int buf = gst & 1;
 #pragma unroll
         for (int i = 0; i < NSTEP; ++i) {
-            if (i + BIG_PF < NSTEP) ldf(i + BIG_PF, (i + BIG_PF) % NSET);
-            if (i == 0 && nextw) {
-#pragma unroll
-                for (int k = 0; k < WPT; ++k) ldw(k, st + 1);
-            }
-            if (i == 1 && nextin) {
-#pragma unroll
-                for (int j = 0; j < MT * IPT; ++j) ldin(j, st / KS + 1);
-            }
-            if (i >= 5 && nextw) {
-#pragma unroll
-                for (int k = 0; k < WPT / 5; ++k) stw((WPT / 5) * (i - 5) + k, buf ^ 1);
-            }
+            constexpr int NR = NB + MT;
+            const int set = (P0 + i) & 1;
+            if (i == NSTEP - 1) {
+                if (!(BIG_EXP & 1)) __syncthreads();           // slab gst + 1 visible; every wave holds its last fragments of slab gst (and of the tiles)
+                if constexpr (R == KS - 1) { if (!(BIG_EXP & 8)) store_input(); }
+                else ldf(set ^ 1, 0, RN, buf ^ 1);
+            } else ldf(set ^ 1, i + 1, R, buf);
+            if (i < WN && !(BIG_EXP & 2)) store_w(WU * i, WU * (i + 1), buf ^ 1);
+            if (i == WN && !(BIG_EXP & 4)) load_w(wsoff);
+            if (i == 0 && R == KS - 2 && !(BIG_EXP & 8)) load_input(tsoff);
 #pragma unroll
             for (int tl = 0; tl < MT; ++tl)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)          // weights as the A operand: D[channel][pixel] (channel-major, conv_epilogue.h)
-                    acc[tl][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i % NSET][nb], xf[i % NSET][tl], acc[tl][nb], 0, 0, 0);
-            if (BIG_FENCE) __builtin_amdgcn_sched_barrier(0);
-        }
-        if (nextin) {                               // chunk boundary: every wave is done with the tiles, the next chunk's take their place
-            __syncthreads();
+                for (int nb = 0; nb < NB; ++nb)                // weights as the A operand: D[channel][pixel] (channel-major, conv_epilogue.h)
+                    acc[tl][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[set][nb], xf[set][tl], acc[tl][nb], 0, 0, 0);
+            // pinned: one fragment read behind each of the first NR MFMAs, then the step's LDS writes / requests two per gap
 #pragma unroll
-            for (int j = 0; j < MT * IPT; ++j) stin(j);
+            for (int k = 0; k < 16; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (k < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x220, 2, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();                            // slab st + 1 (and the tiles) visible to all; everyone is done with slab st
-    }
-    vm_drained();
+    };
 
-    // epilogue: lane = pixel m of each tile, element v of block nb = channel 32 nb + (v & 3) + 8 (v >> 2) + 4 lh (channel-major accumulators);
-    // u[k] = channels 16 k + 8 lh .. + 7 of a 32-channel block.  Forward: bias, then ONE BatchNorm partial per workgroup and channel —
-    // (sum, M2 about the mean) of its four tiles' valid pixels, which launch_bn_fwd_finalize(.., tilesPerPartial = 4) merges
-    // (nn.BatchNorm2d train-mode statistics, vae_nets.py:75,80,85): the four tiles are added up in the lane first, so the cross-lane
-    // column sums (half_wave_colsum16) run once per channel block instead of once per accumulator tile.
-    bool validv[MT];
-    int gyv[MT], gxv[MT], ibv[MT];
+    // ---- prologue: the first item's tiles and slab 0 into LDS, its slab 1 on the way ----
+    if constexpr (BN) { for (int c = tid; c < NCH; c += 256) lds_bias[c] = a.bias[c]; }
+    Item cur = setup(grp0, n00);
+    set_voff(cur);
+    {
+        unsigned ts[MT];
 #pragma unroll
-    for (int tl = 0; tl < MT; ++tl) {
-        gyv[tl] = ty0v[tl] + prem / T::TW; gxv[tl] = tx0v[tl] + prem % T::TW; ibv[tl] = img0v[tl] + pimg;
-        validv[tl] = ibv[tl] < a.B;
+        for (int tl = 0; tl < MT; ++tl) ts[tl] = (unsigned)cur.ibase[tl];
+        load_w(slab_soff(cur.n0, 0));
+        load_input(ts);
     }
-    [[maybe_unused]] float* lds_x = reinterpret_cast<float*>(lds_w);      // [NT bias][S | Q][4 waves][NT] over the weight slabs (every wave is past the last barrier)
-    if constexpr (BN) {
-        if (tid < NT) lds_x[tid] = bias_stash;
-        __syncthreads();
+    store_input();
+    store_w(0, WPT, 0);
+    load_w(slab_soff(cur.n0, 1));
+    __syncthreads();
+    ldf(0, 0, 0, 0);
+    BT(b1);
+#ifdef BIG_TIMING
+    if (BT_ON) tpro = b1 - bt_entry;
+#endif
+
+    int gst = 0;
+    for (;;) {
+        int itn = it + G, grpn, n0n;
+        decode(itn, grpn, n0n);
+        const bool have_next = itn < numItems && grpn < numGroups;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             f32x4 bq[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(lds_x + nb * 32 + 8 * g + 4 * lh);
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (BN) bq[g] = *reinterpret_cast<const f32x4*>(lds_bias + cur.n0 + nb * 32 + 8 * g + 4 * lh);
+                else bq[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int tl = 0; tl < MT; ++tl)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) acc[tl][nb][v] += bq[v >> 2][v & 3];
+                for (int v = 0; v < 16; ++v) acc[tl][nb][v] = bq[v >> 2][v & 3];
         }
-    }
+        BT(b1);
+        // Two chunks per trip (the fragment sets alternate per step, a chunk has KS x NSTEP steps), kernel rows unrolled.  Slab st + 1 is
+        // travelling in wreg when stage st starts (requested by stage st - 1, by the previous item's last stage, or by the prologue).
+        static_assert(NCHUNK % 2 == 0, "chunks are walked in pairs");
+        for (int cp = 0; cp < NCHUNK; cp += 2) {
 #pragma unroll
-    for (int tl = 0; tl < MT; ++tl) {
+            for (int h = 0; h < 2; ++h) {
+                const int cc = cp + h;
+                const bool lastc = h == 1 && cc == NCHUNK - 1;
+                unsigned ts[MT];                               // where the next tiles come from: the next chunk of this item, or chunk 0 of the next item
+#pragma unroll
+                for (int tl = 0; tl < MT; ++tl) ts[tl] = (unsigned)(cur.ibase[tl] + (lastc ? 0 : cc + 1) * KCB * 2);
+                if (lastc && have_next) {                      // between two stages (its own block): the next item's lane offsets and tile bases
+                    const Item nx = setup(grpn, n0n);
+                    set_voff(nx);
+#pragma unroll
+                    for (int tl = 0; tl < MT; ++tl) ts[tl] = (unsigned)nx.ibase[tl];
+                }
+                [[maybe_unused]] long long b3 = 0, b4 = 0;
+                BT(b2);
+#pragma unroll
+                for (int r = 0; r < KS; ++r) {
+                    const int s2 = cc * KS + r + 2;            // the slab requested in this stage: two stages ahead, across the item boundary
+                    const bool own = s2 < NST;
+                    const unsigned wsoff = slab_soff(own || !have_next ? cur.n0 : n0n, own ? s2 : (have_next ? s2 - NST : 0));
+                    constexpr int P0v[2][5] = {{0, NSTEP & 1, 0, NSTEP & 1, 0}, {NSTEP & 1, 0, NSTEP & 1, 0, NSTEP & 1}};
+                    if (h == 0) {
+                        if (r == 0) stage(std::integral_constant<int, P0v[0][0]>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts);
+                        if (r == 1) stage(std::integral_constant<int, P0v[0][1]>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts);
+                        if (r == 2) stage(std::integral_constant<int, P0v[0][2]>{}, std::integral_constant<int, 2>{}, gst, wsoff, ts);
+                        if (r == 3) stage(std::integral_constant<int, P0v[0][3]>{}, std::integral_constant<int, 3>{}, gst, wsoff, ts);
+                        if (r == 4) stage(std::integral_constant<int, P0v[0][4]>{}, std::integral_constant<int, 4>{}, gst, wsoff, ts);
+                    } else {
+                        if (r == 0) stage(std::integral_constant<int, P0v[1][0]>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts);
+                        if (r == 1) stage(std::integral_constant<int, P0v[1][1]>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts);
+                        if (r == 2) stage(std::integral_constant<int, P0v[1][2]>{}, std::integral_constant<int, 2>{}, gst, wsoff, ts);
+                        if (r == 3) stage(std::integral_constant<int, P0v[1][3]>{}, std::integral_constant<int, 3>{}, gst, wsoff, ts);
+                        if (r == 4) stage(std::integral_constant<int, P0v[1][4]>{}, std::integral_constant<int, 4>{}, gst, wsoff, ts);
+                    }
+                    ++gst;
+                }
+                BT(b3);
+                __syncthreads();                               // chunk / item boundary: the new tiles are visible behind this barrier
+                if (!lastc) ldf(h == 0 ? (NSTEP & 1) : 0, 0, 0, gst & 1);
+                BT(b4);
+#ifdef BIG_TIMING
+                if (BT_ON) { tstage += b3 - b2; tclose += b4 - b3; }
+#endif
+            }
+        }
+        BT(b1);
+
+        // ---- epilogue: lane = pixel m of each tile, element v of block nb = channel 32 nb + (v & 3) + 8 (v >> 2) + 4 lh (channel-major accumulators);
+        // u[k] = channels 16 k + 8 lh .. + 7 of a 32-channel block.  Forward: ONE BatchNorm partial per item and channel — (sum, M2 about the
+        // mean) of its MT tiles' valid pixels, which launch_bn_fwd_finalize(.., tilesPerPartial = MT) merges (nn.BatchNorm2d train-mode
+        // statistics, vae_nets.py:75,80,85): the tiles are added up in the lane first, so the cross-lane column sums (half_wave_colsum16)
+        // run once per channel block instead of once per accumulator tile.
+        bool validv[MT];
+        bool allv = true;
+#pragma unroll
+        for (int tl = 0; tl < MT; ++tl) { validv[tl] = cur.img0[tl] + pimg < a.B; allv = allv && (cur.img0[tl] + T::IMGS <= a.B); }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            bf16x8 u[2];
-            cm_pack_units(acc[tl][nb], u);
-            const size_t base = ((size_t)(ibv[tl] * H + gyv[tl]) * H + gxv[tl]) * NCH + n0 + nb * 32 + 8 * lh;
-            if (validv[tl]) { Act<__bf16>::st8(a.out, base, u[0]); Act<__bf16>::st8(a.out, base + 16, u[1]); }
+            [[maybe_unused]] float sv[16], qv[16];
+            if constexpr (BN) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) { sv[v] = 0.f; qv[v] = 0.f; }
+            }
+#pragma unroll
+            for (int tl = 0; tl < MT; ++tl) {
+                // one accumulator tile at a time: the opaque statement pins the tile in its AGPRs until here — without it the compiler copies
+                // all 256 accumulators out in front of the first store and spills what lives across the epilogue to make room
+                asm volatile("" : "+a"(acc[tl][nb]));
+                const f32x16 c = acc[tl][nb];
+                bf16x8 u[2];
+                cm_pack_units(c, u);
+                const unsigned off = validv[tl] ? ((unsigned)(cur.ibase[tl] / (KCH * 2) + orel) * NCH + cur.n0 + nb * 32 + 8 * lh) * 2u : BIG_OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, u[0]), rs_out, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, u[1]), rs_out, off + 32u, 0, 0);
+                if constexpr (BN) {
+                    if (allv) {                                // wave-uniform: every pixel of the item exists
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) { sv[v] += c[v]; qv[v] = fmaf(c[v], c[v], qv[v]); }
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) { const float x = validv[tl] ? c[v] : 0.f; sv[v] += x; qv[v] = fmaf(x, x, qv[v]); }
+                    }
+                }
+            }
+            if constexpr (BN) {
+                const int e16 = li >> 1, chE = (e16 & 3) + 8 * (e16 >> 2) + 4 * lh;       // the element half_wave_colsum16 leaves in this lane
+                const float S = half_wave_colsum16(sv), Q = half_wave_colsum16(qv);
+                if ((lane & 1) == 0) { red[(0 * 4 + wave) * NT + nb * 32 + chE] = S; red[(1 * 4 + wave) * NT + nb * 32 + chE] = Q; }
+            }
         }
+        if constexpr (BN) {
+            __syncthreads();
+            {
+                const int c = tid < NT ? tid : 0;
+                float S = 0.f, Q = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { S += red[(0 * 4 + w) * NT + c]; Q += red[(1 * 4 + w) * NT + c]; }
+                int cnt = 0;
+#pragma unroll
+                for (int tl = 0; tl < MT; ++tl) { int ni = a.B - cur.img0[tl]; ni = ni < 0 ? 0 : (ni > T::IMGS ? T::IMGS : ni); cnt += ni * T::TH * T::TW; }
+                const double m2 = cnt > 0 ? (double)Q - (double)S * (double)S / (double)cnt : 0.0;
+                const unsigned o = tid < NT ? (unsigned)(cur.grp * NCH + cur.n0 + c) * 4u : BIG_OOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, S), rs_bn, o, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(m2 > 0.0 ? m2 : 0.0)), rs_bn,
+                                                      tid < NT ? o + (unsigned)(numGroups * NCH) * 4u : BIG_OOB, 0, 0);
+            }
+        }
+        BT(b2);
+#ifdef BIG_TIMING
+        if (BT_ON) { tepi += b2 - b1; ++nit; }
+#endif
+        if (!have_next) break;
+        cur = setup(grpn, n0n); it = itn;
+        set_voff(cur);                                         // recomputed (not kept) across the epilogue: ~100 VALU per item for 12-16 registers
+        ldf(0, 0, 0, gst & 1);                                 // first fragments of the next item (its tiles and slab 0 are in LDS: the last stage's barriers)
     }
-    if constexpr (BN) {
-        float* red = lds_x + NT;
-        const int e16 = li >> 1, chE = (e16 & 3) + 8 * (e16 >> 2) + 4 * lh;       // the element half_wave_colsum16 leaves in this lane
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            float sv[16], qv[16];
-#pragma unroll
-            for (int v = 0; v < 16; ++v) { sv[v] = 0.f; qv[v] = 0.f; }
-#pragma unroll
-            for (int tl = 0; tl < MT; ++tl)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) { const float x = validv[tl] ? acc[tl][nb][v] : 0.f; sv[v] += x; qv[v] = fmaf(x, x, qv[v]); }
-            const float S = half_wave_colsum16(sv), Q = half_wave_colsum16(qv);
-            if ((lane & 1) == 0) { red[(0 * 4 + wave) * NT + nb * 32 + chE] = S; red[(1 * 4 + wave) * NT + nb * 32 + chE] = Q; }
-        }
-        __syncthreads();
-        if (tid < NT) {
-            float S = 0.f, Q = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) { S += red[(0 * 4 + w) * NT + tid]; Q += red[(1 * 4 + w) * NT + tid]; }
-            int cnt = 0;
-#pragma unroll
-            for (int tl = 0; tl < MT; ++tl) { int ni = a.B - img0v[tl]; ni = ni < 0 ? 0 : (ni > T::IMGS ? T::IMGS : ni); cnt += ni * T::TH * T::TW; }
-            const int numBig = gridDim.x, big = mt0 / MT;
-            const double m2 = cnt > 0 ? (double)Q - (double)S * (double)S / (double)cnt : 0.0;
-            a.bnpart[(size_t)big * NCH + n0 + tid] = S;
-            a.bnpart[((size_t)numBig + big) * NCH + n0 + tid] = (float)(m2 > 0.0 ? m2 : 0.0);
-        }
+#ifdef BIG_TIMING
+    if (BT_ON && (blockIdx.x & 15) == 0 && blockIdx.x < 256 && tid == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        const long long e = clock64();
+        long long* o = big_dbg + (blockIdx.x >> 4) * 12;
+        o[0] = nit; o[1] = tpro; o[2] = tstage; o[3] = tclose; o[4] = tepi; o[5] = e - bt_entry;
+        o[6] = (long long)wall_clock64() - brt0; o[7] = NST; o[8] = brt0; o[9] = (long long)wall_clock64();
     }
+#endif
 }
 
-template <int KCH, int NCH, int H, int NT, int EPI>
+template <int KCH, int NCH, int H, int NT, int MT, int KB, int EPI>
 static int run_big(const ConvBf16Args& a, hipStream_t st) {
     using T = Tile<H>;
-    constexpr int SMEM = (4 * 4 * Bf16Geom<H, 4>::PSP + 2 * 5 * 2 * 2 * NT) * 16;
+    constexpr int OCT = 2 * KB;
+    constexpr int NY = NCH / NT;
+    constexpr int SMEM = (MT * OCT * Bf16Geom<H, OCT>::PSP + 2 * 5 * KB * 2 * NT + 256) * 16 + (EPI == EPI_BIAS_BNSTAT ? (NCH + 2 * 4 * NT) * 4 : 0);
     static_assert(SMEM <= 160 * 1024, "LDS");
-    auto kern = conv5x5_bf16_big_kernel<KCH, NCH, H, NT, EPI>;
+    // 32-bit byte offsets and buffer descriptors inside: larger tensors take the per-tile kernels (size_t addressing)
+    if ((size_t)a.B * H * H * KCH * 2 >= (1ull << 31) || (size_t)a.B * H * H * NCH * 2 >= (1ull << 31)) return -100;
+    auto kern = conv5x5_bf16_big_kernel<KCH, NCH, H, NT, MT, KB, EPI>;
     static DeviceOnce once;
     { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(kern), SMEM); if (rc) return rc; }
-    dim3 grid(cdiv(cdiv(a.B, T::IMGS) * T::TILES_PER_IMG, 4), NCH / NT);
+    const int numTiles = cdiv(a.B, T::IMGS) * T::TILES_PER_IMG, numGroups = cdiv(numTiles, MT);
+    const int numItems = 8 * cdiv(numGroups, 8) * NY;
+    // CVAE_BIG_MAXWG (tests): cap the persistent grid so that small batches walk several items per workgroup
+    static const int maxwg = [] { const char* e = getenv("CVAE_BIG_MAXWG"); return e ? atoi(e) : 0; }();
+    int G = cvae_num_cus();
+    if (maxwg > 0 && G > maxwg) G = maxwg;
+    G -= G % 8;
+    if (G < 8) G = 8;
+    if (G > numItems) G = numItems;
     cvae_probe_begin(st);
-    hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, st, a);
+    hipLaunchKernelGGL(kern, dim3(G), dim3(256), SMEM, st, a, numGroups);
     cvae_probe_end(st);
     CVAE_CHECK_LAUNCH();
     return 0;
 }
 
-// which layers this file serves.  Input gradients: mask bit 0 = the 128-channel one (E4), bit 1 = the 64-channel one (E3).  Forward (bias +
-// BatchNorm partials of FOUR tiles each — the caller must tell launch_bn_fwd_finalize): mask bit 0 = E3 (64 -> 128), bit 1 = E4 (128 -> 256)
+// Which layers this file serves, by mask bit: input gradients — bit 0 = E4 (256 -> 128, 4 x 4 tile), bit 1 = E3 (128 -> 64, 8 x 2 tile);
+// forward (bias + ONE BatchNorm partial per item of conv_bf16_big_tiles(..) tiles — the caller must tell launch_bn_fwd_finalize) —
+// bit 0 = E3 (64 -> 128), bit 1 = E4 (128 -> 256), both on the 4 x 4 tile.
 bool conv_bf16_big_has(int layer, int width, bool dgrad, int mask) {
     if (width != 64 && width != 128) return false;
     if (dgrad) return (layer == 3 && (mask & 1)) || (layer == 2 && (mask & 2));
     return (layer == 2 && (mask & 1)) || (layer == 3 && (mask & 2));
 }
-// returns -100 when the layer has no instantiation
+int conv_bf16_big_tiles(int layer, int width, bool dgrad) { (void)width; return (dgrad && layer == 2) ? 8 : 4; }
+// returns -100 when the layer has no instantiation (or the tensors are too large for its 32-bit offsets)
 int launch_conv_bf16_big(int layer, int width, bool dgrad, int mask, const ConvBf16Args& a, hipStream_t st) {
     if (!conv_bf16_big_has(layer, width, dgrad, mask)) return -100;
     if (dgrad) {
-        if (width == 64 && layer == 3) return run_big<256, 128, 8, 128, EPI_PLAIN>(a, st);
-        if (width == 64 && layer == 2) return run_big<128, 64, 16, 64, EPI_PLAIN>(a, st);
-        if (width == 128 && layer == 3) return run_big<256, 128, 16, 128, EPI_PLAIN>(a, st);
-        if (width == 128 && layer == 2) return run_big<128, 64, 32, 64, EPI_PLAIN>(a, st);
+        if (width == 64 && layer == 3) return run_big<256, 128, 8, 128, 4, 1, EPI_PLAIN>(a, st);
+        if (width == 64 && layer == 2) return run_big<128, 64, 16, 64, 8, 1, EPI_PLAIN>(a, st);
+        if (width == 128 && layer == 3) return run_big<256, 128, 16, 128, 4, 1, EPI_PLAIN>(a, st);
+        if (width == 128 && layer == 2) return run_big<128, 64, 32, 64, 8, 1, EPI_PLAIN>(a, st);
     } else {
-        if (width == 64 && layer == 2) return run_big<64, 128, 16, 128, EPI_BIAS_BNSTAT>(a, st);
-        if (width == 64 && layer == 3) return run_big<128, 256, 8, 128, EPI_BIAS_BNSTAT>(a, st);
-        if (width == 128 && layer == 2) return run_big<64, 128, 32, 128, EPI_BIAS_BNSTAT>(a, st);
-        if (width == 128 && layer == 3) return run_big<128, 256, 16, 128, EPI_BIAS_BNSTAT>(a, st);
+        if (width == 64 && layer == 2) return run_big<64, 128, 16, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);
+        if (width == 64 && layer == 3) return run_big<128, 256, 8, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);
+        if (width == 128 && layer == 2) return run_big<64, 128, 32, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);
+        if (width == 128 && layer == 3) return run_big<128, 256, 16, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);
     }
     return -100;
 }

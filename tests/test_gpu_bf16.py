@@ -298,18 +298,19 @@ def test_bf16x6_step_at_128x128_frames_meets_the_fp32_parity_bar():
 
 
 def test_big_tile_conv_kernels_every_instantiation_exact_on_their_stored_operands():
-    """conv_bf16_big.hip (round 4: 4 x 4 wave tile, staging inside the MFMA stream) runs E4's forward and input gradient by
-    default; its E3 instantiations (forward, and the 64-channel input gradient) are compiled but off (slower).  The switch
-    (CVAE_BF16_BIG) is read once per process, so a child process runs the stored-operand test of this file — every conv
-    output recomputed on the CPU from the bf16 operands the kernels consumed, B = 8 and the ragged B = 5 — with all four
-    instantiations on (bits 2..5), including the forward ones' four-tile BatchNorm partials."""
+    """conv_bf16_big.hip (rounds 4-5: PERSISTENT workgroups on a 16-accumulator-tile wave tile, everything inside the MFMA stream) runs
+    E3 / E4 forward and input gradient by default.  At test batch sizes every item would get its own workgroup, so the item loop — next
+    item's tiles and slabs requested across the epilogue, fragment sets and slab buffers carried over — would never run: a child process
+    caps the grid at 8 workgroups (CVAE_BIG_MAXWG, read once per process) and runs the stored-operand test of this file — every conv
+    output recomputed on the CPU from the bf16 operands the kernels consumed; B = 8, the ragged B = 5, and B = 37 (74 / 19 tiles: several
+    items per workgroup, uneven ends, partial groups, the forward kernels' four-tile BatchNorm partials)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CVAE_BF16_BIG="60")
+    env = dict(os.environ, CVAE_BF16_BIG="60", CVAE_BIG_MAXWG="8")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_bf16.py"), "-m", "gpu", "-q", "-x",
-                        "-k", "kernels_exact_on_their_stored_operands or two_pass_e1"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+                        "-k", "kernels_exact_on_their_stored_operands or two_pass_e1"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
 
@@ -434,7 +435,7 @@ def test_bf16_step_never_stores_y0_unless_a_block0_gamma_is_tiny(B, vec_bound, t
             assert gk[0] == 0 and rk[0] == 0          # gamma = 0, beta = 0: the channel's output is 0 everywhere and ReLU'(0) = 0 blocks its gradient
 
 
-@pytest.mark.parametrize("B", [8, 5])          # 5: ragged tile counts (the persistent D4 / MS-SSIM / E1 loops end unevenly)
+@pytest.mark.parametrize("B", [8, 5, 37])      # 5, 37: ragged tile counts (the persistent D4 / MS-SSIM / E1 / conv loops end unevenly)
 def test_bf16_kernels_exact_on_their_stored_operands(B):
     """Layout / indexing check of every bf16-mode contraction, independent of the bf16 rounding noise: after one
     bf16 step the workspace holds the bf16 activations and activation gradients the kernels actually consumed.

@@ -861,10 +861,10 @@ int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, c
                          float* bnpart, float* ws, hipStream_t st, int* tilesPerPartial) {
     ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0, ns >= 3 ? 3 : 1), bias, out, bnpart, B, 0, nullptr, ns >= 3 ? pack_units(layer) : 0, ns == 6 ? 6 : 9};
     if (tilesPerPartial) *tilesPerPartial = 1;
-    // CVAE_BF16_BIG bits 4 / 5: conv_bf16_big.hip forward (E3 / E4) — persistent workgroups on a 4 x 4 wave tile
+    // CVAE_BF16_BIG bits 4 / 5 / 6: conv_bf16_big.hip forward (E3 / E4 / E2) — persistent workgroups on a 16-accumulator wave tile
     const int big = bf16_big_mask();
-    if (ns == 1 && (big & 48)) {
-        const int rc = launch_conv_bf16_big(layer, width, false, (big >> 4) & 3, a, st);
+    if (ns == 1 && (big & 112)) {
+        const int rc = launch_conv_bf16_big(layer, width, false, (big >> 4) & 7, a, st);
         if (rc != -100) { if (tilesPerPartial) *tilesPerPartial = conv_bf16_big_tiles(layer, width, false); return rc; }
     }
     if (ns == 1 && use_ps_kernel(layer, false)) { const int rc = launch_conv_bf16_ps(layer, width, false, a, st); if (rc != -100) return rc; }

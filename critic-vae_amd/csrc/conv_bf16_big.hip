@@ -40,8 +40,10 @@ extern "C" int cvae_big_dbg_read(long long* out) { return (int)hipMemcpyFromSymb
 #define BT(v)
 #endif
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Timing experiments (WRONG results, never shipped; profiles/experiments/variant.sh -DBIG_EXP=n): what the stage loop pays for each of its
-// parts.  bit 0: no barrier in front of a stage's last step;  bit 1: no slab writes;  bit 2: no slab requests;  bit 3: no tile requests / writes
+// parts.  bit 0: no barrier in front of a stage's last step;  bit 1: no slab writes;  bit 2: no slab requests;  bit 3: no tile requests / writes;
+// bit 4: no BatchNorm sums in the epilogue;  bit 5: no column sums / partial rows;  bit 6: no output stores;  bit 7: workgroups start staggered
 #ifndef BIG_EXP
 #define BIG_EXP 0
 #endif
@@ -65,8 +67,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);       // [tile][octet][halo pixel]
     bf16x8* lds_w = lds_a + MT * A_UNITS;                      // [buffer][tap][kb][half][n]
-    [[maybe_unused]] float* lds_bias = reinterpret_cast<float*>(lds_w + 2 * W_UNITS + 256); // [NCH] (forward only), behind 256 dump units for the staging stores of units that do not exist
-    [[maybe_unused]] float* red = lds_bias + NCH;                                          // [S | Q][wave][NT]
+    // behind the slabs: 256 dump units (4 KB) for the staging stores of units that do not exist, then (forward) the [S | Q][wave][NT] rows of the
+    // BatchNorm partials (they live from an item's epilogue until the next item's first stage barrier: not in the dump area) and [NCH] bias
+    [[maybe_unused]] float* red = reinterpret_cast<float*>(lds_w + 2 * W_UNITS + 256);
+    [[maybe_unused]] float* lds_bias = red + 2 * 4 * NT;
+    bf16x8* const lds_patch = lds_w + 2 * W_UNITS + 256 + (BN ? (2 * 4 * NT + NCH) / 4 : 0);              // [wave][32 rows][8 + 1] units: the epilogue's transposing patch
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     [[maybe_unused]] long long b0 = 0, b1 = 0, b2 = 0, tpro = 0, tstage = 0, tclose = 0, tepi = 0, nit = 0;
@@ -87,7 +92,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int m = wave * 32 + lane_pix<H, true>(li);           // pixel (of the 128 of a tile) behind MFMA column li of this wave
     const int pimg = m / (T::TH * T::TW), prem = m % (T::TH * T::TW);
     const int aPix = pimg * T::HPI + (prem / T::TW) * T::HTW + (prem % T::TW);
-    const int orel = (pimg * H + prem / T::TW) * H + prem % T::TW;          // output pixel relative to the tile's first pixel
+    // epilogue patch of this wave: [32 pixel rows][RU0 = 8 units of 8 channels + 1 pad] = the wave's pixels x 64 channels (two channel blocks: one
+    // 128-byte line per pixel); lane (li, lh) writes units 4 nb' + 2 k + lh of row li, and reads back unit (lane % 8) of rows (lane / 8) + 8 k:
+    // orow[k] = byte offset of that row's pixel from the tile's first pixel, pcol = of the unit
+    constexpr int HB = 2, NH = NB / HB, RU0 = HB * 4, PRS = RU0 + 1, PPI = 64 / RU0, PIT = 32 / PPI;
+    static_assert(NB % HB == 0, "the epilogue walks the channel blocks in pairs");
+    bf16x8* const patch = lds_patch + wave * (32 * PRS);
+    bf16x8* const patch_w = patch + li * PRS + lh;
+    const bf16x8* const patch_r = patch + (lane / RU0) * PRS + lane % RU0;
+    const unsigned pcol = (unsigned)(lane % RU0) * 16u;
+    unsigned orow[PIT];
+#pragma unroll
+    for (int k = 0; k < PIT; ++k) {
+        const int mr = wave * 32 + lane_pix<H, true>(lane / RU0 + PPI * k), ir = mr / (T::TH * T::TW), rr = mr % (T::TH * T::TW);
+        orow[k] = (unsigned)(((ir * H + rr / T::TW) * H + rr % T::TW) * NCH * 2);
+    }
     constexpr int WPT = (W_UNITS + 255) / 256;
     unsigned wbase[WPT];                                       // byte offset inside a stage's slab of the packed weights (without n0)
 #pragma unroll
@@ -189,7 +208,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // R = kernel row; gst = running stage count of the workgroup (slab buffer = gst & 1).  The slab stream runs two stages ahead:
     //   steps 0 .. WN - 1: the slab travelling in wreg (requested a stage ago) is written into the other buffer;
     //   step WN:           the slab at `wsoff` is requested into wreg — it is written during the NEXT stage;
-    //   R == KS - 2:       the tiles at tsoff[] are requested at step 0 (the chunk's last but one stage);
+    //   R == KS - 3:       the tiles at tsoff[] are requested behind that stage's slab request — vmcnt retires in issue order, so whatever is
+    //                      consumed first must be requested first: the two slabs requested after the tiles are written (stage starts of R = KS - 1
+    //                      and of the next chunk) 7 and 12 steps later, by when the tiles have landed; requested at step 0 of stage KS - 2 the
+    //                      tiles sat in front of a slab that is needed 5 steps later (215 cycles per stage, profiles/r05_c_big_ablation.txt);
     //   R == KS - 1:       they are written in the last step behind the barrier (chunk / item boundary; the tiles are single-buffered).
     constexpr int WN = KB == 2 ? 5 : 2, WU = (WPT + WN - 1) / WN;
     static_assert(WN < NSTEP - 1, "the slab request sits in front of the stage's barrier");
@@ -208,7 +230,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             } else ldf(set ^ 1, i + 1, R, buf);
             if (i < WN && !(BIG_EXP & 2)) store_w(WU * i, WU * (i + 1), buf ^ 1);
             if (i == WN && !(BIG_EXP & 4)) load_w(wsoff);
-            if (i == 0 && R == KS - 2 && !(BIG_EXP & 8)) load_input(tsoff);
+            if (i == WN + 1 && R == KS - 3 && !(BIG_EXP & 8)) load_input(tsoff);
 #pragma unroll
             for (int tl = 0; tl < MT; ++tl)
 #pragma unroll
@@ -225,6 +247,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
 
+    // Forward: the finished item's per-wave rows [S | Q][wave][NT] -> ONE (sum, M2) partial per channel.  Deferred: a barrier of its own in the
+    // epilogue waited for the slowest wave's store issue (8.5 k of the 16 k-cycle epilogue, profiles/r05_d_big_epilogue_ablation.txt); the rows are
+    // combined behind the first stage barrier of the NEXT item instead (or behind one barrier at the very end), no branch: without a finished item
+    // the two stores carry an out-of-range offset.
+    [[maybe_unused]] int pd_grp = 0, pd_n0 = 0, pd_cnt = 0;
+    [[maybe_unused]] bool have_pd = false;
+    auto bn_combine = [&]() {
+        if constexpr (BN && !(BIG_EXP & 32)) {
+            const int c = tid < NT ? tid : 0;
+            float S = 0.f, Q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { S += red[(0 * 4 + w) * NT + c]; Q += red[(1 * 4 + w) * NT + c]; }
+            // M2 = Q - S^2 / n in double; a full item's n is a constant (no double-precision division on the path every item takes)
+            const double rn = pd_cnt == MT * 128 ? 1.0 / (MT * 128) : (pd_cnt > 0 ? 1.0 / (double)pd_cnt : 0.0);
+            const double m2 = (double)Q - (double)S * (double)S * rn;
+            const bool ok = have_pd && tid < NT;
+            const unsigned o = (unsigned)(pd_grp * NCH + pd_n0 + c) * 4u;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, S), rs_bn, ok ? o : BIG_OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(m2 > 0.0 ? m2 : 0.0)), rs_bn,
+                                                  ok ? o + (unsigned)(numGroups * NCH) * 4u : BIG_OOB, 0, 0);
+        }
+    };
+    if (BIG_EXP & 128) { for (int k = 0; k < ((int)(blockIdx.x >> 3) & 7); ++k) __builtin_amdgcn_s_sleep(30); }      // 8 phases, ~1.9 k cycles apart
     // ---- prologue: the first item's tiles and slab 0 into LDS, its slab 1 on the way ----
     if constexpr (BN) { for (int c = tid; c < NCH; c += 256) lds_bias[c] = a.bias[c]; }
     Item cur = setup(grp0, n00);
@@ -304,6 +349,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         if (r == 4) stage(std::integral_constant<int, P0v[1][4]>{}, std::integral_constant<int, 4>{}, gst, wsoff, ts);
                     }
                     ++gst;
+                    if (BN && h == 0 && r == 0 && cp == 0) bn_combine();      // behind stage 0's barrier: the previous item's rows are complete
                 }
                 BT(b3);
                 __syncthreads();                               // chunk / item boundary: the new tiles are visible behind this barrier
@@ -325,56 +371,89 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         bool allv = true;
 #pragma unroll
         for (int tl = 0; tl < MT; ++tl) { validv[tl] = cur.img0[tl] + pimg < a.B; allv = allv && (cur.img0[tl] + T::IMGS <= a.B); }
+        // Two channel blocks (64 channels = one 128-byte line per pixel) at a time, tile by tile: the wave's 32 pixels x 64 channels go through its
+        // private LDS patch (rows = pixels, 16-byte units of 8 channels, one pad unit per row: conflict-free ds_write_b128) and leave as WHOLE lines —
+        // 8 consecutive lanes store the 128 contiguous bytes of one pixel, so a store instruction touches 8 full lines.  Straight from the accumulator
+        // layout a lane stores 16 bytes of ITS pixel: 64 lines per instruction, and the 16-tile epilogue was bound by exactly that (9.5 k cycles for
+        // 128 KB per CU, profiles/r05_b_big_timing_persistent.txt).  A wave's LDS operations execute in order: no wait between the patch's writes
+        // and reads.  Forward: the BatchNorm sums of the pair's 2 x 16 channels per lane are taken from the same register copies.
+        if constexpr (BN) {
+            // ragged end only (wave-uniform, rare): the accumulators of tiles that do not exist hold the bias — zeroed, so that the sums below need no mask
+            if (!allv) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            [[maybe_unused]] float sv[16], qv[16];
-            if constexpr (BN) {
+                for (int tl = 0; tl < MT; ++tl)
+                    if (!validv[tl]) {
 #pragma unroll
-                for (int v = 0; v < 16; ++v) { sv[v] = 0.f; qv[v] = 0.f; }
-            }
+                        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int tl = 0; tl < MT; ++tl) {
-                // one accumulator tile at a time: the opaque statement pins the tile in its AGPRs until here — without it the compiler copies
-                // all 256 accumulators out in front of the first store and spills what lives across the epilogue to make room
-                asm volatile("" : "+a"(acc[tl][nb]));
-                const f32x16 c = acc[tl][nb];
-                bf16x8 u[2];
-                cm_pack_units(c, u);
-                const unsigned off = validv[tl] ? ((unsigned)(cur.ibase[tl] / (KCH * 2) + orel) * NCH + cur.n0 + nb * 32 + 8 * lh) * 2u : BIG_OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, u[0]), rs_out, off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, u[1]), rs_out, off + 32u, 0, 0);
-                if constexpr (BN) {
-                    if (allv) {                                // wave-uniform: every pixel of the item exists
-#pragma unroll
-                        for (int v = 0; v < 16; ++v) { sv[v] += c[v]; qv[v] = fmaf(c[v], c[v], qv[v]); }
-                    } else {
-#pragma unroll
-                        for (int v = 0; v < 16; ++v) { const float x = validv[tl] ? c[v] : 0.f; sv[v] += x; qv[v] = fmaf(x, x, qv[v]); }
+                            for (int v = 0; v < 16; ++v) acc[tl][nb][v] = 0.f;
                     }
-                }
-            }
-            if constexpr (BN) {
-                const int e16 = li >> 1, chE = (e16 & 3) + 8 * (e16 >> 2) + 4 * lh;       // the element half_wave_colsum16 leaves in this lane
-                const float S = half_wave_colsum16(sv), Q = half_wave_colsum16(qv);
-                if ((lane & 1) == 0) { red[(0 * 4 + wave) * NT + nb * 32 + chE] = S; red[(1 * 4 + wave) * NT + nb * 32 + chE] = Q; }
             }
         }
-        if constexpr (BN) {
-            __syncthreads();
-            {
-                const int c = tid < NT ? tid : 0;
-                float S = 0.f, Q = 0.f;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) { S += red[(0 * 4 + w) * NT + c]; Q += red[(1 * 4 + w) * NT + c]; }
-                int cnt = 0;
+        for (int hp = 0; hp < NH; ++hp) {
+            [[maybe_unused]] f32x2 sv[HB][8], qv[HB][8];       // packed pairs: v_pk_add_f32 / v_pk_fma_f32 — two channels per instruction
+            if constexpr (BN) {
 #pragma unroll
-                for (int tl = 0; tl < MT; ++tl) { int ni = a.B - cur.img0[tl]; ni = ni < 0 ? 0 : (ni > T::IMGS ? T::IMGS : ni); cnt += ni * T::TH * T::TW; }
-                const double m2 = cnt > 0 ? (double)Q - (double)S * (double)S / (double)cnt : 0.0;
-                const unsigned o = tid < NT ? (unsigned)(cur.grp * NCH + cur.n0 + c) * 4u : BIG_OOB;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, S), rs_bn, o, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(m2 > 0.0 ? m2 : 0.0)), rs_bn,
-                                                      tid < NT ? o + (unsigned)(numGroups * NCH) * 4u : BIG_OOB, 0, 0);
+                for (int j = 0; j < HB; ++j)
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) { sv[j][v] = f32x2{0.f, 0.f}; qv[j][v] = f32x2{0.f, 0.f}; }
             }
+            bf16x8 rows[PIT];                                  // the previous tile's rows, stored one tile later: the patch reads travel under the next tile's VALU work
+            unsigned rbase = BIG_OOB;
+            auto flush_rows = [&]() {
+#pragma unroll
+                for (int k = 0; k < PIT; ++k)
+                    if (!(BIG_EXP & 64)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, rows[k]), rs_out, rbase == BIG_OOB ? BIG_OOB : rbase + orow[k], 0, 0);
+            };
+#pragma unroll
+            for (int tl = 0; tl < MT; ++tl) {
+#pragma unroll
+                for (int j = 0; j < HB; ++j) {
+                    const int nb = hp * HB + j;
+                    // one accumulator tile at a time: the opaque statement pins the tile in its AGPRs until here — without it the compiler copies
+                    // all 256 accumulators out in front of the first store and spills what lives across the epilogue to make room
+                    asm volatile("" : "+a"(acc[tl][nb]));
+                    const f32x16 c = acc[tl][nb];
+                    bf16x8 u[2];
+                    cm_pack_units(c, u);
+                    patch_w[4 * j] = u[0];
+                    patch_w[4 * j + 2] = u[1];
+                    if constexpr (BN && !(BIG_EXP & 16)) {
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) {
+                            const f32x2 x = f32x2{c[2 * v], c[2 * v + 1]};
+                            sv[j][v] += x;
+                            qv[j][v] = __builtin_elementwise_fma(x, x, qv[j][v]);
+                        }
+                    }
+                }
+                asm volatile("" ::: "memory");
+                if (tl > 0) flush_rows();
+#pragma unroll
+                for (int k = 0; k < PIT; ++k) rows[k] = patch_r[k * PPI * PRS];
+                rbase = validv[tl] ? ((unsigned)(cur.ibase[tl] / (KCH * 2)) * NCH + cur.n0 + hp * HB * 32) * 2u + pcol : BIG_OOB;
+                asm volatile("" ::: "memory");
+            }
+            if constexpr (BN && !(BIG_EXP & 32)) {
+#pragma unroll
+                for (int j = 0; j < HB; ++j) {
+                    const int nb = hp * HB + j;
+                    const int e16 = li >> 1, chE = (e16 & 3) + 8 * (e16 >> 2) + 4 * lh;   // the element half_wave_colsum16 leaves in this lane
+                    float s1[16], q1[16];
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) { s1[2 * v] = sv[j][v][0]; s1[2 * v + 1] = sv[j][v][1]; q1[2 * v] = qv[j][v][0]; q1[2 * v + 1] = qv[j][v][1]; }
+                    const float S = half_wave_colsum16(s1), Q = half_wave_colsum16(q1);
+                    if ((lane & 1) == 0) { red[(0 * 4 + wave) * NT + nb * 32 + chE] = S; red[(1 * 4 + wave) * NT + nb * 32 + chE] = Q; }
+                }
+            }
+            flush_rows();                                      // the pair's last tile (behind the column sums: its patch reads have long landed)
+        }
+        if constexpr (BN) {                                    // the four waves' rows meet behind the NEXT barrier the workgroup passes anyway (bn_combine)
+            pd_cnt = 0;
+#pragma unroll
+            for (int tl = 0; tl < MT; ++tl) { int ni = a.B - cur.img0[tl]; ni = ni < 0 ? 0 : (ni > T::IMGS ? T::IMGS : ni); pd_cnt += ni * T::TH * T::TW; }
+            pd_grp = cur.grp; pd_n0 = cur.n0; have_pd = true;
         }
         BT(b2);
 #ifdef BIG_TIMING
@@ -385,6 +464,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         set_voff(cur);                                         // recomputed (not kept) across the epilogue: ~100 VALU per item for 12-16 registers
         ldf(0, 0, 0, gst & 1);                                 // first fragments of the next item (its tiles and slab 0 are in LDS: the last stage's barriers)
     }
+    if constexpr (BN) { __syncthreads(); bn_combine(); }       // the last item's rows
 #ifdef BIG_TIMING
     if (BT_ON && (blockIdx.x & 15) == 0 && blockIdx.x < 256 && tid == 0) {
         __builtin_amdgcn_sched_barrier(0);
@@ -401,7 +481,7 @@ static int run_big(const ConvBf16Args& a, hipStream_t st) {
     using T = Tile<H>;
     constexpr int OCT = 2 * KB;
     constexpr int NY = NCH / NT;
-    constexpr int SMEM = (MT * OCT * Bf16Geom<H, OCT>::PSP + 2 * 5 * KB * 2 * NT + 256) * 16 + (EPI == EPI_BIAS_BNSTAT ? (NCH + 2 * 4 * NT) * 4 : 0);
+    constexpr int SMEM = (MT * OCT * Bf16Geom<H, OCT>::PSP + 2 * 5 * KB * 2 * NT + 256 + 4 * 32 * 9) * 16 + (EPI == EPI_BIAS_BNSTAT ? (2 * 4 * NT + NCH) * 4 : 0);
     static_assert(SMEM <= 160 * 1024, "LDS");
     // 32-bit byte offsets and buffer descriptors inside: larger tensors take the per-tile kernels (size_t addressing)
     if ((size_t)a.B * H * H * KCH * 2 >= (1ull << 31) || (size_t)a.B * H * H * NCH * 2 >= (1ull << 31)) return -100;
@@ -426,13 +506,13 @@ static int run_big(const ConvBf16Args& a, hipStream_t st) {
 
 // Which layers this file serves, by mask bit: input gradients — bit 0 = E4 (256 -> 128, 4 x 4 tile), bit 1 = E3 (128 -> 64, 8 x 2 tile);
 // forward (bias + ONE BatchNorm partial per item of conv_bf16_big_tiles(..) tiles — the caller must tell launch_bn_fwd_finalize) —
-// bit 0 = E3 (64 -> 128), bit 1 = E4 (128 -> 256), both on the 4 x 4 tile.
+// bit 0 = E3 (64 -> 128), bit 1 = E4 (128 -> 256), both on the 4 x 4 tile, bit 2 = E2 (32 -> 64, 8 x 2 tile).
 bool conv_bf16_big_has(int layer, int width, bool dgrad, int mask) {
     if (width != 64 && width != 128) return false;
     if (dgrad) return (layer == 3 && (mask & 1)) || (layer == 2 && (mask & 2));
-    return (layer == 2 && (mask & 1)) || (layer == 3 && (mask & 2));
+    return (layer == 2 && (mask & 1)) || (layer == 3 && (mask & 2)) || (layer == 1 && (mask & 4));
 }
-int conv_bf16_big_tiles(int layer, int width, bool dgrad) { (void)width; return (dgrad && layer == 2) ? 8 : 4; }
+int conv_bf16_big_tiles(int layer, int width, bool dgrad) { (void)width; return ((dgrad && layer == 2) || (!dgrad && layer == 1)) ? 8 : 4; }
 // returns -100 when the layer has no instantiation (or the tensors are too large for its 32-bit offsets)
 int launch_conv_bf16_big(int layer, int width, bool dgrad, int mask, const ConvBf16Args& a, hipStream_t st) {
     if (!conv_bf16_big_has(layer, width, dgrad, mask)) return -100;
@@ -442,8 +522,10 @@ int launch_conv_bf16_big(int layer, int width, bool dgrad, int mask, const ConvB
         if (width == 128 && layer == 3) return run_big<256, 128, 16, 128, 4, 1, EPI_PLAIN>(a, st);
         if (width == 128 && layer == 2) return run_big<128, 64, 32, 64, 8, 1, EPI_PLAIN>(a, st);
     } else {
+        if (width == 64 && layer == 1) return run_big<32, 64, 32, 64, 8, 1, EPI_BIAS_BNSTAT>(a, st);
         if (width == 64 && layer == 2) return run_big<64, 128, 16, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);
         if (width == 64 && layer == 3) return run_big<128, 256, 8, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);
+        if (width == 128 && layer == 1) return run_big<32, 64, 64, 64, 8, 1, EPI_BIAS_BNSTAT>(a, st);
         if (width == 128 && layer == 2) return run_big<64, 128, 32, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);
         if (width == 128 && layer == 3) return run_big<128, 256, 16, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);
     }

@@ -16,7 +16,39 @@ from oracle import cvae_oracle as orc
 
 ENC = [(32, 64), (64, 32), (128, 16), (256, 8)]       # (channels, conv output size at width 64)
 DEC = [(128, 4), (64, 8), (32, 16), (32, 32)]
-TIE_TOL = 1e-5          # |difference to a tie| of a flipped unit, in units of the normalised / pre-activation value (O(1))
+# |difference to a tie| of a flipped unit, in units of the normalised / pre-activation value (O(1)), per precision mode.  Why a bound and where
+# it comes from: if the HIP step picks window position a and the oracle position b, then n_hip(a) >= n_hip(b) and n_orc(b) >= n_orc(a), hence
+# 0 <= n_orc(b) - n_orc(a) <= 2 E with E = max |n_hip - n_orc| over the layer — a flip further from a tie than twice the two sides' largest
+# value deviation cannot be round-off (the same for a ReLU input: |n_orc| <= E).  value_deviation() measures E per layer in the run under test
+# and check_step_against_oracle asserts gap <= 2 E for every flip; TIE_TOL bounds E itself from the measured distribution over data seeds
+# 1234 / 7 / 11 / 21 / 33 at 64x64 (B = 32) and 128x128 (B = 3), profiles/r05_tie_gap_study.txt (tests/../profiles/experiments/tie_gap_study.py):
+# worst flipped-unit gap x 2, rounded up.  The fp32-MFMA mode sums in the reference's k order; the emulation modes add the partial products of
+# a 16-channel block smallest first (bf16x6 drops three of nine), a different but equally round-off-sized ordering.
+TIE_TOL_BY_MODE = {"f32": 1e-5, "bf16x9": 2e-5, "bf16x6": 2e-5}
+TIE_TOL = TIE_TOL_BY_MODE["f32"]
+
+
+def tie_tol(vae):
+    return TIE_TOL_BY_MODE.get(getattr(vae.handle, "precision", "f32"), TIE_TOL)
+
+
+def value_deviation(vae, B, taps):
+    """E_l = max |n_hip - n_orc| of the normalised pre-pool values of encoder block l (what the pool / ReLU decisions are taken on), and of the
+    decoder's pre-activations recomputed from... the stored o_i (post-ReLU: compared where both sides are positive)."""
+    ws, h, k = vae._workspace(B), vae.handle, vae.width // 64
+    out = {}
+    for l, (c, s) in enumerate(ENC):
+        s *= k
+        y = h.ws_view(ws, B, f"y{l}", B * s * s * c).view(B, s, s, c).permute(0, 3, 1, 2).double()
+        coef = h.ws_view(ws, B, f"coef{l}", c * 4).view(c, 4).double()
+        n = (y * coef[:, 0].view(1, c, 1, 1) + coef[:, 1].view(1, c, 1, 1)).float().cpu()
+        out[f"enc{l}"] = float((n - taps[f"enc_n{l}"].detach()).abs().max())
+    for i, (c, s) in enumerate(DEC):
+        o = h.ws_view(ws, B, f"o{i}", B * s * k * s * k * c).view(B, s * k, s * k, c).permute(0, 3, 1, 2).cpu()
+        pre = taps[f"dec_pre{i}"].detach()
+        both = (o > 0) & (pre > 0)
+        out[f"dec{i}"] = float((o - pre)[both].abs().max()) if bool(both.any()) else 0.0
+    return out
 
 
 def hip_decisions(vae, B):
@@ -127,8 +159,12 @@ def check_step_against_oracle(vae, x, pred, eps, B, wseed=0, tol=1e-4, rel=1e-4,
     n_units = sum(v.numel() for v in d_hip.values())
     n_flips = sum(f[1] for f in rep["flips"])
     assert n_flips <= max_flips, f"{n_flips} decision flips among {n_units} units: {rep['flips']}"
+    rep["dev"] = value_deviation(vae, B, taps)
     for k, nf, gap in rep["flips"]:
-        assert gap <= TIE_TOL, f"{k}: {nf} flipped unit(s) up to {gap:.3e} away from a tie — not round-off"
+        if not k.startswith("relu_dec"):               # encoder decisions: E is exact there (decoder: measured on the units both sides keep, a proxy)
+            e = rep["dev"]["enc" + k[-1]]
+            assert gap <= 2.0 * e + 1e-12, f"{k}: {nf} flipped unit(s) up to {gap:.3e} away from a tie, but the two sides' values differ by at most {e:.3e}"
+        assert gap <= tie_tol(vae), f"{k}: {nf} flipped unit(s) up to {gap:.3e} away from a tie — not round-off ({getattr(vae.handle, 'precision', 'f32')} bound {tie_tol(vae):.0e})"
     if n_flips:
         p2 = orc.to_torch(params, requires_grad=True)
         orc.train_step(p2, x, pred, eps, bn_state=orc.new_bn_state(p2), decisions=d_hip)

@@ -282,7 +282,8 @@ def test_bf16x6_step_at_128x128_frames_meets_the_fp32_parity_bar():
     from decisions import check_step_against_oracle
     from critic_vae_amd.nets import VariationalAutoencoder
     dev = torch.device("cuda:0")
-    W, B, DSEED = 128, 3, 7          # (data seed 1234 has one block-3 pool window 1.007e-5 from a tie: decisions.TIE_TOL = 1e-5 rejects it; 7 and 11 have none)
+    W, B, DSEED = 128, 3, 1234       # data seed 1234 has one block-3 pool window 1.007e-5 from a tie in this mode: inside the mode's bound (decisions.TIE_TOL_BY_MODE,
+                                     # derived from profiles/r05_tie_gap_study.txt) and inside twice the two sides' value deviation, which check_step_against_oracle asserts
     x, pred, eps = (torch.from_numpy(v) for v in synth.make_batch(DSEED, 0, B, W))
     vae = VariationalAutoencoder(width=W, max_batch=B, seed=0, precision="bf16x6").to(dev)
     vae.load_reference_params(synth.make_params(0, W))

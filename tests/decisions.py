@@ -22,9 +22,11 @@ DEC = [(128, 4), (64, 8), (32, 16), (32, 32)]
 # value deviation cannot be round-off (the same for a ReLU input: |n_orc| <= E).  value_deviation() measures E per layer in the run under test
 # and check_step_against_oracle asserts gap <= 2 E for every flip; TIE_TOL bounds E itself from the measured distribution over data seeds
 # 1234 / 7 / 11 / 21 / 33 at 64x64 (B = 32) and 128x128 (B = 3), profiles/r05_tie_gap_study.txt (tests/../profiles/experiments/tie_gap_study.py):
-# worst flipped-unit gap x 2, rounded up.  The fp32-MFMA mode sums in the reference's k order; the emulation modes add the partial products of
-# a 16-channel block smallest first (bf16x6 drops three of nine), a different but equally round-off-sized ordering.
-TIE_TOL_BY_MODE = {"f32": 1e-5, "bf16x9": 2e-5, "bf16x6": 2e-5}
+# worst flipped-unit gap x 2, rounded up (measured worst: f32 6.6e-6, bf16x9 / bf16x6 1.0e-5; E itself is 1-2e-5 in the encoder blocks in ALL
+# three modes — BatchNorm's 1/std amplifies the convs' summation-order noise alike — and every observed flip sat within 0.35 of 2 E).  The
+# fp32-MFMA mode sums in the reference's k order; the emulation modes add the partial products of a 16-channel block smallest first (bf16x6
+# drops three of nine), a different but equally round-off-sized ordering.
+TIE_TOL_BY_MODE = {"f32": 2e-5, "bf16x9": 2e-5, "bf16x6": 2e-5}
 TIE_TOL = TIE_TOL_BY_MODE["f32"]
 
 

@@ -39,6 +39,11 @@ extern "C" int cvae_big_dbg_read(long long* out) { return (int)hipMemcpyFromSymb
 #define BT_ON false
 #define BT(v)
 #endif
+// -DBIG_STEPTIME (with -DBIG_TIMING): s_memtime at the top of every step of ONE chunk pair (the second trip of the first item) of workgroup 0, wave 0
+#ifdef BIG_STEPTIME
+__device__ long long big_steps[128];
+extern "C" int cvae_big_steps_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(big_steps), sizeof(big_steps)); }
+#endif
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Timing experiments (WRONG results, never shipped; profiles/experiments/variant.sh -DBIG_EXP=n): what the stage loop pays for each of its
@@ -55,7 +60,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t big_rsrc(const void* p, unsign
 }
 static constexpr unsigned BIG_OOB = 0x80000000u;
 
-template <int KCH, int NCH, int H, int NT, int MT, int KB, int EPI>
+template <int KCH, int NCH, int H, int NT, int MT, int KB, int EPI, bool TDB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv5x5_bf16_big_kernel(ConvBf16Args a, int numGroups) {
     using T = Tile<H>;
     static_assert(EPI == EPI_PLAIN || EPI == EPI_BIAS_BNSTAT, "epilogues: plain (input gradient) or bias + BatchNorm partials (forward)");
@@ -66,7 +71,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     static_assert(KCH % KCB == 0 && NCH % NT == 0 && MT * NB == 16 && (KB == 1 || KB == 2), "tiling");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);       // [tile][octet][halo pixel]
-    bf16x8* lds_w = lds_a + MT * A_UNITS;                      // [buffer][tap][kb][half][n]
+    constexpr int TBUFS = TDB ? 2 : 1;                         // TDB: the input tiles are double-buffered too (tile buffer = chunk parity)
+    bf16x8* lds_w = lds_a + TBUFS * MT * A_UNITS;              // [buffer][tap][kb][half][n]
     // behind the slabs: 256 dump units (4 KB) for the staging stores of units that do not exist, then (forward) the [S | Q][wave][NT] rows of the
     // BatchNorm partials (they live from an item's epilogue until the next item's first stage barrier: not in the dump area) and [NCH] bias
     [[maybe_unused]] float* red = reinterpret_cast<float*>(lds_w + 2 * W_UNITS + 256);
@@ -180,21 +186,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int i = 0; i < IPT; ++i)
                 breg[tl * IPT + i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[tl * IPT + i], tsoff[tl], 0));
     };
+    // TDB: two staged units per step — requested in stages 0..2 (steps 3, 4), written two stages later into the OTHER tile buffer
+    auto load_unit = [&](int u, const unsigned (&tsoff)[MT]) {
+        if (u < MT * IPT) breg[u] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[u], tsoff[u / IPT], 0));
+    };
+    auto store_unit = [&](int u, int tb) {
+        if (u < MT * IPT) {
+            const int tl = u / IPT, i = u % IPT, q = tid + i * 256;
+            lds_a[(NQ % 256 == 0 || q < NQ) ? (tb * MT + tl) * A_UNITS + (q % OCT) * PSP + q / OCT : TBUFS * MT * A_UNITS + 2 * W_UNITS + tid] = breg[u];
+        }
+    };
     auto store_input = [&]() {
 #pragma unroll
         for (int tl = 0; tl < MT; ++tl)
 #pragma unroll
             for (int i = 0; i < IPT; ++i) {
                 const int q = tid + i * 256;
-                lds_a[(NQ % 256 == 0 || q < NQ) ? tl * A_UNITS + (q % OCT) * PSP + q / OCT : MT * A_UNITS + 2 * W_UNITS + tid] = breg[tl * IPT + i];
+                lds_a[(NQ % 256 == 0 || q < NQ) ? tl * A_UNITS + (q % OCT) * PSP + q / OCT : TBUFS * MT * A_UNITS + 2 * W_UNITS + tid] = breg[tl * IPT + i];
             }
     };
 
     f32x16 acc[MT][NB];
     bf16x8 wf[2][NB], xf[2][MT];                               // two fragment sets, alternating per step (they live across stages)
-    auto ldf = [&](int set, int i, int r, int buf) {           // fragments of step i of a stage (kernel row r, slab buffer buf)
+    auto ldf = [&](int set, int i, int r, int buf, int tb = 0) {   // fragments of step i of a stage (kernel row r, slab buffer buf, tile buffer tb)
         const int s = i / KB, kb = i % KB;
-        const bf16x8* ap = lds_a + lh * PSP + aPix + r * T::HTW;
+        const bf16x8* ap = lds_a + (TDB ? tb : 0) * (MT * A_UNITS) + lh * PSP + aPix + r * T::HTW;
         const bf16x8* bp = lds_w + buf * W_UNITS + lh * NT + li;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) wf[set][nb] = bp[((s * KB + kb) * 2) * NT + nb * 32];
@@ -215,22 +231,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     //   R == KS - 1:       they are written in the last step behind the barrier (chunk / item boundary; the tiles are single-buffered).
     constexpr int WN = KB == 2 ? 5 : 2, WU = (WPT + WN - 1) / WN;
     static_assert(WN < NSTEP - 1, "the slab request sits in front of the stage's barrier");
-    auto stage = [&](auto p0c, auto rc, int gst, unsigned wsoff, const unsigned (&tsoff)[MT]) {
-        constexpr int P0 = decltype(p0c)::value, R = decltype(rc)::value;
+#ifdef BIG_STEPTIME
+    bool steptime_on = false, steptime_first = false;
+    int steptime_idx = 0;
+    const __amdgpu_buffer_rsrc_t rs_steps = big_rsrc(big_steps, (unsigned)sizeof(big_steps));
+#endif
+    static_assert(!TDB || (KB == 1 && MT * IPT <= 12), "the unit schedule of the double-buffered tiles: 6 slots of two units");
+    auto stage = [&](auto p0c, auto rc, auto tbc, int gst, unsigned wsoff, const unsigned (&tsoff)[MT]) {
+        constexpr int P0 = decltype(p0c)::value, R = decltype(rc)::value, TB = decltype(tbc)::value;       // TB: tile buffer of this chunk (TDB)
         constexpr int RN = R == KS - 1 ? 0 : R + 1;
         const int buf = gst & 1;
 #pragma unroll
         for (int i = 0; i < NSTEP; ++i) {
             constexpr int NR = NB + MT;
             const int set = (P0 + i) & 1;
+#ifdef BIG_STEPTIME
+            if (BT_ON) {                                       // branch-free: every lane but one carries an out-of-range offset
+                __builtin_amdgcn_sched_barrier(0);
+                const long long t = clock64();
+                const unsigned so = (steptime_on && tid == 0) ? (unsigned)(steptime_idx * 8) : BIG_OOB;
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)t, rs_steps, so, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)(t >> 32), rs_steps, so == BIG_OOB ? BIG_OOB : so + 4u, 0, 0);
+                ++steptime_idx;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
             if (i == NSTEP - 1) {
                 if (!(BIG_EXP & 1)) __syncthreads();           // slab gst + 1 visible; every wave holds its last fragments of slab gst (and of the tiles)
-                if constexpr (R == KS - 1) { if (!(BIG_EXP & 8)) store_input(); }
+                if constexpr (TDB) ldf(set ^ 1, 0, RN, buf ^ 1, R == KS - 1 ? TB ^ 1 : TB);      // the next chunk's tiles were written in stages 2..4
+                else if constexpr (R == KS - 1) { if (!(BIG_EXP & 8)) store_input(); }
                 else ldf(set ^ 1, 0, RN, buf ^ 1);
-            } else ldf(set ^ 1, i + 1, R, buf);
+            } else ldf(set ^ 1, i + 1, R, buf, TB);
             if (i < WN && !(BIG_EXP & 2)) store_w(WU * i, WU * (i + 1), buf ^ 1);
             if (i == WN && !(BIG_EXP & 4)) load_w(wsoff);
-            if (i == WN + 1 && R == KS - 3 && !(BIG_EXP & 8)) load_input(tsoff);
+            if constexpr (TDB) {
+                // the tile stream, two units per step (the 12 requests of a chunk in ONE step held the wave at the texture unit for 800 cycles, and
+                // their 12 LDS writes + a second barrier closed every chunk: 1.7 k of a 16.4 k-cycle chunk, profiles/r05_f_big_steptime.txt)
+                if (R <= 2 && (i == 3 || i == 4) && !(BIG_EXP & 8)) { const int sl = R * 2 + (i - 3); load_unit(2 * sl, tsoff); load_unit(2 * sl + 1, tsoff); }
+                if ((R == 2 || R == 3) && (i == 3 || i == 4) && !(BIG_EXP & 8)) { const int sl = (R - 2) * 2 + (i - 3); store_unit(2 * sl, TB ^ 1); store_unit(2 * sl + 1, TB ^ 1); }
+                if (R == 4 && (i == 2 || i == 3) && !(BIG_EXP & 8)) { const int sl = 4 + (i - 2); store_unit(2 * sl, TB ^ 1); store_unit(2 * sl + 1, TB ^ 1); }
+            } else {
+                if (i == WN + 1 && R == KS - 3 && !(BIG_EXP & 8)) load_input(tsoff);
+            }
 #pragma unroll
             for (int tl = 0; tl < MT; ++tl)
 #pragma unroll
@@ -292,6 +334,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 
     int gst = 0;
+#ifdef BIG_STEPTIME
+    steptime_first = true;
+#endif
     for (;;) {
         int itn = it + G, grpn, n0n;
         decode(itn, grpn, n0n);
@@ -314,6 +359,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // travelling in wreg when stage st starts (requested by stage st - 1, by the previous item's last stage, or by the prologue).
         static_assert(NCHUNK % 2 == 0, "chunks are walked in pairs");
         for (int cp = 0; cp < NCHUNK; cp += 2) {
+#ifdef BIG_STEPTIME
+            steptime_on = BT_ON && blockIdx.x == 0 && steptime_first && cp == (NCHUNK >= 4 ? 2 : 0);
+            steptime_idx = 0;
+#endif
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int cc = cp + h;
@@ -336,24 +385,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     const unsigned wsoff = slab_soff(own || !have_next ? cur.n0 : n0n, own ? s2 : (have_next ? s2 - NST : 0));
                     constexpr int P0v[2][5] = {{0, NSTEP & 1, 0, NSTEP & 1, 0}, {NSTEP & 1, 0, NSTEP & 1, 0, NSTEP & 1}};
                     if (h == 0) {
-                        if (r == 0) stage(std::integral_constant<int, P0v[0][0]>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts);
-                        if (r == 1) stage(std::integral_constant<int, P0v[0][1]>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts);
-                        if (r == 2) stage(std::integral_constant<int, P0v[0][2]>{}, std::integral_constant<int, 2>{}, gst, wsoff, ts);
-                        if (r == 3) stage(std::integral_constant<int, P0v[0][3]>{}, std::integral_constant<int, 3>{}, gst, wsoff, ts);
-                        if (r == 4) stage(std::integral_constant<int, P0v[0][4]>{}, std::integral_constant<int, 4>{}, gst, wsoff, ts);
+                        if (r == 0) stage(std::integral_constant<int, P0v[0][0]>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts);
+                        if (r == 1) stage(std::integral_constant<int, P0v[0][1]>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts);
+                        if (r == 2) stage(std::integral_constant<int, P0v[0][2]>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts);
+                        if (r == 3) stage(std::integral_constant<int, P0v[0][3]>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts);
+                        if (r == 4) stage(std::integral_constant<int, P0v[0][4]>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts);
                     } else {
-                        if (r == 0) stage(std::integral_constant<int, P0v[1][0]>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts);
-                        if (r == 1) stage(std::integral_constant<int, P0v[1][1]>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts);
-                        if (r == 2) stage(std::integral_constant<int, P0v[1][2]>{}, std::integral_constant<int, 2>{}, gst, wsoff, ts);
-                        if (r == 3) stage(std::integral_constant<int, P0v[1][3]>{}, std::integral_constant<int, 3>{}, gst, wsoff, ts);
-                        if (r == 4) stage(std::integral_constant<int, P0v[1][4]>{}, std::integral_constant<int, 4>{}, gst, wsoff, ts);
+                        if (r == 0) stage(std::integral_constant<int, P0v[1][0]>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts);
+                        if (r == 1) stage(std::integral_constant<int, P0v[1][1]>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts);
+                        if (r == 2) stage(std::integral_constant<int, P0v[1][2]>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts);
+                        if (r == 3) stage(std::integral_constant<int, P0v[1][3]>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts);
+                        if (r == 4) stage(std::integral_constant<int, P0v[1][4]>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts);
                     }
                     ++gst;
                     if (BN && h == 0 && r == 0 && cp == 0) bn_combine();      // behind stage 0's barrier: the previous item's rows are complete
                 }
                 BT(b3);
-                __syncthreads();                               // chunk / item boundary: the new tiles are visible behind this barrier
-                if (!lastc) ldf(h == 0 ? (NSTEP & 1) : 0, 0, 0, gst & 1);
+                if constexpr (!TDB) {
+                    __syncthreads();                           // chunk / item boundary: the new tiles are visible behind this barrier
+                    if (!lastc) ldf(h == 0 ? (NSTEP & 1) : 0, 0, 0, gst & 1);
+                }
                 BT(b4);
 #ifdef BIG_TIMING
                 if (BT_ON) { tstage += b3 - b2; tclose += b4 - b3; }
@@ -459,10 +510,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef BIG_TIMING
         if (BT_ON) { tepi += b2 - b1; ++nit; }
 #endif
+#ifdef BIG_STEPTIME
+        steptime_first = false;
+#endif
         if (!have_next) break;
         cur = setup(grpn, n0n); it = itn;
         set_voff(cur);                                         // recomputed (not kept) across the epilogue: ~100 VALU per item for 12-16 registers
-        ldf(0, 0, 0, gst & 1);                                 // first fragments of the next item (its tiles and slab 0 are in LDS: the last stage's barriers)
+        if constexpr (!TDB) ldf(0, 0, 0, gst & 1);             // first fragments of the next item (its tiles and slab 0 are in LDS: the last stage's barriers);
+                                                               // TDB: the last stage's last step has requested them already (tile buffer 0, kernel row 0)
     }
     if constexpr (BN) { __syncthreads(); bn_combine(); }       // the last item's rows
 #ifdef BIG_TIMING
@@ -478,14 +533,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 template <int KCH, int NCH, int H, int NT, int MT, int KB, int EPI>
 static int run_big(const ConvBf16Args& a, hipStream_t st) {
+    constexpr bool TDB = MT == 4 && KB == 1;                  // the 4 x 4 tile leaves LDS for a second set of input tiles
     using T = Tile<H>;
     constexpr int OCT = 2 * KB;
     constexpr int NY = NCH / NT;
-    constexpr int SMEM = (MT * OCT * Bf16Geom<H, OCT>::PSP + 2 * 5 * KB * 2 * NT + 256 + 4 * 32 * 9) * 16 + (EPI == EPI_BIAS_BNSTAT ? (2 * 4 * NT + NCH) * 4 : 0);
+    constexpr int SMEM = ((TDB ? 2 : 1) * MT * OCT * Bf16Geom<H, OCT>::PSP + 2 * 5 * KB * 2 * NT + 256 + 4 * 32 * 9) * 16 + (EPI == EPI_BIAS_BNSTAT ? (2 * 4 * NT + NCH) * 4 : 0);
     static_assert(SMEM <= 160 * 1024, "LDS");
     // 32-bit byte offsets and buffer descriptors inside: larger tensors take the per-tile kernels (size_t addressing)
     if ((size_t)a.B * H * H * KCH * 2 >= (1ull << 31) || (size_t)a.B * H * H * NCH * 2 >= (1ull << 31)) return -100;
-    auto kern = conv5x5_bf16_big_kernel<KCH, NCH, H, NT, MT, KB, EPI>;
+    auto kern = conv5x5_bf16_big_kernel<KCH, NCH, H, NT, MT, KB, EPI, TDB>;
     static DeviceOnce once;
     { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(kern), SMEM); if (rc) return rc; }
     const int numTiles = cdiv(a.B, T::IMGS) * T::TILES_PER_IMG, numGroups = cdiv(numTiles, MT);
@@ -504,15 +560,17 @@ static int run_big(const ConvBf16Args& a, hipStream_t st) {
     return 0;
 }
 
-// Which layers this file serves, by mask bit: input gradients — bit 0 = E4 (256 -> 128, 4 x 4 tile), bit 1 = E3 (128 -> 64, 8 x 2 tile);
-// forward (bias + ONE BatchNorm partial per item of conv_bf16_big_tiles(..) tiles — the caller must tell launch_bn_fwd_finalize) —
-// bit 0 = E3 (64 -> 128), bit 1 = E4 (128 -> 256), both on the 4 x 4 tile, bit 2 = E2 (32 -> 64, 8 x 2 tile).
+// Which layers this file serves, by mask bit: input gradients — bit 0 = E4 (256 -> 128, 4 x 4 tile), bit 1 = E3 (128 -> 64, 8 x 2 tile, single-buffered
+// input tiles); forward (bias + ONE BatchNorm partial per item of conv_bf16_big_tiles(..) tiles — the kernel that ran tells launch_bn_fwd_finalize) —
+// bit 0 = E3 (64 -> 128), bit 1 = E4 (128 -> 256), both on the 4 x 4 tile.  Measured and not instantiated: E2 forward (32 -> 64) on the 8 x 2 tile —
+// eight 4-row tiles with their own halos are 98 KB of requests per 16-channel chunk and CU: 268-285 us against 219 us on the two-workgroup persistent
+// kernel (profiles/r05_e_kprof_conv_r4_vs_new.txt; it wants ONE image-high tile with one halo).
 bool conv_bf16_big_has(int layer, int width, bool dgrad, int mask) {
     if (width != 64 && width != 128) return false;
     if (dgrad) return (layer == 3 && (mask & 1)) || (layer == 2 && (mask & 2));
-    return (layer == 2 && (mask & 1)) || (layer == 3 && (mask & 2)) || (layer == 1 && (mask & 4));
+    return (layer == 2 && (mask & 1)) || (layer == 3 && (mask & 2));
 }
-int conv_bf16_big_tiles(int layer, int width, bool dgrad) { (void)width; return ((dgrad && layer == 2) || (!dgrad && layer == 1)) ? 8 : 4; }
+int conv_bf16_big_tiles(int layer, int width, bool dgrad) { (void)width; return (dgrad && layer == 2) ? 8 : 4; }
 // returns -100 when the layer has no instantiation (or the tensors are too large for its 32-bit offsets)
 int launch_conv_bf16_big(int layer, int width, bool dgrad, int mask, const ConvBf16Args& a, hipStream_t st) {
     if (!conv_bf16_big_has(layer, width, dgrad, mask)) return -100;
@@ -522,10 +580,8 @@ int launch_conv_bf16_big(int layer, int width, bool dgrad, int mask, const ConvB
         if (width == 128 && layer == 3) return run_big<256, 128, 16, 128, 4, 1, EPI_PLAIN>(a, st);
         if (width == 128 && layer == 2) return run_big<128, 64, 32, 64, 8, 1, EPI_PLAIN>(a, st);
     } else {
-        if (width == 64 && layer == 1) return run_big<32, 64, 32, 64, 8, 1, EPI_BIAS_BNSTAT>(a, st);
         if (width == 64 && layer == 2) return run_big<64, 128, 16, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);
         if (width == 64 && layer == 3) return run_big<128, 256, 8, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);
-        if (width == 128 && layer == 1) return run_big<32, 64, 64, 64, 8, 1, EPI_BIAS_BNSTAT>(a, st);
         if (width == 128 && layer == 2) return run_big<64, 128, 32, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);
         if (width == 128 && layer == 3) return run_big<128, 256, 16, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);
     }

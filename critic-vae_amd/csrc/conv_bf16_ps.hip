@@ -123,12 +123,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     bf16x8 wreg[WPT], breg[MT * IPT];
     unsigned okmask = 0u;
+    // Operands travel as BUFFER loads (uniform descriptor + 32-bit lane offset + uniform SGPR offset).  Round 4 used a laundered uniform pointer
+    // + lane offset, which hipcc emits as FLAT loads: they count in lgkmcnt too and return out of order with the LDS reads, so every fragment
+    // wait of the MFMA phase became lgkmcnt(0) and its first MFMA waited for the next stage's slab and tiles — the loads the phase was meant
+    // to hide (round 5: 1052 flat_load in this file's listing; conv_bf16_big.hip header).
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.wp, (unsigned)(25u * (KCH / 16) * 2u * NCH * 16u));
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, (unsigned)((size_t)a.B * H * H * KCH * 2));
     auto load_w = [&](const Item& x, int cc, int r) {
-        const char* wst = reinterpret_cast<const char*>(a.wp + (size_t)(r * KS * (KCH / 16) + cc * KB) * 2 * NCH + x.n0);
-        asm volatile("" : "+s"(wst));       // opaque uniform base: keeps the loads in the SGPR-base + 32-bit-offset form (hoisted out of the item
-                                            // loop as 64-bit lane addresses, the 25 slab pointers cost 50 VGPRs and the kernel spilled)
+        const unsigned soff = (unsigned)((r * KS * (KCH / 16) + cc * KB) * 2 * NCH + x.n0) * 16u;
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) wreg[i] = *reinterpret_cast<const bf16x8*>(wst + wbase[i]);
+        for (int i = 0; i < WPT; ++i) wreg[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wbase[i], soff, 0));
     };
     auto store_w = [&]() {
 #pragma unroll
@@ -136,8 +140,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (W_UNITS % 256 == 0 || tid + i * 256 < W_UNITS) lds_w[tid + i * 256] = wreg[i];
     };
     auto load_input = [&](const Item& x, int cc) {
-        const char* inb = reinterpret_cast<const char*>(a.in);
-        asm volatile("" : "+s"(inb));
 #pragma unroll
         for (int tl = 0; tl < MT; ++tl)
 #pragma unroll
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const unsigned okb = (ipk[i] >> 31) & (unsigned)((unsigned)(x.ty0[tl] + hy - 2) < (unsigned)H) &
                                      (unsigned)((unsigned)(x.tx0[tl] + hx - 2) < (unsigned)H) & (unsigned)(x.img0[tl] + img < a.B);
                 const unsigned e = okb ? (unsigned)(x.ibase[tl] + irel[i] + cc * KCB * 2) : 0u;      // bytes from a.in (uniform base + 32-bit lane offset)
-                breg[tl * IPT + i] = *reinterpret_cast<const bf16x8*>(inb + e);    // unconditional load (unit 0 when padding), select when staged
+                breg[tl * IPT + i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_in, e, 0, 0));    // unconditional load (unit 0 when padding), select when staged
                 okmask = (okmask & ~(1u << (tl * IPT + i))) | (okb << (tl * IPT + i));
             }
     };

@@ -107,13 +107,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     f32x4 wreg[WPT], ireg[IPT];
     unsigned okmask = 0u;
+    // Operands travel as BUFFER loads: uniform descriptor + 32-bit lane offset + uniform SGPR offset.  Rounds 3-4 used a laundered uniform
+    // pointer + lane offset, which hipcc emits as FLAT loads: those count in lgkmcnt as well as vmcnt and return out of order with the LDS
+    // reads, so every fragment wait of the MFMA phase became lgkmcnt(0) — the phase's first MFMA waited for the NEXT stage's weight slab and
+    // input tile to arrive from L2 / HBM, the very loads it was meant to hide (found in round 5: 414 flat_load in this file's listing).
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc_f(a.w, (unsigned)(25u * KCH * NCH * 4u));
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc_f(a.in, (unsigned)((size_t)a.B * H * H * KCH * 4));
     auto load_w = [&](const Item& x, int cc, int r) {
         // forward: W[(r*5+s)][cc*KC+kc][n0 + ..]; dgrad: W[24-(r*5+s)][n0+n][cc*KC + ..] (flipped taps, transposed read)
-        const char* wst = reinterpret_cast<const char*>(DGRAD ? a.w + ((size_t)(20 - r * 5) * NCH + x.n0) * KCH + cc * KC
-                                                              : a.w + ((size_t)(r * 5) * KCH + cc * KC) * NCH + x.n0);
-        asm volatile("" : "+s"(wst));       // opaque uniform base + 32-bit lane offset (see conv_bf16_ps.hip)
+        const unsigned soff = (unsigned)(DGRAD ? ((20 - r * 5) * NCH + x.n0) * KCH + cc * KC : ((r * 5) * KCH + cc * KC) * NCH + x.n0) * 4u;
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) wreg[i] = *reinterpret_cast<const f32x4*>(wst + wbase[i]);
+        for (int i = 0; i < WPT; ++i) wreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wbase[i], soff, 0));
     };
     auto store_w = [&]() {
 #pragma unroll
@@ -126,15 +130,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     auto load_input = [&](const Item& x, int cc) {
-        const char* inb = reinterpret_cast<const char*>(a.in);
-        asm volatile("" : "+s"(inb));
 #pragma unroll
         for (int i = 0; i < IPT; ++i) {
             const int hy = ipk[i] & 255, hx = (ipk[i] >> 8) & 255, img = (ipk[i] >> 16) & 255;
             const unsigned okb = (ipk[i] >> 31) & (unsigned)((unsigned)(x.ty0 + hy - 2) < (unsigned)H) &
                                  (unsigned)((unsigned)(x.tx0 + hx - 2) < (unsigned)H) & (unsigned)(x.img0 + img < a.B);
             const unsigned e = okb ? (unsigned)(x.ibase + irel[i] + cc * KC * 4) : 0u;
-            ireg[i] = *reinterpret_cast<const f32x4*>(inb + e);
+            ireg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, e, 0, 0));
             okmask = (okmask & ~(1u << i)) | (okb << i);
         }
     };
@@ -309,6 +311,8 @@ int launch_conv_mfma_ps(int layer, int width, bool dgrad, int B, const float* in
                 case 2: return run_mfma_ps<64, 128, 16, false, 64, EPI_BIAS_BNSTAT>(a, st);
 #ifdef CONVF_PS_ALL
                 case 3: return run_mfma_ps<128, 256, 8, false, 32, EPI_BIAS_BNSTAT>(a, st);
+#elif defined(CONVF_PS_E4_64)
+                case 3: return run_mfma_ps<128, 256, 8, false, 64, EPI_BIAS_BNSTAT>(a, st);
 #endif
             }
         } else if (width == 128) {
@@ -328,6 +332,8 @@ int launch_conv_mfma_ps(int layer, int width, bool dgrad, int B, const float* in
 #ifdef CONVF_PS_ALL
                 case 1: return run_mfma_ps<64, 32, 32, true, 32, EPI_PLAIN>(a, st);
                 case 3: return run_mfma_ps<256, 128, 8, true, 32, EPI_PLAIN>(a, st);
+#elif defined(CONVF_PS_E4_64)
+                case 3: return run_mfma_ps<256, 128, 8, true, 64, EPI_PLAIN>(a, st);
 #endif
             }
         } else if (width == 128) {

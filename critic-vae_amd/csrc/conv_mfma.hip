@@ -451,7 +451,9 @@ int64_t conv_fwd_ws_floats(int layer, int width, int B) {
 // (bit layer-1 forward, bit 3+layer-1 input gradient; 0 = none, for A/B runs).
 int launch_conv_mfma_ps(int layer, int width, bool dgrad, int B, const float* in, const float* w, const float* bias, float* out, float* bnpart, hipStream_t st);
 #ifndef CONVF_PS_DEFAULT
-#define CONVF_PS_DEFAULT 19      // the 64-channel-tile layers (E2, E3 forward, E3 input gradient: -2.5 % each); the 32-channel-tile instantiations spill and lose
+#define CONVF_PS_DEFAULT 55      // the 64-channel-tile layers: E2, E3 forward, E3 input gradient (-2.5 % each), and — round 5, once the kernel's operands travelled
+                                 // as buffer loads — E4 forward / input gradient on 64-channel tiles (step 87.90 -> 88.32 k img/s, masks alternating on one box,
+                                 // profiles/r05_h_ps_buffer_loads.txt); the 32-channel-tile instantiations (E2 input gradient) spill and lose
 #endif
 static bool use_f32_ps(int layer, bool dgrad) {
     static const int mask = [] { const char* e = getenv("CVAE_CONVF_PS"); return e ? atoi(e) : CONVF_PS_DEFAULT; }();

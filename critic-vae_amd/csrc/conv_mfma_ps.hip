@@ -300,8 +300,9 @@ static int run_mfma_ps(const ConvPsArgs& a, hipStream_t st) {
 }
 
 // returns -100 when the layer has no persistent instantiation (the caller falls back to the per-tile kernel).  Built by default: the
-// 64-channel-tile layers the default mask selects (E2 forward, E3 forward, E3 input gradient, both frame sizes).  -DCONVF_PS_ALL adds the
-// others — the 32-channel-tile ones spill and lose (header comment), the rest were never the default — at 8 minutes of compile time.
+// 64-channel-tile layers the default mask selects (E2 / E3 / E4 forward, E3 / E4 input gradient at 64 x 64; E2 / E3 forward and E3 input gradient
+// at 128 x 128).  -DCONVF_PS_ALL adds the others — the 32-channel-tile ones spill and lose (header comment), the rest were never the default —
+// at 8 minutes of compile time.
 int launch_conv_mfma_ps(int layer, int width, bool dgrad, int B, const float* in, const float* w, const float* bias, float* out, float* bnpart, hipStream_t st) {
     const ConvPsArgs a{in, w, bias, out, bnpart, B};
     if (!dgrad) {
@@ -311,8 +312,8 @@ int launch_conv_mfma_ps(int layer, int width, bool dgrad, int B, const float* in
                 case 2: return run_mfma_ps<64, 128, 16, false, 64, EPI_BIAS_BNSTAT>(a, st);
 #ifdef CONVF_PS_ALL
                 case 3: return run_mfma_ps<128, 256, 8, false, 32, EPI_BIAS_BNSTAT>(a, st);
-#elif defined(CONVF_PS_E4_64)
-                case 3: return run_mfma_ps<128, 256, 8, false, 64, EPI_BIAS_BNSTAT>(a, st);
+#else
+                case 3: return run_mfma_ps<128, 256, 8, false, 64, EPI_BIAS_BNSTAT>(a, st);      // round 5: E4 on 64-channel tiles (no spills): 215 -> 207 us
 #endif
             }
         } else if (width == 128) {
@@ -332,8 +333,8 @@ int launch_conv_mfma_ps(int layer, int width, bool dgrad, int B, const float* in
 #ifdef CONVF_PS_ALL
                 case 1: return run_mfma_ps<64, 32, 32, true, 32, EPI_PLAIN>(a, st);
                 case 3: return run_mfma_ps<256, 128, 8, true, 32, EPI_PLAIN>(a, st);
-#elif defined(CONVF_PS_E4_64)
-                case 3: return run_mfma_ps<256, 128, 8, true, 64, EPI_PLAIN>(a, st);
+#else
+                case 3: return run_mfma_ps<256, 128, 8, true, 64, EPI_PLAIN>(a, st);              // 212 -> 211 us
 #endif
             }
         } else if (width == 128) {

@@ -218,6 +218,41 @@ def real_frames_case():
     step_case("real_b68", 68, real=(x, pred, extra), params_np=wp)
 
 
+def real_frames_training_case(steps=200):
+    """Training on frames that look like frames (missing 3): the reference's modules + torch.optim.Adam(lr = 5e-5, vae.py:36)
+    for `steps` steps on the 68 real frames of step_real_b68.npz as ONE batch (B = 68, the weights of that fixture: last decoder bias raised by
+    0.2; eps of step s = the generator's make_batch(dseed, s, 68)).  Records the loss triple of every step and the first step whose loss is not
+    finite (-1: none) — the reference's MS-SSIM goes NaN whenever a level turns negative, so a comparison of precision modes on
+    these frames is only defined over the finite prefix.  The oracle runs beside the reference for the first 5 steps (bit-identical)."""
+    fx = np.load(os.path.join(HERE, "step_real_b68.npz"))
+    x = orc.preprocess_frames(torch.from_numpy(fx["u8"]))
+    pred = torch.from_numpy(fx["pred"])
+    wp = synth.make_params(int(fx["wseed"]))
+    wp["decoder.model.12.bias"] = wp["decoder.model.12.bias"] + np.float32(fx["last_bias_shift"])
+    v = load_reference(wp)
+    opt = torch.optim.Adam(list(v.parameters()), lr=vae_parameters.lr)
+    op = orc.to_torch(wp, requires_grad=True)
+    ostate, obn = {}, orc.new_bn_state(op)
+    traj, first_bad = [], -1
+    for s in range(steps):
+        eps = torch.from_numpy(synth.make_batch(int(fx["dseed"]), s, 68)[2])
+        opt.zero_grad()
+        _, losses = run_reference_step(v, x, pred, eps)
+        opt.step()
+        traj.append([losses["total_loss"].item(), losses["recon_loss"].item(), losses["KLD"].item()])
+        if first_bad < 0 and not np.isfinite(traj[-1]).all():
+            first_bad = s
+        if s < 5:
+            orc.zero_grad(op)
+            o = orc.train_step(op, x, pred, eps, bn_state=obn)
+            orc.adam_step(op, ostate, lr=vae_parameters.lr)
+            assert abs(o["total_loss"].item() - traj[-1][0]) == 0.0, "oracle training step != reference"
+    traj = np.array(traj, np.float32)
+    print(f"[real training] {steps} steps at B = 68: loss {traj[0, 0]:.5f} -> {traj[-1, 0]:.5f}; first non-finite step {first_bad}")
+    np.savez_compressed(os.path.join(HERE, "train_real_b68.npz"), traj=traj, steps=steps, first_nonfinite_step=first_bad,
+                        dseed=int(fx["dseed"]), wseed=int(fx["wseed"]), lr=np.float32(vae_parameters.lr))
+
+
 def trajectory_case(n_frames=1024, batch=32, wseed=0, dseed=1234):
     """BASELINE.json config 1: one epoch of the vae.py:33-66 loop on synthetic frames (fixed
     order, explicit eps), torch.optim.Adam(lr=5e-5) — reference modules + torch's own Adam."""
@@ -371,10 +406,14 @@ def critic_real_case(batch=8):
 
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if "--only-real-training" in sys.argv:          # needs step_real_b68.npz (written by real_frames_case)
+        real_frames_training_case()
+        sys.exit(0)
     step_case("b2", 2)
     step_case("b32", 32)
     step_case("w128_b2", 2, width=128)
     real_frames_case()
+    real_frames_training_case()
     msssim_cases()
     critic_case()
     critic_real_case()

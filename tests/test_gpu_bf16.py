@@ -316,6 +316,33 @@ def test_big_tile_conv_kernels_every_instantiation_exact_on_their_stored_operand
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
+@pytest.mark.parametrize("W,B", [(128, 5), (64, 5), (128, 2)])
+def test_big_tile_bn_partials_match_the_per_tile_kernels(W, B, tmp_path):
+    """The persistent big-tile forward kernels emit ONE BatchNorm partial per item of four 128-pixel tiles, and launch_bn_fwd_finalize derives the
+    pixel count of every partial from the tile geometry: a quarter of an image (tiles per image >= 4: E3 at 128 x 128), two whole images (two tiles
+    per image: E4 at 128 x 128, E3 at 64 x 64), four half-filled... (8 x 8 images: E4 at 64 x 64), with ragged ends at odd batch sizes.  Two child
+    processes (the switch is read once per process) run the same bf16 forward with the big-tile kernels (CVAE_BF16_BIG=60: all four) and with
+    the per-tile / two-workgroup kernels (0): the running statistics — sums over ALL pixels, merged from differently grouped partials — must agree
+    to fp32 summation noise, the outputs to bf16 noise.  A wrong count or a wrong partial row would be off by whole percents."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mask in ("60", "0"):
+        out = str(tmp_path / f"bn_{mask}.npz")
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "bn_geom_worker.py"), str(W), str(B), out],
+                           env=dict(os.environ, CVAE_BF16_BIG=mask), capture_output=True, text=True, timeout=300, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res[mask] = np.load(out)
+    a, b = res["60"], res["0"]
+    for bi in (1, 5, 9, 13):
+        for k in (f"rm{bi}", f"rv{bi}"):
+            scale = max(float(np.abs(b[k]).max()), 1e-6)
+            assert np.abs(a[k] - b[k]).max() <= 2e-4 * scale, (k, float(np.abs(a[k] - b[k]).max()), scale)
+    assert np.abs(a["mu"] - b["mu"]).max() < 2e-2 and np.abs(a["logvar"] - b["logvar"]).max() < 2e-2
+
+
 def test_bn_pool_ops_follow_the_handle_storage_type():
     """The stand-alone BatchNorm/pool ops of a bf16-storage handle read and write bf16 tensors (as the step does):
     eval-mode forward (coefficients from the running statistics) and the backward apply pass against a torch

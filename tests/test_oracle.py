@@ -63,6 +63,25 @@ def real_frames_params(fx):
     return pn
 
 
+def test_training_on_the_references_real_frames_first_steps(golden_dir):
+    """tests/golden/train_real_b68.npz (200 reference Adam steps on the 68 real frames): the oracle's train_step + adam_step reproduce the first
+    three loss triples (same thread count as the generating run: bit-identical there; 1e-6 here), and the fixture says the reference stays finite."""
+    fx = np.load(os.path.join(golden_dir, "step_real_b68.npz"))
+    tf = np.load(os.path.join(golden_dir, "train_real_b68.npz"))
+    assert int(tf["first_nonfinite_step"]) == -1 and tf["traj"].shape == (int(tf["steps"]), 3)
+    x = orc.preprocess_frames(torch.from_numpy(fx["u8"]))
+    pred = torch.from_numpy(fx["pred"])
+    p = orc.to_torch(real_frames_params(fx), requires_grad=True)
+    state, bn = {}, orc.new_bn_state(p)
+    for s in range(3):
+        eps = torch.from_numpy(synth.make_batch(int(tf["dseed"]), s, 68)[2])
+        orc.zero_grad(p)
+        o = orc.train_step(p, x, pred, eps, bn_state=bn)
+        orc.adam_step(p, state, lr=float(tf["lr"]))
+        got = np.array([o["total_loss"].item(), o["recon_loss"].item(), o["KLD"].item()])
+        assert np.abs(got - tf["traj"][s]).max() < 1e-5, (s, got, tf["traj"][s])
+
+
 def test_step_on_the_references_real_frames(golden_dir):
     """tests/golden/step_real_b68.npz: the reference's own 68 evaluation frames (source-images/*.jpg) through its own
     pre-processing, predictions of its Critic with the real checkpoint, its forward / vae_loss / backward

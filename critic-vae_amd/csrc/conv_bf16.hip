@@ -994,38 +994,62 @@ int launch_conv_up_dgrad_bf16(int layer, int width, int ns, int B, const float* 
 
 // WT_NW waves per workgroup (4: two workgroups per CU, 8 accumulator tiles per wave; 8: one workgroup per CU whose
 // 8 waves share every staged tile, 5 accumulator tiles per wave — better for the 32-channel layer E2)
+#ifndef WGRAD_PIPE
+#define WGRAD_PIPE 2       // input fragments requested this many MFMA slots ahead (0: round-4 form — request, wait, MFMA)
+#endif
 template <int H, int WT_NW, int W, int COB>
 __device__ __forceinline__ void wgrad_tr_body(f32x16 (&acc)[COB][24 / WT_NW + 2], const __bf16* lds_in, const __bf16* lds_d, int ibase, int dbase,
                                               bf16x8 ones) {
     using T = WtTile<H>;
     constexpr int JT = 24 / WT_NW;
     static_assert(T::KG % WT_NW == 0, "pixel groups per tile must split evenly over the waves");
+    // A slot = one input fragment (two transposed reads) and its COB MFMAs: the JT taps of this wave for every pixel group.
+    // Round 5: the fragment of slot n + WGRAD_PIPE is requested before the MFMAs of slot n and the dy fragments of the
+    // next pixel group half a group ahead, pinned (one MFMA, then its share of reads).  Round 4 left the order to the compiler, which emitted
+    // request -> s_waitcnt lgkmcnt(0) -> MFMA for every slot: a wave's MFMA sat behind the full latency of its own transposed reads and the
+    // matrix pipe was busy 47-58 % with two waves per SIMD (profiles/r04_m_pmc_summary_bf16.csv).
+    auto in_frag = [&](int kg, int tap) {
+        const int r = tap / 5, s = tap % 5;
+        const __bf16* q = lds_in + ibase + T::halobase(kg) * 32 + (r * T::HTW + s) * 32;
+        return tr_frag(q, q + T::IT * 32);
+    };
+    auto dy_frag = [&](int kg, int cb) {
+        const __bf16* dp = lds_d + cb * T::NPX * 32 + dbase + T::pixbase(kg) * 32;
+        return tr_frag(dp, dp + T::DT * 32);
+    };
+    constexpr int NSLOT = T::KG * JT, PD = WGRAD_PIPE, RING = PD + 1;        // the regular slots: n = kg * JT + j (tap 24 rides outside the pipeline)
+    bf16x8 av[RING], bv[2][COB];
+#pragma unroll
+    for (int cb = 0; cb < COB; ++cb) bv[0][cb] = dy_frag(0, cb);
+#pragma unroll
+    for (int k = 0; k < PD; ++k) av[k % RING] = in_frag(k / JT, WT_NW * (k % JT) + W);
 #pragma unroll
     for (int kg = 0; kg < T::KG; ++kg) {
-        bf16x8 bv[COB];
-#pragma unroll
-        for (int cb = 0; cb < COB; ++cb) {               // one [pixel][32 co] image per output-channel block
-            const __bf16* dp = lds_d + cb * T::NPX * 32 + dbase + T::pixbase(kg) * 32;
-            bv[cb] = tr_frag(dp, dp + T::DT * 32);
-        }
-        const __bf16* ip = lds_in + ibase + T::halobase(kg) * 32;
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
-            const int tap = WT_NW * j + W, r = tap / 5, s = tap % 5;
-            const __bf16* q = ip + (r * T::HTW + s) * 32;
-            const bf16x8 av = tr_frag(q, q + T::IT * 32);                    // one staged / fetched input fragment serves COB MFMAs
+            const int n = kg * JT + j, na = n + PD;
+            if (na < NSLOT) av[na % RING] = in_frag(na / JT, WT_NW * (na % JT) + W);
+            if (j == JT / 2 && kg + 1 < T::KG) {
 #pragma unroll
-            for (int cb = 0; cb < COB; ++cb) acc[cb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[cb], acc[cb][j], 0, 0, 0);
+                for (int cb = 0; cb < COB; ++cb) bv[(kg + 1) & 1][cb] = dy_frag(kg + 1, cb);
+            }
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb)
+                acc[cb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[n % RING], bv[kg & 1][cb], acc[cb][j], 0, 0, 0);
+            if constexpr (PD > 0) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                if (j == JT / 2 && kg + 1 < T::KG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * COB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, COB, 0);
+            }
         }
-        if ((kg % WT_NW) == W) {
-            const __bf16* q = ip + (4 * T::HTW + 4) * 32;
-            const bf16x8 av = tr_frag(q, q + T::IT * 32);
+        if ((kg % WT_NW) == W) {                                // tap 24: every WT_NW-th pixel group of this wave (1 / 25 of the MFMAs, unpipelined)
+            const bf16x8 a24 = in_frag(kg, 24);
 #pragma unroll
-            for (int cb = 0; cb < COB; ++cb) acc[cb][JT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[cb], acc[cb][JT], 0, 0, 0);
+            for (int cb = 0; cb < COB; ++cb) acc[cb][JT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a24, bv[kg & 1][cb], acc[cb][JT], 0, 0, 0);
         }
         if ((kg % WT_NW) == ((W + 1) % WT_NW)) {
 #pragma unroll
-            for (int cb = 0; cb < COB; ++cb) acc[cb][JT + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bv[cb], acc[cb][JT + 1], 0, 0, 0);
+            for (int cb = 0; cb < COB; ++cb) acc[cb][JT + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bv[kg & 1][cb], acc[cb][JT + 1], 0, 0, 0);
         }
     }
 }

@@ -73,6 +73,7 @@ struct WsLayout {
     int64_t zcat, h, o[4];
     int64_t dout4, d_o[4], d_h, d_zcat, d_a[4], d_y[4];
     int64_t wc[3];             // phase-collapsed weights of D1..D3 (rebuilt every forward)
+    int64_t xp;                // bf16 mode: the frame as packed bf16 (r, g, b, 0) pixels, written by E1's statistics pass (B * W * W * 8 bytes)
     int64_t wpack;             // bf16 mode: packed E2..E4 / D0 weights, forward + dgrad orientation (rebuilt every forward)
     int64_t ms, scratch_w, scratch, total;     // scratch_w: wgrad slabs (side stream); scratch: everything else (last)
 };
@@ -149,6 +150,7 @@ static WsLayout carve(const cvae_handle_s* h, int B) {
     }
     w.dout4 = take(b16 ? 0 : (int64_t)B * 3 * W * W);          // bf16 mode applies the Tanh backward inside d4_bwd: no dOut tensor
     for (int i = 0; i < 3; ++i) w.wc[i] = take(conv_up_wc_floats(5 + i));
+    w.xp = take(b16 ? (int64_t)B * W * W * 2 : 0);
     w.wpack = take(h->cfg.precision != 0 ? conv_bf16_pack_floats(h->cfg.precision >= 2 ? 3 : 1) : 0);
     w.ms = take(msssim_ws_floats(W, B));
     int64_t sc = 0, scw = 0;
@@ -309,14 +311,14 @@ int cvae_forward(cvae_handle h, int32_t B, const float* x, const float* pred, co
         if (l == 0 && h->e1_two_pass) {
             // bf16 mode, block 0: conv (statistics only) -> merged statistics -> conv again with BatchNorm/pool/ReLU in its
             // epilogue (writes y0 for the backward and a0); bn_pool_act_fwd's read of y0 is replaced by a second read of x
-            if (train) RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), nullptr, ws + w.bnpart[0], st, true, 1));
+            if (train) RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), nullptr, ws + w.bnpart[0], st, true, 1, nullptr, nullptr, true, ws + w.xp));     // also writes the packed bf16 frame
             RC(launch_bn_fwd_finalize(0, W, B, ws + w.bnpart[0], P_(h->enc_g[0]), P_(h->enc_be[0]), bn_state + kBnOff[0],
                                       bn_state + 480 + kBnOff[0], ws + w.coef[0], ws + w.scratch, train, st));
             { ProbeArm pa(h, 0, 0);
               // y0 is written only for the CVAE_FUSE_E1=0 path (or, decided on the device, when a channel's gamma is tiny):
               // the fused weight-gradient kernel recomputes it
               RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], nullptr, st, true, 2, ws + w.coef[0], ws + w.a[0],
-                               !h->fuse_e1)); }
+                               !h->fuse_e1, train ? ws + w.xp : nullptr)); }          // eval mode: no statistics pass, no packed frame
             continue;
         }
         if (l == 0) { ProbeArm pa(h, 0, 0); RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), ws + w.y[0], ws + w.bnpart[0], st, h->cfg.precision == 1)); }
@@ -511,7 +513,8 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
             const float* fu[7] = {ws + w.y[0], ws + w.a[0], ws + w.d_a[0], ws + w.coef[0], bn_bwd_bcoef(0, W, B, sc),
                                   P_(h->enc_w[0]), P_(h->enc_b[0])};
             { ProbeArm pa(h, 2, 0); RedArm ra(h, side_red, &red_pending, st); ra.arm(&sred);
-              RC(launch_e1_wgrad(W, B, x, fuse0 ? nullptr : ws + w.d_y[0], G_(h->enc_w[0]), G_(h->enc_b[0]), scw, sd, h->cfg.precision == 1, fuse0 ? fu : nullptr)); }
+              RC(launch_e1_wgrad(W, B, x, fuse0 ? nullptr : ws + w.d_y[0], G_(h->enc_w[0]), G_(h->enc_b[0]), scw, sd, h->cfg.precision == 1, fuse0 ? fu : nullptr,
+                                 (h->e1_two_pass && fuse0) ? ws + w.xp : nullptr)); }
         } else {
             { ProbeArm pa(h, 2, l); RedArm ra(h, side_red, &red_pending, st); ra.arm(&sred);
               if (use_bf16_wgrad(h, l)) RC(launch_conv_wgrad_bf16(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd));

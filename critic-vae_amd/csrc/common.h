@@ -212,11 +212,13 @@ int launch_col_reduce(const float* in, int R, int W, int64_t stride, float* out,
 // conv_thin.hip (E1 / D4)
 int launch_e1_fwd(int width, int B, const float* x, const float* w, const float* bias, float* y,
                   float* bnpart, hipStream_t st, bool bf16 = false, int pass = 0, const float* coef = nullptr, float* a1 = nullptr,
-                  bool keep_y = true);
-                  // bf16 mode: pass 1 = BatchNorm partials only, pass 2 = fused BatchNorm/pool/ReLU -> a1 (needs coef); y is written
+                  bool keep_y = true, float* xp = nullptr);
+                  // bf16 mode: pass 1 = BatchNorm partials only (+ writes the packed bf16 frame xp, B*width*width*8 bytes of workspace),
+                  // pass 2 = fused BatchNorm/pool/ReLU -> a1 (needs coef; stages its strips from xp); y is written
                   // by pass 2 only if keep_y or a channel has |gamma| < 1e-2 (the backward's statistics then read it)
 int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw, float* dbias, float* ws,
-                    hipStream_t st, bool bf16 = false, const float* const* fuse = nullptr);   // fuse: {y0, a0, d_a0, coef0, bcoef0, w1, b1}, dy unused
+                    hipStream_t st, bool bf16 = false, const float* const* fuse = nullptr,    // fuse: {y0, a0, d_a0, coef0, bcoef0, w1, b1}, dy unused
+                    const float* xp = nullptr);                                               // bf16 mode: the packed frame of launch_e1_fwd's pass 1, or null
                     // (bf16 mode recomputes y0 from x, w1, b1 and never reads fuse[0])
 const float* bn_bwd_bcoef(int layer, int width, int B, const float* ws);                       // where launch_bn_pool_act_bwd left (k1, k2)
 int64_t e1_wgrad_ws_floats(int width, int B);

@@ -170,14 +170,22 @@ __device__ __forceinline__ f32x16 e1_wk_conv(const bf16x4* __restrict__ p, int l
     return acc;
 }
 
-enum { E1_Y = 0, E1_STATS = 1, E1_POOL = 2 };
+typedef float f32x2t __attribute__((ext_vector_type(2)));
+enum { E1_Y = 0, E1_STATS = 1, E1_POOL = 2, E1_POOL_X = 3 };      // E1_POOL_X: the pool pass staging its strips from the fp32 frame (eval mode: no statistics pass ran)
 template <int H, int PASS>
 __global__ __launch_bounds__(256, PASS == 1 ? 3 : 2) void e1_fwd_bf16_kernel(      // statistics pass: 3 workgroups per CU (<= 168 VGPRs)
                                                          const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           float* __restrict__ bnpart, int B,
-                                                          const float* __restrict__ coef, float* __restrict__ a1, int numStrips, int keepY) {
+                                                          const float* __restrict__ coef, float* __restrict__ a1, int numStrips, int keepY,
+                                                          bf16x4* __restrict__ xp) {
+    // xp (round 5): the frame as packed bf16 pixels (r, g, b, 0) = the LDS unit of this kernel, 8 bytes per pixel, in the workspace.  The
+    // statistics pass writes it from the strip it stages anyway (interior pixels: one 8-byte store per pixel and step); the pool pass and
+    // E1's weight-gradient kernel then stage their strips as plain 8-byte units — buffer loads whose padding lanes carry an out-of-range
+    // offset (the load returns 0) — instead of three 4-byte plane loads + three conversions + a select per pixel, three times per step.
+    // The operands are bit-identical (x is rounded to bf16 exactly once either way).
     constexpr int SR = 16, SW = 32, HR_ = SR + 4, HWX = 40;
+    constexpr bool XP_RD = PASS == E1_POOL, XP_WR = PASS == E1_STATS, POOL = PASS == E1_POOL || PASS == E1_POOL_X;
     constexpr int SX = H / SW, SY = H / SR;
     __shared__ __attribute__((aligned(16))) bf16x4 lds_x[HR_ * HWX];
     __shared__ __attribute__((aligned(16))) float patch_all[4 * 32 * 36];
@@ -189,16 +197,31 @@ __global__ __launch_bounds__(256, PASS == 1 ? 3 : 2) void e1_fwd_bf16_kernel(   
     e1_wk_load(w, li, lh, bw);
     const float bv = bias[li];
     bool wr_y = PASS != E1_STATS;
-    if constexpr (PASS == E1_POOL) {
+    if constexpr (POOL) {
         const float gam = coef[li * 4] / coef[li * 4 + 3];             // gamma = scale / invstd, as bn.hip's backward tests it
         wr_y = keepY != 0 || __any(!(fabsf(gam) >= 1e-2f));           // the same answer in every wave (a wave spans all 32 channels)
     }
     constexpr int NIT = (HR_ * HWX + 255) / 256;
     float v0[NIT], v1[NIT], v2[NIT];
+    typedef unsigned u32x2x __attribute__((ext_vector_type(2)));
+    [[maybe_unused]] u32x2x pk[NIT];            // XP_RD: the strip's packed units
     unsigned okm = 0u;                          // validity bit per staged unit (frame pixels vs zero padding)
+    constexpr unsigned XP_BIAS = (2 * H + 2) * 8;       // the descriptor starts this far in front of xp: halo offsets are non-negative lane offsets
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_xp =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(xp) - XP_BIAS, 0, (int)((size_t)B * H * H * 8 + XP_BIAS), 0x00020000);
     auto fetch = [&](int strip) {                // all loads first (clamped address), the LDS writes (+ zero select) follow later
         const int ib = strip / (SX * SY), t = strip % (SX * SY);
         const int ty0 = (t / SX) * SR, tx0 = (t % SX) * SW;
+        if constexpr (XP_RD) {
+            const unsigned soff = (unsigned)(((ib * H + ty0) * H + tx0) * 8);
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int q = tid + i * 256, hy = q / HWX, hx = q % HWX;
+                const bool ok = q < HR_ * HWX && (unsigned)(ty0 + hy - 2) < (unsigned)H && (unsigned)(tx0 + hx - 2) < (unsigned)H;
+                pk[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_xp, ok ? (unsigned)(((hy - 2) * H + hx - 2) * 8 + (int)XP_BIAS) : 0x80000000u, soff, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int q = tid + i * 256, hy = q / HWX, hx = q % HWX;
@@ -227,8 +250,19 @@ __global__ __launch_bounds__(256, PASS == 1 ? 3 : 2) void e1_fwd_bf16_kernel(   
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int q = tid + i * 256;
-            const bool ok = (okm >> i) & 1u;
-            if (q < HR_ * HWX) { bf16x4 u; u[0] = (__bf16)(ok ? v0[i] : 0.f); u[1] = (__bf16)(ok ? v1[i] : 0.f); u[2] = (__bf16)(ok ? v2[i] : 0.f); u[3] = (__bf16)0.f; lds_x[q] = u; }
+            if constexpr (XP_RD) {
+                if (q < HR_ * HWX) lds_x[q] = __builtin_bit_cast(bf16x4, pk[i]);
+            } else {
+                const bool ok = (okm >> i) & 1u;
+                bf16x4 u; u[0] = (__bf16)(ok ? v0[i] : 0.f); u[1] = (__bf16)(ok ? v1[i] : 0.f); u[2] = (__bf16)(ok ? v2[i] : 0.f); u[3] = (__bf16)0.f;
+                if (q < HR_ * HWX) lds_x[q] = u;
+                if constexpr (XP_WR) {               // the strip's own 16 x 32 pixels (every pixel of the frame is interior to exactly one strip)
+                    const int hy = q / HWX, hx = q % HWX;
+                    const bool mine = xp != nullptr && q < HR_ * HWX && hy >= 2 && hy < SR + 2 && hx >= 2 && hx < SW + 2;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2x, u), rs_xp,
+                        mine ? (unsigned)(((ib * H + ty0 + hy - 2) * H + tx0 + hx - 2) * 8 + (int)XP_BIAS) : 0x80000000u, 0, 0);
+                }
+            }
         }
         __syncthreads();
         if (n + G < numStrips) fetch(strip + sstep);
@@ -236,31 +270,49 @@ __global__ __launch_bounds__(256, PASS == 1 ? 3 : 2) void e1_fwd_bf16_kernel(   
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) acc[rr] = e1_wk_conv<HWX>(lds_x + (wave * 4 + rr) * HWX + li, lh, bw);
         // epilogue: element v of lane (li, lh) in tile r = pixel column (v&3)+8*(v>>2)+4*lh of row 4*wave+r, channel li
-        float s = 0.f;
+        // BatchNorm partial of the strip (sum, M2 about its mean) — round 5: ONE pass of packed sums over the raw accumulators (S0, Q0 of
+        // conv without the bias: M2 = Q0 - S0^2 / n is shift-invariant and better conditioned without it, the bias re-enters the sum as
+        // n * bias), one barrier; rounds 2-4 added the bias first, summed, met, subtracted the strip mean and summed squares behind a
+        // second barrier: ~190 more VALU instructions per wave and strip in a kernel that is issue-bound at three waves per SIMD.
+        if constexpr (!POOL) {
+            f32x2t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int v = 0; v < 16; v += 2) {
+                    const f32x2t xx = {acc[r][v], acc[r][v + 1]};
+                    s2 += xx;
+                    q2 = __builtin_elementwise_fma(xx, xx, q2);
+                }
+            float S0 = s2.x + s2.y, Q0 = q2.x + q2.y;
+            S0 += __shfl_xor(S0, 32, 64); Q0 += __shfl_xor(Q0, 32, 64);
+            if (lh == 0) { red[0][wave][li] = S0; red[1][wave][li] = Q0; }
+        }
         float* patch = patch_all + wave * (32 * 36);
+        if (POOL || wr_y) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const float val = acc[r][v] + bv;
-                acc[r][v] = val;
-                s += val;
-                if (wr_y) patch[((v & 3) + 8 * (v >> 2) + 4 * lh) * 36 + li] = val;
-            }
-            if (!wr_y) continue;
-            const int gy = ty0 + wave * 4 + r;
+                for (int v = 0; v < 16; ++v) {
+                    const float val = acc[r][v] + bv;
+                    acc[r][v] = val;
+                    if (wr_y) patch[((v & 3) + 8 * (v >> 2) + 4 * lh) * 36 + li] = val;
+                }
+                if (!wr_y) continue;
+                const int gy = ty0 + wave * 4 + r;
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int idx = it * 64 + lane, px = idx >> 2, c8 = idx & 3;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(patch + px * 36 + c8 * 8);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(patch + px * 36 + c8 * 8 + 4);
-                bf16x8 o;
+                for (int it = 0; it < 2; ++it) {
+                    const int idx = it * 64 + lane, px = idx >> 2, c8 = idx & 3;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(patch + px * 36 + c8 * 8);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(patch + px * 36 + c8 * 8 + 4);
+                    bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { o[e] = (__bf16)lo[e]; o[4 + e] = (__bf16)hi[e]; }
-                Act<__bf16>::st8(y, ((size_t)(ib * H + gy) * H + tx0 + px) * 32 + c8 * 8, o);
+                    for (int e = 0; e < 4; ++e) { o[e] = (__bf16)lo[e]; o[4 + e] = (__bf16)hi[e]; }
+                    Act<__bf16>::st8(y, ((size_t)(ib * H + gy) * H + tx0 + px) * 32 + c8 * 8, o);
+                }
             }
         }
-        if constexpr (PASS == E1_POOL) {
+        if constexpr (POOL) {
             // BatchNorm + 2x2 max + ReLU of this wave's 4 rows x 32 columns: both rows and both columns of a window sit in
             // this lane's accumulators (rows 2q / 2q+1, elements v / v+1 for even v)
             const float sc = coef[li * 4], sh = coef[li * 4 + 1];
@@ -291,21 +343,13 @@ __global__ __launch_bounds__(256, PASS == 1 ? 3 : 2) void e1_fwd_bf16_kernel(   
             }
             continue;                                        // the statistics came from the E1_STATS pass
         }
-        s += __shfl_xor(s, 32, 64);
-        if (lh == 0) red[0][wave][li] = s;
-        __syncthreads();
-        const float mean = ((red[0][0][li] + red[0][1][li]) + (red[0][2][li] + red[0][3][li])) * (1.0f / (SR * SW));
-        float m2 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) { const float d = acc[r][v] - mean; m2 += d * d; }
-        m2 += __shfl_xor(m2, 32, 64);
-        if (lh == 0) red[1][wave][li] = m2;
         __syncthreads();
         if (tid < 32) {
-            bnpart[(size_t)strip * 32 + tid] = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
-            bnpart[((size_t)numStrips + strip) * 32 + tid] = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+            const float S = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
+            const float Q = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+            const double m2 = (double)Q - (double)S * (double)S * (1.0 / (SR * SW));
+            bnpart[(size_t)strip * 32 + tid] = S + (float)(SR * SW) * bias[tid];
+            bnpart[((size_t)numStrips + strip) * 32 + tid] = (float)(m2 > 0.0 ? m2 : 0.0);
         }
     }
     (void)B;
@@ -319,6 +363,7 @@ struct ThinWgradArgs {
     float* din;          // D4: d_o3 (NHWC, 32)
     float* slab;         // [S][96][32]
     int B, numTiles, tilesPerSplit;
+    const void* xp = nullptr;      // E1, bf16 mode: the packed bf16 frame (r, g, b, 0) the forward's statistics pass wrote, or null
 };
 
 // sum acc[3] over the 4 waves (through LDS, fixed order) and write the block's slab
@@ -521,11 +566,10 @@ static constexpr int E1W_ROW = 128 * 32;
 //   3. dy never leaves the registers: the weight-gradient MFMA contracts over pixels in any order, so accumulator elements
 //      8ks .. 8ks+7 of every lane ARE its B fragment of k-step ks (quadrant row ks), and the transposed reads of the A operand
 //      fetch the pixels in that order (an earlier form stored dy to LDS channel-major and read it back behind a third barrier).
-typedef float f32x2t __attribute__((ext_vector_type(2)));
 #ifndef E1W_OCC
 #define E1W_OCC 3          // workgroups per CU of the bf16 E1 weight-gradient kernel (VGPR budget 512 / (E1W_OCC) per lane; splits = E1W_OCC * CUs)
 #endif
-template <int H, bool FUSE>
+template <int H, bool FUSE, bool XP>          // XP: the strip comes from the packed bf16 frame the forward's statistics pass left in the workspace (a.xp)
 __global__ __launch_bounds__(256, E1W_OCC) void e1_wgrad_bf16_kernel(ThinWgradArgs a, E1Fuse fu) {
     using T = Tile<H>;
     static_assert(T::TW == 32 && T::TH == 4 && T::IMGS == 1, "one tile row per wave");
@@ -560,6 +604,11 @@ __global__ __launch_bounds__(256, E1W_OCC) void e1_wgrad_bf16_kernel(ThinWgradAr
     int t1 = t0 + a.tilesPerSplit; if (t1 > a.numTiles) t1 = a.numTiles;
     constexpr int XQ = (NPXH + 255) / 256;
     float rx[XQ][3];
+    typedef unsigned u32x2x __attribute__((ext_vector_type(2)));
+    [[maybe_unused]] u32x2x pk[XQ];
+    constexpr unsigned XP_BIAS = (2 * H + 2) * 8;
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_xp =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.xp)) - XP_BIAS, 0, (int)((size_t)a.B * H * H * 8 + XP_BIAS), 0x00020000);
     unsigned okm = 0u;                               // validity bit per staged strip unit
     bf16x8 rd[2];
     bf16x8 rp;                                       // FUSE: 8 channels of one pooled pixel of a0 (threads 0..127) / d_a0 (128..255)
@@ -576,6 +625,15 @@ __global__ __launch_bounds__(256, E1W_OCC) void e1_wgrad_bf16_kernel(ThinWgradAr
     auto fetch = [&](int mt) {
         const int ib = mt / T::TILES_PER_IMG, tileInImg = mt % T::TILES_PER_IMG;
         const int ty0 = (tileInImg / T::TILES_X) * T::TH, tx0 = (tileInImg % T::TILES_X) * T::TW;
+        if constexpr (XP) {                        // 8-byte units, zero padding = an out-of-range lane offset (e1_fwd_bf16_kernel)
+            const unsigned soff = (unsigned)(((ib * H + ty0) * H + tx0) * 8);
+#pragma unroll
+            for (int i = 0; i < XQ; ++i) {
+                const int q = tid + i * 256, hy = q / HWX, hx = q % HWX;
+                const bool ok = q < NPXH && (unsigned)(ty0 + hy - 2) < (unsigned)H && (unsigned)(tx0 + hx - 2) < (unsigned)H;
+                pk[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_xp, ok ? (unsigned)(((hy - 2) * H + hx - 2) * 8 + (int)XP_BIAS) : 0x80000000u, soff, 0);
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < XQ; ++i) {
             const int q = tid + i * 256, hy = q / HWX, hx = q % HWX;
@@ -585,6 +643,7 @@ __global__ __launch_bounds__(256, E1W_OCC) void e1_wgrad_bf16_kernel(ThinWgradAr
             // raw values; the zero padding is selected at staging time (see e1_fwd_bf16_kernel: a select here exposes the load latency)
             rx[i][0] = a.a0[e]; rx[i][1] = a.a0[e + (size_t)H * H]; rx[i][2] = a.a0[e + 2 * (size_t)H * H];
             okm = ok ? (okm | (1u << i)) : (okm & ~(1u << i));
+        }
         }
         if constexpr (FUSE) {
             const int t = tid & 127, pp = t >> 2, c8 = t & 3;            // pooled pixel pp = prow*16 + pcol of the tile's 2 x 16
@@ -606,8 +665,12 @@ __global__ __launch_bounds__(256, E1W_OCC) void e1_wgrad_bf16_kernel(ThinWgradAr
 #pragma unroll
         for (int i = 0; i < XQ; ++i) {
             const int q = tid + i * 256;
-            const bool ok = (okm >> i) & 1u;
-            if (q < NPXH) { bf16x4 u; u[0] = (__bf16)(ok ? rx[i][0] : 0.f); u[1] = (__bf16)(ok ? rx[i][1] : 0.f); u[2] = (__bf16)(ok ? rx[i][2] : 0.f); u[3] = (__bf16)0.f; lds_x[q] = u; }
+            if constexpr (XP) {
+                if (q < NPXH) lds_x[q] = __builtin_bit_cast(bf16x4, pk[i]);
+            } else {
+                const bool ok = (okm >> i) & 1u;
+                if (q < NPXH) { bf16x4 u; u[0] = (__bf16)(ok ? rx[i][0] : 0.f); u[1] = (__bf16)(ok ? rx[i][1] : 0.f); u[2] = (__bf16)(ok ? rx[i][2] : 0.f); u[3] = (__bf16)0.f; lds_x[q] = u; }
+            }
         }
         if constexpr (FUSE) {
             *reinterpret_cast<bf16x8*>(lds_p + (size_t)tid * 8) = rp;       // [a0 | d_a0][pp][32]: thread order IS the layout
@@ -763,18 +826,23 @@ int64_t e1_wgrad_ws_floats(int width, int B) {
 }
 
 int launch_e1_fwd(int width, int B, const float* x, const float* w, const float* bias, float* y,
-                  float* bnpart, hipStream_t st, bool bf16, int pass, const float* coef, float* a1, bool keep_y) {
+                  float* bnpart, hipStream_t st, bool bf16, int pass, const float* coef, float* a1, bool keep_y, float* xpf) {
+    bf16x4* xp = reinterpret_cast<bf16x4*>(xpf);          // packed bf16 frame (workspace): written by pass 1, read by pass 2; null: pass 2 is not available
     const int keepY = keep_y ? 1 : 0;
     if (pass != 0 && !bf16) { cvae_set_error("e1_fwd: passes 1/2 exist in bf16 mode only"); return -2; }
+    if (pass < 0 || pass > 2) { cvae_set_error("e1_fwd: pass %d", pass); return -2; }
+    if (pass == 2 && !xp) pass = 3;                       // no packed frame (eval mode: no statistics pass ran): the pool pass stages from the fp32 frame
     const int ns64 = B * 8, ns128 = B * 32, cap = cvae_num_cus() * 3;      // persistent: 3 workgroups per CU (<= 168 VGPRs), one strip each per turn
     const dim3 g64(ns64 < cap ? ns64 : cap), g128(ns128 < cap ? ns128 : cap);
     cvae_probe_begin(st);
-    if (width == 64 && bf16 && pass == 1) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_STATS>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64, keepY);
-    else if (width == 64 && bf16 && pass == 2) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_POOL>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64, keepY);
-    else if (width == 128 && bf16 && pass == 1) hipLaunchKernelGGL((e1_fwd_bf16_kernel<128, E1_STATS>), g128, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns128, keepY);
-    else if (width == 128 && bf16 && pass == 2) hipLaunchKernelGGL((e1_fwd_bf16_kernel<128, E1_POOL>), g128, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns128, keepY);
-    else if (width == 64 && bf16) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_Y>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64, keepY);
-    else if (width == 128 && bf16) hipLaunchKernelGGL((e1_fwd_bf16_kernel<128, E1_Y>), g128, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns128, keepY);
+    if (width == 64 && bf16 && pass == 1) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_STATS>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64, keepY, xp);
+    else if (width == 64 && bf16 && pass == 2) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_POOL>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64, keepY, xp);
+    else if (width == 128 && bf16 && pass == 1) hipLaunchKernelGGL((e1_fwd_bf16_kernel<128, E1_STATS>), g128, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns128, keepY, xp);
+    else if (width == 128 && bf16 && pass == 2) hipLaunchKernelGGL((e1_fwd_bf16_kernel<128, E1_POOL>), g128, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns128, keepY, xp);
+    else if (width == 64 && bf16 && pass == 3) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_POOL_X>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64, keepY, xp);
+    else if (width == 128 && bf16 && pass == 3) hipLaunchKernelGGL((e1_fwd_bf16_kernel<128, E1_POOL_X>), g128, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns128, keepY, xp);
+    else if (width == 64 && bf16) hipLaunchKernelGGL((e1_fwd_bf16_kernel<64, E1_Y>), g64, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns64, keepY, xp);
+    else if (width == 128 && bf16) hipLaunchKernelGGL((e1_fwd_bf16_kernel<128, E1_Y>), g128, dim3(256), 0, st, x, w, bias, y, bnpart, B, coef, a1, ns128, keepY, xp);
     else if (width == 64) hipLaunchKernelGGL(e1_fwd_kernel<64>, dim3(B * 8), dim3(256), 0, st, x, w, bias, y, bnpart, B);
     else if (width == 128) hipLaunchKernelGGL(e1_fwd_kernel<128>, dim3(B * 32), dim3(256), 0, st, x, w, bias, y, bnpart, B);
     else { cvae_set_error("e1_fwd: width %d unsupported", width); return -2; }
@@ -784,20 +852,22 @@ int launch_e1_fwd(int width, int B, const float* x, const float* w, const float*
 }
 
 int launch_e1_wgrad(int width, int B, const float* x, const float* dy, float* dw, float* dbias, float* ws, hipStream_t st, bool bf16,
-                    const float* const* fuse) {
+                    const float* const* fuse, const float* xp) {
     if (width != 64 && width != 128) { cvae_set_error("e1_wgrad: width %d unsupported", width); return -2; }
     int tps; const int tiles = B * (width / 4) * (width / 32);
     const int S = thin_splits(tiles, &tps, bf16 ? E1W_OCC * cvae_num_cus() : 512);
-    ThinWgradArgs a{x, nullptr, dy, nullptr, nullptr, ws, B, tiles, tps};
+    ThinWgradArgs a{x, nullptr, dy, nullptr, nullptr, ws, B, tiles, tps, xp};
     // fuse = {y0, a0, d_a0, coef0, bcoef0, w1, b1}: block 0's BatchNorm/pool/ReLU backward is applied while staging (no dy
     // tensor); the bf16 kernel recomputes y0 from x, w1, b1 and never reads fuse[0]
     const E1Fuse fu = fuse ? E1Fuse{fuse[0], fuse[1], fuse[2], fuse[3], fuse[4], fuse[5], fuse[6]} : E1Fuse{};
     cvae_probe_begin(st);
     if (bf16) {          // precision mode 1: transposed-read kernel, its own slab layout + a permuting finish
-        if (width == 64 && fuse) hipLaunchKernelGGL((e1_wgrad_bf16_kernel<64, true>), dim3(S), dim3(256), 0, st, a, fu);
-        else if (width == 64) hipLaunchKernelGGL((e1_wgrad_bf16_kernel<64, false>), dim3(S), dim3(256), 0, st, a, fu);
-        else if (fuse) hipLaunchKernelGGL((e1_wgrad_bf16_kernel<128, true>), dim3(S), dim3(256), 0, st, a, fu);
-        else hipLaunchKernelGGL((e1_wgrad_bf16_kernel<128, false>), dim3(S), dim3(256), 0, st, a, fu);
+        if (width == 64 && fuse && xp) hipLaunchKernelGGL((e1_wgrad_bf16_kernel<64, true, true>), dim3(S), dim3(256), 0, st, a, fu);
+        else if (width == 64 && fuse) hipLaunchKernelGGL((e1_wgrad_bf16_kernel<64, true, false>), dim3(S), dim3(256), 0, st, a, fu);
+        else if (width == 64) hipLaunchKernelGGL((e1_wgrad_bf16_kernel<64, false, false>), dim3(S), dim3(256), 0, st, a, fu);
+        else if (fuse && xp) hipLaunchKernelGGL((e1_wgrad_bf16_kernel<128, true, true>), dim3(S), dim3(256), 0, st, a, fu);
+        else if (fuse) hipLaunchKernelGGL((e1_wgrad_bf16_kernel<128, true, false>), dim3(S), dim3(256), 0, st, a, fu);
+        else hipLaunchKernelGGL((e1_wgrad_bf16_kernel<128, false, false>), dim3(S), dim3(256), 0, st, a, fu);
         cvae_probe_end(st);
         CVAE_CHECK_LAUNCH();
         st = cvae_reduce_stream(st);

@@ -90,6 +90,8 @@ struct cvae_handle_s {
     hipEvent_t ev_ready[8] = {}, ev_side = nullptr, ev_red = nullptr, ev_red_done = nullptr;
     bool streams_ready = false;
     bool e1_two_pass = false;        // bf16 mode: E1 forward as statistics pass + fused BatchNorm/pool pass (CVAE_E1_TWO_PASS=0: conv, then bn_pool_act_fwd)
+    const void* xp_ws = nullptr;     // the workspace (and batch) whose packed bf16 frame the last train-mode forward wrote: the backward stages E1's strips from
+    int xp_B = 0;                    // it only then (an eval-mode forward, or another workspace, leaves it stale -> the fp32 frame is staged instead)
     bool fuse_e1 = true;             // block 0's BatchNorm backward applied inside E1's weight-gradient kernel (CVAE_FUSE_E1=0: separate apply pass, for A/B runs)
     bool side_reduce = false;        // weight-gradient slab reductions on the side stream: measured -2.8 % (fp32, B=256) and
                                      // -1.6 % (bf16, B=2048) against in-order launches, so OFF; CVAE_SIDE_REDUCE=1 enables it for A/B runs
@@ -252,6 +254,7 @@ int64_t cvae_ws_offset(cvae_handle h, int32_t batch, const char* name) {
     if (!strcmp(name, "d_h")) return w.d_h;
     if (!strcmp(name, "dout4")) return w.dout4;
     if (!strcmp(name, "scratch")) return w.scratch;
+    if (!strcmp(name, "xp")) return h->cfg.precision == 1 ? w.xp : -1;      // packed bf16 frame (precision mode 1)
     return -1;
 }
 
@@ -312,6 +315,7 @@ int cvae_forward(cvae_handle h, int32_t B, const float* x, const float* pred, co
             // bf16 mode, block 0: conv (statistics only) -> merged statistics -> conv again with BatchNorm/pool/ReLU in its
             // epilogue (writes y0 for the backward and a0); bn_pool_act_fwd's read of y0 is replaced by a second read of x
             if (train) RC(launch_e1_fwd(W, B, x, P_(h->enc_w[0]), P_(h->enc_b[0]), nullptr, ws + w.bnpart[0], st, true, 1, nullptr, nullptr, true, ws + w.xp));     // also writes the packed bf16 frame
+            h->xp_ws = train ? wsv : nullptr; h->xp_B = B;
             RC(launch_bn_fwd_finalize(0, W, B, ws + w.bnpart[0], P_(h->enc_g[0]), P_(h->enc_be[0]), bn_state + kBnOff[0],
                                       bn_state + 480 + kBnOff[0], ws + w.coef[0], ws + w.scratch, train, st));
             { ProbeArm pa(h, 0, 0);
@@ -514,7 +518,7 @@ int cvae_backward_phases(cvae_handle h, int32_t B, const float* x, const float* 
                                   P_(h->enc_w[0]), P_(h->enc_b[0])};
             { ProbeArm pa(h, 2, 0); RedArm ra(h, side_red, &red_pending, st); ra.arm(&sred);
               RC(launch_e1_wgrad(W, B, x, fuse0 ? nullptr : ws + w.d_y[0], G_(h->enc_w[0]), G_(h->enc_b[0]), scw, sd, h->cfg.precision == 1, fuse0 ? fu : nullptr,
-                                 (h->e1_two_pass && fuse0) ? ws + w.xp : nullptr)); }
+                                 (h->e1_two_pass && fuse0 && h->xp_ws == (const void*)ws && h->xp_B == B) ? ws + w.xp : nullptr)); }
         } else {
             { ProbeArm pa(h, 2, l); RedArm ra(h, side_red, &red_pending, st); ra.arm(&sred);
               if (use_bf16_wgrad(h, l)) RC(launch_conv_wgrad_bf16(l, W, B, ws + w.a[l - 1], ws + w.d_y[l], G_(h->enc_w[l]), G_(h->enc_b[l]), scw, sd));

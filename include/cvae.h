@@ -110,7 +110,10 @@ int cvae_loss(cvae_handle h, int32_t batch, const float* x, const float* mu, con
  * `x`, `params` and `ws` MUST be the ones the matching cvae_forward ran on, bit for bit (no optimizer step, no other
  * forward on the same workspace in between): in precision mode 1 the first conv's output y0 is not stored — the E1
  * weight-gradient kernel recomputes it from `x` and the enc0.w / enc0.b of `params` and re-derives block 0's max-pool
- * decisions from those values — and every mode reads the saved activations of that forward from `ws`.
+ * decisions from those values — and every mode reads the saved activations of that forward from `ws`.  (Round 5: in
+ * precision mode 1 a train-mode forward also leaves the frame in `ws` as packed bf16 pixels — 8 bytes per pixel, slot "xp" —
+ * and the backward stages E1's strips from that copy when `ws` and `batch` are the ones of the handle's last train-mode
+ * forward; after an eval-mode forward, or on another workspace, it converts the fp32 `x` itself, as rounds 3-4 did.)
  */
 int cvae_backward(cvae_handle h, int32_t batch, const float* x, const float* pred, const float* eps,
                   const float* params, const float* logvar, const float* recon, const float* d_recon,

@@ -207,6 +207,54 @@ def test_bf16_config2_trains_like_fp32_at_full_batch():
     assert gap < 1.5e-3 and abs(ratio - 1.0) < 5e-4          # measured: max gap 4.7e-4, ratio 0.99999
 
 
+def test_packed_frame_is_the_bf16_rounded_frame_and_survives_an_eval_forward():
+    """Round 5: E1's statistics pass leaves the frame in the workspace as packed bf16 pixels (r, g, b, 0), and the pool pass and E1's weight-gradient
+    kernel stage their strips from that copy.  (1) The copy is exactly the RNE-rounded frame, every pixel once.  (2) A backward that follows an
+    EVAL-mode forward on the same workspace (no statistics pass: the copy is stale) must not read it: the gradients of a train forward + backward are
+    bit-identical whether or not an eval-mode encoder call on OTHER frames ran in between and overwrote nothing... and, the hard case, when the copy
+    is poisoned by hand between forward and backward the backward still uses it only if the handle says it is current — so poisoning after a train
+    forward changes dW1 (the copy IS what the kernel reads), while an eval forward in between makes the kernel fall back to the fp32 frame."""
+    from critic_vae_amd.nets import VariationalAutoencoder
+    from critic_vae_amd.train import FusedTrainer
+    dev = torch.device("cuda:0")
+    B = 6
+    x, pred, eps = (torch.from_numpy(v).to(dev) for v in synth.make_batch(1234, 0, B))
+    vae = VariationalAutoencoder(max_batch=B, seed=0, precision="bf16").to(dev)
+    tr = FusedTrainer(vae)
+    h, theta = vae.handle, vae.theta.data
+
+    def fwd(train):
+        h.forward(B, x, pred, eps, theta, vae.bn_state, tr.mu, tr.logvar, tr.recon, tr.ws, train=train)
+        h.loss(B, x, tr.mu, tr.logvar, tr.recon, tr.ws, tr.scalars, tr.d_recon, tr.d_mu, tr.d_logvar)
+
+    def bwd():
+        h.backward(B, x, pred, eps, theta, tr.logvar, tr.recon, tr.d_recon, tr.d_mu, tr.d_logvar, tr.ws, tr.grads)
+        torch.cuda.synchronize()
+        return tr.grads.clone()
+
+    off = h.lib.cvae_ws_offset(h.h, B, b"xp")
+    assert off >= 0
+    fwd(True)
+    xp = tr.ws.view(torch.bfloat16)[2 * off:2 * off + B * 64 * 64 * 4].view(B, 64, 64, 4)
+    want = torch.cat([x.permute(0, 2, 3, 1).to(torch.bfloat16), torch.zeros(B, 64, 64, 1, device=dev, dtype=torch.bfloat16)], dim=-1)
+    assert torch.equal(xp, want)
+    g_ref = bwd()
+    # the copy is what the kernel stages: poisoning it after a train-mode forward changes E1's weight gradient
+    fwd(True)
+    xp.zero_()
+    g_poison = bwd()
+    assert not torch.equal(g_poison, g_ref)
+    # an eval-mode forward makes the copy stale: the backward converts the fp32 frame itself (poison ignored).  The saved activations of an
+    # eval-mode forward differ from a train-mode one's, so compare against the same sequence without the poison
+    bn0 = vae.bn_state.clone()                     # the eval-mode forward reads the running statistics every train-mode forward moves
+    fwd(True); fwd(False)
+    g_a = bwd()
+    vae.bn_state.copy_(bn0)
+    fwd(True); fwd(False); xp.fill_(3.0)
+    g_b = bwd()
+    assert torch.equal(g_a, g_b)
+
+
 def test_unknown_precisions_are_rejected():
     import ctypes as C
     from critic_vae_amd import lib as cvlib

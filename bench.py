@@ -158,14 +158,15 @@ def hbm_kernel_bytes(pid, B, width, precision, two_pass_e1=True):
     e = 2.0 if precision == "bf16" else 4.0        # activation element size
     W2 = float(width * width)
     x_b, half32 = 3 * W2 * 4.0, (W2 / 4) * 32 * e
+    xp_b = W2 * 8.0                                # bf16 mode: the frame as packed bf16 (r, g, b, 0) pixels, written by E1's statistics pass (round 5)
     if pid in (27, 28, 29, 30):                    # BatchNorm + pool backward apply: read y, a, da; write dy
         c, h = BN_CH_H[pid - 27]
         h = h * width // 64
         return 2.5 * B * h * h * c * e
-    if pid == 0:                                   # E1 forward: fp32 = read x, write y0; bf16 (second pass) = read x, write a0
-        return B * (x_b + (half32 if precision == "bf16" else W2 * 32 * e))
+    if pid == 0:                                   # E1 forward: fp32 = read x, write y0; bf16 (second pass) = read the packed frame, write a0
+        return B * ((xp_b + half32) if precision == "bf16" else (x_b + W2 * 32 * e))
     if pid == 18:                                  # E1 weight gradient with block 0's BatchNorm/pool backward fused:
-        return B * (x_b + 2 * half32 + (0.0 if precision == "bf16" else W2 * 32 * e))   # x, a0, d_a0 (+ y0 in fp32 mode)
+        return B * ((xp_b if precision == "bf16" else x_b + W2 * 32 * e) + 2 * half32)    # x (bf16: its packed copy), a0, d_a0 (+ y0 in fp32 mode)
     if pid == 8:                                   # D4 forward: read o3, write recon
         return B * (half32 + x_b)
     if pid == 17:                                  # D4 backward: read d_recon, recon (or dOut) and o3, write d_o3

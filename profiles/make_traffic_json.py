@@ -66,7 +66,7 @@ def patterns(prec, width):
         p["d4_bwd"] = rf"d4_bwd_kernel<{width}, float>"
     else:
         p["e1_fwd"] = rf"e1_fwd_bf16_kernel<{width}, 2>"
-        p["e1_wgrad"] = rf"e1_wgrad_bf16_kernel<{width}, true>"
+        p["e1_wgrad"] = rf"e1_wgrad_bf16_kernel<{width}, true, true>"
         p["d4_fwd"] = rf"d4_fwd_bf16_kernel<{width}>"
         p["d4_bwd"] = rf"d4_bwd_bf16_kernel<{width}>"
     p["msssim_fwd_level0"] = rf"msssim_(stream|fwd)_kernel<{width}[,>]" if width == 128 else rf"msssim_plane_kernel<{width}, false>"

@@ -57,6 +57,15 @@ int cvae_num_cus() {
     return n;
 }
 
+thread_local bool g_conv_dry = false;
+// include/cvae.h: which kernel family a conv pass of E2..E4 takes at a batch size (host logic only, no device access)
+extern "C" int32_t cvae_conv_route(int32_t precision, int32_t width, int32_t layer, int32_t dgrad, int64_t batch) {
+    if ((width != 64 && width != 128) || layer < 1 || layer > 3 || precision < 0 || precision > 3 || batch < 1 || batch > 0x7fffffffLL) return CVAE_EINVAL;
+    if (precision == 0) return conv_f32_route(layer, width, dgrad != 0, (int)batch);
+    if (precision == 1) return conv_bf16_route(layer, width, dgrad != 0, (int)batch);
+    return 0;                                                  // fp32 emulation (three operand splits): the per-tile kernels
+}
+
 struct SideRed { hipStream_t st; hipEvent_t ev; };
 static thread_local const SideRed* g_side_red = nullptr;
 hipStream_t cvae_reduce_stream(hipStream_t st) {

@@ -183,6 +183,11 @@ int64_t conv_dgrad_ws_floats(int layer, int width, int B);
 bool conv_bf16_supported(int layer, int width);
 int64_t conv_bf16_pack_floats(int ns);
 int launch_pack_w_bf16(const float* const w[4], float* packed, int ns, hipStream_t st);     // ns = 1 (bf16) or 3 (fp32 emulation)
+// cvae_conv_route (host logic only): while set, the persistent launchers return 0 behind their size guards WITHOUT touching the device
+extern thread_local bool g_conv_dry;
+// kernel family the conv launchers pick for E2..E4 (layer 1..3; 4 = D0 at 128 x 128) at batch B: 0 per-tile, 1 two-workgroup persistent, 2 big-tile persistent
+int conv_bf16_route(int layer, int width, bool dgrad, int B);
+int conv_f32_route(int layer, int width, bool dgrad, int B);
 int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, const float* packed, const float* bias, float* out,
                          float* bnpart, float* ws, hipStream_t st, int* tilesPerPartial = nullptr);    // out: 128-pixel tiles per BatchNorm partial row
 int launch_conv_dgrad_bf16(int layer, int width, int ns, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st);

@@ -26,7 +26,8 @@ template <int H, int OCT> struct Bf16Geom {
 
 // conv_bf16_ps.hip: persistent forward / input-gradient kernel of E2..E4 in bf16 mode (returns -100 if the layer has no instantiation)
 int launch_conv_bf16_ps(int layer, int width, bool dgrad, const ConvBf16Args& a, hipStream_t st);
-// conv_bf16_big.hip: 4 x 4 wave-tile kernel (experiment, CVAE_BF16_BIG bit 2: E4 input gradient); -100 if the layer has no instantiation
+// conv_bf16_big.hip: persistent big-tile kernel (16 accumulator tiles per wave; `mask`: the layer bits of CVAE_BF16_BIG for this pass); -100 if the
+// layer has no instantiation, is masked out, or a tensor is too large for its 32-bit offsets
 int launch_conv_bf16_big(int layer, int width, bool dgrad, int mask, const ConvBf16Args& a, hipStream_t st);
 bool conv_bf16_big_has(int layer, int width, bool dgrad, int mask);
 int conv_bf16_big_tiles(int layer, int width, bool dgrad);      // 128-pixel tiles per item (= per BatchNorm partial of its forward passes)

@@ -39,13 +39,14 @@ enum { MODE_STD = 0, MODE_UP_FWD = 1, MODE_UP_DGRAD = 2 };
 #endif
 #ifndef BF16_BIG_DEFAULT
 // CVAE_BF16_BIG: layers on the persistent 16-accumulator-tile kernel (conv_bf16_big.hip) — bit 2 = E4 input gradient, bit 3 = E3 input gradient, bit 4 = E3
-// forward, bit 5 = E4 forward (BatchNorm partials of four tiles each); 0 = the two-workgroup kernels (A/B runs).  Defaults from the un-profiled step on one
-// box, masks alternating (profiles/r05_g_big_mask_sweep.txt): 64 x 64 frames 44 (E4 both passes + E3 input gradient; E3 forward is 19 us faster in-step and the
-// step 0.5 % slower with it — the chip is at its power limit), 128 x 128 frames 52 (E3's input gradient on 8 x 32-wide tiles spills and loses: 487 vs 362 us).
+// forward, bit 5 = E4 forward, bit 6 = E2 forward at 64 x 64 (one BatchNorm partial per item of four / eight tiles); 0 = the two-workgroup kernels (A/B
+// runs).  Defaults from the un-profiled step on one box, masks alternating (profiles/r05_g_big_mask_sweep.txt, r05_k_big_image_layout.txt): 64 x 64 frames 44
+// (E4 both passes + E3 input gradient; E3 forward is 15-19 us faster as a kernel and the step no faster with it — the chip is at its power limit; E2 forward
+// loses as a kernel, 244 vs 205 us), 128 x 128 frames 60 (with the image layout E3's input gradient no longer spills on its 32-row item: +0.5 % on the step).
 #define BF16_BIG_DEFAULT 44
 #endif
 #ifndef BF16_BIG_DEFAULT_W128
-#define BF16_BIG_DEFAULT_W128 52
+#define BF16_BIG_DEFAULT_W128 60
 #endif
 #ifndef BF16_WDMA
 #define BF16_WDMA 0        // 1 (experiment, round 3): weight slabs travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) into a double
@@ -860,6 +861,26 @@ static int bf16_big_mask(int width) {
     static const int big = [] { const char* e = getenv("CVAE_BF16_BIG"); return e ? atoi(e) : -1; }();
     return big >= 0 ? big : (width == 128 ? BF16_BIG_DEFAULT_W128 : BF16_BIG_DEFAULT);
 }
+// E2..E4 forward / input gradient in bf16 mode: the persistent kernel families in the order the launchers try them.  *family = 2 (the big-tile
+// kernel of conv_bf16_big.hip took the layer), 1 (the two-workgroup kernel of conv_bf16_ps.hip did) or 0 (neither serves this layer at this size — no
+// instantiation, masked out, or a tensor of 2 GiB and more: the caller runs the per-tile kernel).  Returns the launch's error code.
+static int try_persistent_bf16(int layer, int width, bool dgrad, const ConvBf16Args& a, hipStream_t st, int* family) {
+    *family = 0;
+    const int big = bf16_big_mask(width);
+    const int m = dgrad ? (big >> 2) & 3 : (big >> 4) & 7;        // bits 2 / 3: E4 / E3 input gradient; bits 4 / 5 / 6: E3 / E4 / E2 forward
+    if (m) { const int rc = launch_conv_bf16_big(layer, width, dgrad, m, a, st); if (rc != -100) { *family = 2; return rc; } }
+    if (use_ps_kernel(layer, dgrad)) { const int rc = launch_conv_bf16_ps(layer, width, dgrad, a, st); if (rc != -100) { *family = 1; return rc; } }
+    return 0;
+}
+int conv_bf16_route(int layer, int width, bool dgrad, int B) {
+    ConvBf16Args a{};
+    a.B = B;
+    int family = 0;
+    g_conv_dry = true;
+    (void)try_persistent_bf16(layer, width, dgrad, a, nullptr, &family);
+    g_conv_dry = false;
+    return family;
+}
 // `tilesPerPartial` (out, may be null): how many 128-pixel tiles one BatchNorm partial row of `bnpart` covers — 1 for the per-tile and the
 // two-workgroup persistent kernels, 4 for the items of conv_bf16_big.hip.  The caller hands it to launch_bn_fwd_finalize: the kernel that
 // actually ran decides, not a second reading of the switches.
@@ -867,13 +888,12 @@ int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, c
                          float* bnpart, float* ws, hipStream_t st, int* tilesPerPartial) {
     ConvBf16Args a{in, pack_ptr(const_cast<float*>(packed), layer, 0, ns >= 3 ? 3 : 1), bias, out, bnpart, B, 0, nullptr, ns >= 3 ? pack_units(layer) : 0, ns == 6 ? 6 : 9};
     if (tilesPerPartial) *tilesPerPartial = 1;
-    // CVAE_BF16_BIG bits 4 / 5: conv_bf16_big.hip forward (E3 / E4) — persistent workgroups on a 16-accumulator wave tile
-    const int big = bf16_big_mask(width);
-    if (ns == 1 && (big & 48)) {
-        const int rc = launch_conv_bf16_big(layer, width, false, (big >> 4) & 3, a, st);
-        if (rc != -100) { if (tilesPerPartial) *tilesPerPartial = conv_bf16_big_tiles(layer, width, false); return rc; }
+    if (ns == 1) {       // the persistent kernels; the big-tile one emits one BatchNorm partial per item
+        int family;
+        const int rc = try_persistent_bf16(layer, width, false, a, st, &family);
+        if (family == 2 && tilesPerPartial) *tilesPerPartial = conv_bf16_big_tiles(layer, width, false);
+        if (family) return rc;
     }
-    if (ns == 1 && use_ps_kernel(layer, false)) { const int rc = launch_conv_bf16_ps(layer, width, false, a, st); if (rc != -100) return rc; }
     if (width == 64) {
         switch (layer) {
             case 1: return run_bf16<32, 64, 32, 64, EPI_BIAS_BNSTAT>(a, st);
@@ -904,10 +924,11 @@ int launch_conv_fwd_bf16(int layer, int width, int ns, int B, const float* in, c
 
 int launch_conv_dgrad_bf16(int layer, int width, int ns, int B, const float* dout, const float* packed, float* din, float* ws, hipStream_t st) {
     ConvBf16Args a{dout, pack_ptr(const_cast<float*>(packed), layer, 1, ns >= 3 ? 3 : 1), nullptr, din, nullptr, B, 0, nullptr, ns >= 3 ? pack_units(layer) : 0, ns == 6 ? 6 : 9};
-    // CVAE_BF16_BIG bits 2 / 3: conv_bf16_big.hip for the 128- / 64-channel input gradients (E4: 4 x 4 wave tile, E3: 8 x 2)
-    { const int big = bf16_big_mask(width);
-      if (ns == 1 && (big & 12)) { const int rc = launch_conv_bf16_big(layer, width, true, (big >> 2) & 3, a, st); if (rc != -100) return rc; } }
-    if (ns == 1 && use_ps_kernel(layer, true)) { const int rc = launch_conv_bf16_ps(layer, width, true, a, st); if (rc != -100) return rc; }
+    if (ns == 1) {
+        int family;
+        const int rc = try_persistent_bf16(layer, width, true, a, st, &family);
+        if (family) return rc;
+    }
     if (width == 64) {
         switch (layer) {
             case 1: return run_bf16<64, 32, 32, 32, EPI_PLAIN>(a, st);

@@ -52,6 +52,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef BIG_EXP
 #define BIG_EXP 0
 #endif
+#ifndef BIG_IMGL
+#define BIG_IMGL true      // false (A/B builds): the per-tile halo layout for the instantiations that existed before the image layout
+#endif
 
 // raw buffer descriptor over a whole tensor (gfx9 word 3: DATA_FORMAT_32): a lane whose byte offset is >= bytes is dropped by the
 // bounds check, so "store if valid" needs no branch (tensors of 2 GiB and more do not take this kernel: run_big returns -100)
@@ -60,7 +63,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t big_rsrc(const void* p, unsign
 }
 static constexpr unsigned BIG_OOB = 0x80000000u;
 
-template <int KCH, int NCH, int H, int NT, int MT, int KB, int EPI, bool TDB>
+template <int KCH, int NCH, int H, int NT, int MT, int KB, int EPI, bool TDB, bool IMGL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv5x5_bf16_big_kernel(ConvBf16Args a, int numGroups) {
     using T = Tile<H>;
     static_assert(EPI == EPI_PLAIN || EPI == EPI_BIAS_BNSTAT, "epilogues: plain (input gradient) or bias + BatchNorm partials (forward)");
@@ -69,10 +72,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int PSP = Bf16Geom<H, OCT>::PSP, A_UNITS = OCT * PSP, W_UNITS = KS * KB * 2 * NT;
     constexpr int NCHUNK = KCH / KCB, NST = NCHUNK * KS, NSTEP = KS * KB;
     static_assert(KCH % KCB == 0 && NCH % NT == 0 && MT * NB == 16 && (KB == 1 || KB == 2), "tiling");
+    // IMGL (image layout, round 5): an item's MT tiles are NIMG WHOLE images, kept in LDS as ONE plane per octet of (H + 4) x (H + 4) halo images.
+    // Every halo pixel of a whole image is zero padding: the planes are zeroed once per kernel and only the H x H interiors are ever staged —
+    // 128 instead of 288 units per 8 x 8-image tile, 1024 instead of 2304 for a 32 x 32 image cut into eight 4-row tiles (the tiles of the
+    // per-tile layout carry a halo each: 98 KB of requests per 16-channel chunk, which is what kept E2 off this kernel).
+    constexpr int HW = H + 4, NIMG = MT * 128 / (H * H);
+    static_assert(!IMGL || (NIMG >= 1 && NIMG * H * H == MT * 128 && T::TW == H && T::HTW == HW), "image layout: the item's tiles are whole images");
+    constexpr int PSPI = ((NIMG * HW * HW + 15 - Bf16Geom<H, OCT>::PAD) / 16) * 16 + Bf16Geom<H, OCT>::PAD;      // plane stride, == 16 / OCT (mod 16) like PSP
+    constexpr int PSX = IMGL ? PSPI : PSP;                     // octet-plane stride of the layout in use
+    constexpr int TILE_UNITS = IMGL ? OCT * PSPI : MT * A_UNITS;       // one tile buffer
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);       // [tile][octet][halo pixel]
+    bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);       // [tile][octet][halo pixel]; IMGL: [octet][image][halo pixel]
     constexpr int TBUFS = TDB ? 2 : 1;                         // TDB: the input tiles are double-buffered too (tile buffer = chunk parity)
-    bf16x8* lds_w = lds_a + TBUFS * MT * A_UNITS;              // [buffer][tap][kb][half][n]
+    bf16x8* lds_w = lds_a + TBUFS * TILE_UNITS;                // [buffer][tap][kb][half][n]
     // behind the slabs: 256 dump units (4 KB) for the staging stores of units that do not exist, then (forward) the [S | Q][wave][NT] rows of the
     // BatchNorm partials (they live from an item's epilogue until the next item's first stage barrier: not in the dump area) and [NCH] bias
     [[maybe_unused]] float* red = reinterpret_cast<float*>(lds_w + 2 * W_UNITS + 256);
@@ -120,16 +132,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int q = tid + i * 256, n = q % NT, row = q / NT, half = row & 1, kb = (row >> 1) % KB, s = row / (2 * KB);
         wbase[i] = (W_UNITS % 256 == 0 || q < W_UNITS) ? (((s * (KCH / 16) + kb) * 2 + half) * NCH + n) * 16 : 0;      // past the slab: unit 0 (never staged)
     }
-    constexpr int NQ = T::HP * OCT, IPT = (NQ + 255) / 256;
-    static_assert(MT * IPT <= 32, "one validity bit per staged unit");
-    int irel[IPT];                                             // byte offset of the unit relative to the tile's first pixel, chunk 0
-    unsigned ipk[IPT];                                         // halo row | halo column << 8 | image << 16 | unit exists << 31
+    // staged 16-byte units per thread and tile buffer: per tile IPT units of its halo image (tables shared by the tiles), or (IMGL) the item's
+    // NU units of image interiors
+    constexpr int NQ = IMGL ? NIMG * H * H * OCT : T::HP * OCT, IPT = (NQ + 255) / 256;
+    constexpr int NU = IMGL ? IPT : MT * IPT;                  // units a thread stages per tile buffer
+    static_assert(NU <= 32 && (!IMGL || NQ % 256 == 0), "staged units");
+    constexpr int IPTT = IMGL ? 1 : IPT;
+    int irel[IPTT];                                            // byte offset of the unit relative to the tile's first pixel, chunk 0
+    unsigned ipk[IPTT];                                        // halo row | halo column << 8 | image << 16 | unit exists << 31
+    // IMGL: unit u of a thread is pixel (tid / OCT) + u UPX of the item — UPX = 256 / OCT pixels are whole rows, so unit u sits a compile-time
+    // number of images and rows behind unit 0 in memory (cgl, carried by the scalar offset of the load) and in LDS (clds, the write's immediate):
+    // one lane offset, one LDS address and one image number per thread instead of a table per unit
+    constexpr int UPX = 256 / OCT;
+    static_assert(!IMGL || (UPX % H == 0 && (H * H) % UPX == 0) || UPX % (H * H) == 0, "a unit step is whole rows of one image, or whole images");
+    [[maybe_unused]] unsigned irel0 = 0;
+    [[maybe_unused]] int ilds0 = 0, pimg0 = 0;
+    if constexpr (IMGL) {
+        const int oct = tid % OCT, px = tid / OCT, img = px / (H * H), rem = px - img * (H * H), y = rem / H, x = rem % H;
+        irel0 = (unsigned)((px * KCH + oct * 8) * 2 + (2 * H + 2) * KCH * 2);     // + IBIAS (the input descriptor starts that far in front of the tensor)
+        ilds0 = oct * PSPI + img * (HW * HW) + (y + 2) * HW + x + 2;
+        pimg0 = img;
+    } else {
 #pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-        const int q = tid + i * 256, oct = q % OCT, hp = q / OCT, img = hp / T::HPI, rem = hp - img * T::HPI;
-        const int hy = rem / T::HTW, hx = rem % T::HTW;
-        irel[i] = (((img * H + hy - 2) * H + hx - 2) * KCH + oct * 8) * 2;
-        ipk[i] = (unsigned)hy | ((unsigned)hx << 8) | ((unsigned)img << 16) | ((NQ % 256 == 0 || q < NQ) ? 0x80000000u : 0u);
+        for (int i = 0; i < IPT; ++i) {
+            const int q = tid + i * 256, oct = q % OCT;
+            const int hp = q / OCT, img = hp / T::HPI, rem = hp - img * T::HPI;
+            const int hy = rem / T::HTW, hx = rem % T::HTW;
+            irel[i] = (((img * H + hy - 2) * H + hx - 2) * KCH + oct * 8) * 2;
+            ipk[i] = (unsigned)hy | ((unsigned)hx << 8) | ((unsigned)img << 16) | ((NQ % 256 == 0 || q < NQ) ? 0x80000000u : 0u);
+        }
     }
     const __amdgpu_buffer_rsrc_t rs_out = big_rsrc(a.out, (unsigned)((size_t)a.B * H * H * NCH * 2));
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_bn = big_rsrc(a.bnpart, BN ? (unsigned)((size_t)2 * numGroups * NCH * 4) : 0u);
@@ -154,8 +185,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         return x;
     };
-    bf16x8 wreg[WPT], breg[MT * IPT];
-    unsigned voff[MT * IPT];                                   // lane offsets of the staged units of the item whose tiles are being requested (padding: out of range)
+    bf16x8 wreg[WPT], breg[NU];
+    constexpr int NVO = IMGL ? 1 : NU;
+    unsigned voff[NVO];                                        // lane offsets of the staged units of the item whose tiles are being requested (padding: out of range)
+    [[maybe_unused]] int nv_req = NIMG;                        // IMGL: images of that item that exist (fewer than NIMG only at the ragged end)
     auto slab_soff = [&](int n0, int st) {                     // byte offset of the slab of stage st = (chunk st / 5, kernel row st % 5), channel block n0
         const int cc = st / KS, r = st - cc * KS;
         return (unsigned)(((r * KS * (KCH / 16) + cc * KB) * 2 * NCH + n0) * 16);
@@ -170,52 +203,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (i < WPT) lds_w[(W_UNITS % 256 == 0 || tid + i * 256 < W_UNITS) ? buf * W_UNITS + tid + i * 256 : 2 * W_UNITS + tid] = wreg[i < WPT ? i : 0];
     };
     auto set_voff = [&](const Item& x) {
+        if constexpr (IMGL) {                                  // interiors only: a unit is missing only when its image is (ragged last item)
+            nv_req = a.B - x.img0[0];
+        } else {
 #pragma unroll
-        for (int tl = 0; tl < MT; ++tl)
+            for (int tl = 0; tl < MT; ++tl)
 #pragma unroll
-            for (int i = 0; i < IPT; ++i) {
-                const int hy = ipk[i] & 255, hx = (ipk[i] >> 8) & 255, img = (ipk[i] >> 16) & 255;
-                const bool ok = (ipk[i] >> 31) && (unsigned)(x.ty0[tl] + hy - 2) < (unsigned)H && (unsigned)(x.tx0[tl] + hx - 2) < (unsigned)H && x.img0[tl] + img < a.B;
-                voff[tl * IPT + i] = ok ? (unsigned)(irel[i] + IBIAS) : BIG_OOB;
-            }
-    };
-    auto load_input = [&](const unsigned (&tsoff)[MT]) {       // tsoff[tl] = byte offset of tile tl's first pixel, chunk included
-#pragma unroll
-        for (int tl = 0; tl < MT; ++tl)
-#pragma unroll
-            for (int i = 0; i < IPT; ++i)
-                breg[tl * IPT + i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[tl * IPT + i], tsoff[tl], 0));
-    };
-    // TDB: two staged units per step — requested in stages 0..2 (steps 3, 4), written two stages later into the OTHER tile buffer
-    auto load_unit = [&](int u, const unsigned (&tsoff)[MT]) {
-        if (u < MT * IPT) breg[u] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[u], tsoff[u / IPT], 0));
-    };
-    auto store_unit = [&](int u, int tb) {
-        if (u < MT * IPT) {
-            const int tl = u / IPT, i = u % IPT, q = tid + i * 256;
-            lds_a[(NQ % 256 == 0 || q < NQ) ? (tb * MT + tl) * A_UNITS + (q % OCT) * PSP + q / OCT : TBUFS * MT * A_UNITS + 2 * W_UNITS + tid] = breg[u];
+                for (int i = 0; i < IPT; ++i) {
+                    const int hy = ipk[i] & 255, hx = (ipk[i] >> 8) & 255, img = (ipk[i] >> 16) & 255;
+                    const bool ok = (ipk[i] >> 31) && (unsigned)(x.ty0[tl] + hy - 2) < (unsigned)H && (unsigned)(x.tx0[tl] + hx - 2) < (unsigned)H && x.img0[tl] + img < a.B;
+                    voff[tl * IPT + i] = ok ? (unsigned)(irel[i] + IBIAS) : BIG_OOB;
+                }
         }
     };
-    auto store_input = [&]() {
-#pragma unroll
-        for (int tl = 0; tl < MT; ++tl)
-#pragma unroll
-            for (int i = 0; i < IPT; ++i) {
-                const int q = tid + i * 256;
-                lds_a[(NQ % 256 == 0 || q < NQ) ? tl * A_UNITS + (q % OCT) * PSP + q / OCT : TBUFS * MT * A_UNITS + 2 * W_UNITS + tid] = breg[tl * IPT + i];
+    // unit u of a tile buffer: where it comes from (tsoff[tl] = byte offset of tile tl's first pixel, chunk included; IMGL: tile 0's = the item's)
+    // and where it goes (units that do not exist land in the dump slots behind the slabs: no branch around a store)
+    auto load_unit = [&](int u, const unsigned (&tsoff)[MT]) {
+        if (u < NU) {
+            if constexpr (IMGL) {
+                const int cimg = (u * UPX) / (H * H);
+                const unsigned v = (NIMG == 1 || pimg0 + cimg < nv_req) ? irel0 : BIG_OOB;
+                breg[u] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v, tsoff[0] + (unsigned)(u * UPX * KCH * 2), 0));
+            } else breg[u] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[u], tsoff[u / IPT], 0));
+        }
+    };
+    auto store_unit = [&](int u, int tb) {
+        if (u < NU) {
+            if constexpr (IMGL) {
+                const int clds = ((u * UPX) / (H * H)) * (HW * HW) + (((u * UPX) % (H * H)) / H) * HW;
+                lds_a[tb * TILE_UNITS + clds + ilds0] = breg[u];
+            } else {
+                const int tl = u / IPT, i = u % IPT, q = tid + i * 256;
+                lds_a[(NQ % 256 == 0 || q < NQ) ? (tb * MT + tl) * A_UNITS + (q % OCT) * PSP + q / OCT : TBUFS * TILE_UNITS + 2 * W_UNITS + tid] = breg[u];
             }
+        }
+    };
+    auto load_input = [&](const unsigned (&tsoff)[MT]) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) load_unit(u, tsoff);
+    };
+    auto store_input = [&]() {                                 // tile buffer 0
+#pragma unroll
+        for (int u = 0; u < NU; ++u) store_unit(u, 0);
     };
 
     f32x16 acc[MT][NB];
     bf16x8 wf[2][NB], xf[2][MT];                               // two fragment sets, alternating per step (they live across stages)
     auto ldf = [&](int set, int i, int r, int buf, int tb = 0) {   // fragments of step i of a stage (kernel row r, slab buffer buf, tile buffer tb)
         const int s = i / KB, kb = i % KB;
-        const bf16x8* ap = lds_a + (TDB ? tb : 0) * (MT * A_UNITS) + lh * PSP + aPix + r * T::HTW;
+        const bf16x8* ap = lds_a + (TDB ? tb : 0) * TILE_UNITS + lh * PSX + aPix + r * T::HTW;
         const bf16x8* bp = lds_w + buf * W_UNITS + lh * NT + li;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) wf[set][nb] = bp[((s * KB + kb) * 2) * NT + nb * 32];
 #pragma unroll
-        for (int tl = 0; tl < MT; ++tl) xf[set][tl] = ap[tl * A_UNITS + (kb * 2) * PSP + s];
+        for (int tl = 0; tl < MT; ++tl) {                      // IMGL: tile tl = 128 consecutive pixels of the item's images, its first one at halo pixel toff
+            constexpr int TPX = 128;
+            const int toff = IMGL ? (tl * TPX / (H * H)) * (HW * HW) + ((tl * TPX % (H * H)) / H) * HW : tl * A_UNITS;
+            xf[set][tl] = ap[toff + (kb * 2) * PSX + s];
+        }
     };
 
     // One stage = one kernel row x KCB channels = NSTEP steps of 16 MFMAs, straight-line code (every step is ONE scheduling region: a branch
@@ -236,7 +281,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int steptime_idx = 0;
     const __amdgpu_buffer_rsrc_t rs_steps = big_rsrc(big_steps, (unsigned)sizeof(big_steps));
 #endif
-    static_assert(!TDB || (KB == 1 && MT * IPT <= 12), "the unit schedule of the double-buffered tiles: 6 slots of two units");
+    static_assert(!TDB || (KB == 1 && NU <= 12), "the unit schedule of the double-buffered tiles: 6 slots of two units");
     auto stage = [&](auto p0c, auto rc, auto tbc, int gst, unsigned wsoff, const unsigned (&tsoff)[MT]) {
         constexpr int P0 = decltype(p0c)::value, R = decltype(rc)::value, TB = decltype(tbc)::value;       // TB: tile buffer of this chunk (TDB)
         constexpr int RN = R == KS - 1 ? 0 : R + 1;
@@ -314,6 +359,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (BIG_EXP & 128) { for (int k = 0; k < ((int)(blockIdx.x >> 3) & 7); ++k) __builtin_amdgcn_s_sleep(30); }      // 8 phases, ~1.9 k cycles apart
     // ---- prologue: the first item's tiles and slab 0 into LDS, its slab 1 on the way ----
     if constexpr (BN) { for (int c = tid; c < NCH; c += 256) lds_bias[c] = a.bias[c]; }
+    if constexpr (IMGL) {                                      // the zero padding around every image, once: staging never writes there
+        for (int i = tid; i < TBUFS * TILE_UNITS; i += 256) lds_a[i] = bf16x8{};
+        __syncthreads();
+    }
     Item cur = setup(grp0, n00);
     set_voff(cur);
     {
@@ -531,17 +580,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 }
 
-template <int KCH, int NCH, int H, int NT, int MT, int KB, int EPI>
+template <int KCH, int NCH, int H, int NT, int MT, int KB, int EPI, bool IMGL = false>
 static int run_big(const ConvBf16Args& a, hipStream_t st) {
-    constexpr bool TDB = MT == 4 && KB == 1;                  // the 4 x 4 tile leaves LDS for a second set of input tiles
+    constexpr bool TDB = (MT == 4 || IMGL) && KB == 1;         // the 4 x 4 tile / the image layout leave LDS for a second set of input tiles
     using T = Tile<H>;
     constexpr int OCT = 2 * KB;
     constexpr int NY = NCH / NT;
-    constexpr int SMEM = ((TDB ? 2 : 1) * MT * OCT * Bf16Geom<H, OCT>::PSP + 2 * 5 * KB * 2 * NT + 256 + 4 * 32 * 9) * 16 + (EPI == EPI_BIAS_BNSTAT ? (2 * 4 * NT + NCH) * 4 : 0);
+    constexpr int NIMG = MT * 128 / (H * H), PAD = Bf16Geom<H, OCT>::PAD;
+    constexpr int TILE_UNITS = IMGL ? OCT * (((NIMG * (H + 4) * (H + 4) + 15 - PAD) / 16) * 16 + PAD) : MT * OCT * Bf16Geom<H, OCT>::PSP;
+    constexpr int SMEM = ((TDB ? 2 : 1) * TILE_UNITS + 2 * 5 * KB * 2 * NT + 256 + 4 * 32 * 9) * 16 + (EPI == EPI_BIAS_BNSTAT ? (2 * 4 * NT + NCH) * 4 : 0);
     static_assert(SMEM <= 160 * 1024, "LDS");
     // 32-bit byte offsets and buffer descriptors inside: larger tensors take the per-tile kernels (size_t addressing)
     if ((size_t)a.B * H * H * KCH * 2 >= (1ull << 31) || (size_t)a.B * H * H * NCH * 2 >= (1ull << 31)) return -100;
-    auto kern = conv5x5_bf16_big_kernel<KCH, NCH, H, NT, MT, KB, EPI, TDB>;
+    if (g_conv_dry) return 0;
+    auto kern = conv5x5_bf16_big_kernel<KCH, NCH, H, NT, MT, KB, EPI, TDB, IMGL>;
     static DeviceOnce once;
     { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(kern), SMEM); if (rc) return rc; }
     const int numTiles = cdiv(a.B, T::IMGS) * T::TILES_PER_IMG, numGroups = cdiv(numTiles, MT);
@@ -568,22 +620,23 @@ static int run_big(const ConvBf16Args& a, hipStream_t st) {
 bool conv_bf16_big_has(int layer, int width, bool dgrad, int mask) {
     if (width != 64 && width != 128) return false;
     if (dgrad) return (layer == 3 && (mask & 1)) || (layer == 2 && (mask & 2));
-    return (layer == 2 && (mask & 1)) || (layer == 3 && (mask & 2));
+    return (layer == 2 && (mask & 1)) || (layer == 3 && (mask & 2)) || (layer == 1 && width == 64 && (mask & 4));
 }
-int conv_bf16_big_tiles(int layer, int width, bool dgrad) { (void)width; return (dgrad && layer == 2) ? 8 : 4; }
+int conv_bf16_big_tiles(int layer, int width, bool dgrad) { (void)width; return ((dgrad && layer == 2) || (!dgrad && layer == 1)) ? 8 : 4; }
 // returns -100 when the layer has no instantiation (or the tensors are too large for its 32-bit offsets)
 int launch_conv_bf16_big(int layer, int width, bool dgrad, int mask, const ConvBf16Args& a, hipStream_t st) {
     if (!conv_bf16_big_has(layer, width, dgrad, mask)) return -100;
     if (dgrad) {
-        if (width == 64 && layer == 3) return run_big<256, 128, 8, 128, 4, 1, EPI_PLAIN>(a, st);
-        if (width == 64 && layer == 2) return run_big<128, 64, 16, 64, 8, 1, EPI_PLAIN>(a, st);
-        if (width == 128 && layer == 3) return run_big<256, 128, 16, 128, 4, 1, EPI_PLAIN>(a, st);
-        if (width == 128 && layer == 2) return run_big<128, 64, 32, 64, 8, 1, EPI_PLAIN>(a, st);
+        if (width == 64 && layer == 3) return run_big<256, 128, 8, 128, 4, 1, EPI_PLAIN, BIG_IMGL>(a, st);
+        if (width == 64 && layer == 2) return run_big<128, 64, 16, 64, 8, 1, EPI_PLAIN, BIG_IMGL>(a, st);
+        if (width == 128 && layer == 3) return run_big<256, 128, 16, 128, 4, 1, EPI_PLAIN, BIG_IMGL>(a, st);
+        if (width == 128 && layer == 2) return run_big<128, 64, 32, 64, 8, 1, EPI_PLAIN, BIG_IMGL>(a, st);
     } else {
-        if (width == 64 && layer == 2) return run_big<64, 128, 16, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);
-        if (width == 64 && layer == 3) return run_big<128, 256, 8, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);
-        if (width == 128 && layer == 2) return run_big<64, 128, 32, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);
-        if (width == 128 && layer == 3) return run_big<128, 256, 16, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);
+        if (width == 64 && layer == 1) return run_big<32, 64, 32, 64, 8, 1, EPI_BIAS_BNSTAT, true>(a, st);
+        if (width == 64 && layer == 2) return run_big<64, 128, 16, 128, 4, 1, EPI_BIAS_BNSTAT, BIG_IMGL>(a, st);
+        if (width == 64 && layer == 3) return run_big<128, 256, 8, 128, 4, 1, EPI_BIAS_BNSTAT, BIG_IMGL>(a, st);
+        if (width == 128 && layer == 2) return run_big<64, 128, 32, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);       // half an image per item: per-tile layout
+        if (width == 128 && layer == 3) return run_big<128, 256, 16, 128, 4, 1, EPI_BIAS_BNSTAT, BIG_IMGL>(a, st);
     }
     return -100;
 }

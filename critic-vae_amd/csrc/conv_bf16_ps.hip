@@ -398,6 +398,7 @@ static int run_ps(const ConvBf16Args& a, hipStream_t st) {
     // 32-bit byte offsets, a 32-bit num_records and 0x80000000 as the "skip this lane" offset inside: tensors of 2 GiB and more take the
     // per-tile kernel (size_t addressing) — the caller falls back on -100
     if ((size_t)a.B * H * H * KCH * 2 >= (1ull << 31) || (size_t)a.B * H * H * NCH * 2 >= (1ull << 31)) return -100;
+    if (g_conv_dry) return 0;
     auto kern = conv5x5_bf16_ps_kernel<KCH, NCH, H, NT, EPI>;
     static DeviceOnce once;
     { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(kern), SMEM); if (rc) return rc; }

@@ -460,6 +460,14 @@ static bool use_f32_ps(int layer, bool dgrad) {
     return ((mask >> ((dgrad ? 3 : 0) + (layer >= 4 ? 2 : layer - 1))) & 1) != 0;
 }
 
+int conv_f32_route(int layer, int width, bool dgrad, int B) {
+    if (!use_f32_ps(layer, dgrad)) return 0;
+    g_conv_dry = true;
+    const int rc = launch_conv_mfma_ps(layer, width, dgrad, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    g_conv_dry = false;
+    return rc == 0 ? 1 : 0;
+}
+
 int launch_conv_fwd(int layer, int width, int B, const float* in, const float* w, const float* bias,
                     float* out, float* bnpart, float* ws, hipStream_t st) {
     if (use_f32_ps(layer, false)) { const int rc = launch_conv_mfma_ps(layer, width, false, B, in, w, bias, out, bnpart, st); if (rc != -100) return rc; }

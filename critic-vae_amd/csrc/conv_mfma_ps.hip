@@ -286,6 +286,7 @@ static int run_mfma_ps(const ConvPsArgs& a, hipStream_t st) {
     // the kernel addresses both tensors with 32-bit byte offsets and marks skipped lanes with the offset 0x80000000: tensors of 2 GiB and
     // more take the per-tile kernel (size_t addressing) — the caller falls back on -100
     if ((size_t)a.B * H * H * KCH * 4 >= (1ull << 31) || (size_t)a.B * H * H * NCH * 4 >= (1ull << 31)) return -100;
+    if (g_conv_dry) return 0;
     const int numTiles = cdiv(a.B, T::IMGS) * T::TILES_PER_IMG;
     const int numItems = cdiv(numTiles, 8) * 8 * NY;
     int G = 2 * cvae_num_cus();

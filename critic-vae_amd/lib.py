@@ -48,6 +48,7 @@ _SIGS = {
     "cvae_workspace_bytes": (_i64, [_p, _i32]),
     "cvae_bn_state_floats": (_i64, [_p]),
     "cvae_ws_offset": (_i64, [_p, _i32, C.c_char_p]),
+    "cvae_conv_route": (_i32, [_i32, _i32, _i32, _i32, _i64]),
     "cvae_forward": (C.c_int, [_p, _i32] + [_p] * 9 + [_i32, _p]),
     "cvae_decode": (C.c_int, [_p, _i32] + [_p] * 5),
     "cvae_loss": (C.c_int, [_p, _i32] + [_p] * 10),

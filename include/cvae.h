@@ -186,6 +186,14 @@ int cvae_diff_grey(cvae_handle h, int32_t batch, const float* recon_one, const f
  * decides per step) or CVAE_FUSE_E1=0 — do not read it otherwise.  Slots hold bf16 elements in precision mode 1. */
 int64_t cvae_ws_offset(cvae_handle h, int32_t batch, const char* name);
 
+/* Which kernel family the forward (dgrad = 0) or input-gradient (dgrad = 1) pass of encoder conv layer 1..3 (E2..E4, nn.Conv2d at
+ * vae_nets.py:74,79,84) takes at `batch` images: 0 = per-tile kernel (64-bit addressing, any size), 1 = two-workgroup persistent kernel,
+ * 2 = big-tile persistent kernel.  The persistent kernels address their tensors with 32-bit byte offsets and REFUSE activations of 2 GiB
+ * and more (E2's output: batch >= 8192 in fp32, >= 16384 in bf16 mode at 64 x 64); the launchers then take the per-tile kernel by
+ * themselves.  Host logic only (the launchers' own decision path up to the launch; no device access, works without a GPU);
+ * CVAE_EINVAL for arguments outside these ranges.  precision as in cvae_config. */
+int32_t cvae_conv_route(int32_t precision, int32_t width, int32_t layer, int32_t dgrad, int64_t batch);
+
 /*
  * In-step kernel probe (measurement only): bit (kind*9 + layer) of `mask` arms a HIP event pair
  * around that conv kernel (kind 0 forward, 1 dgrad, 2 wgrad; layer 1..7) inside cvae_forward /

@@ -59,6 +59,40 @@ def test_bad_arguments_return_errors_not_crashes():
     assert h.workspace_bytes(4) > 0 and h.workspace_bytes(4) % 4 == 0
 
 
+def test_persistent_conv_kernels_refuse_tensors_of_two_gib():
+    """The persistent conv kernels (conv_bf16_big.hip, conv_bf16_ps.hip, conv_mfma_ps.hip) address their tensors with 32-bit byte offsets
+    and buffer descriptors; their launchers must hand an activation of 2 GiB or more to the per-tile kernels (64-bit addressing).
+    cvae_conv_route walks the launchers' own decision path up to the launch (no device access): the family changes exactly where
+    the larger of a layer's two tensors crosses 2^31 bytes.  A child process, so that no CVAE_* switch of the caller changes the masks."""
+    code = """
+import sys
+sys.path.insert(0, %r)
+from critic_vae_amd import lib as cvlib
+lib = cvlib.load()
+r = lib.cvae_conv_route
+ch = {1: (32, 64), 2: (64, 128), 3: (128, 256)}
+for prec, elt in ((0, 4), (1, 2)):
+    for width in (64, 128):
+        for layer in (1, 2, 3):
+            H = (width // 2) >> (layer - 1)
+            edge = (1 << 31) // (H * H * max(ch[layer]) * elt)          # first batch whose larger tensor has 2^31 bytes
+            for dgrad in (0, 1):
+                small, below, at = r(prec, width, layer, dgrad, 8), r(prec, width, layer, dgrad, edge - 1), r(prec, width, layer, dgrad, edge)
+                assert small == below, (prec, width, layer, dgrad, small, below)
+                assert at == 0 and r(prec, width, layer, dgrad, 4 * edge) == 0, (prec, width, layer, dgrad, at)
+                print(prec, width, layer, dgrad, edge, small)
+# the default configuration does use them below the edge: fp32 E2..E4 forward on the two-workgroup kernel, bf16 E4 on the big-tile kernel
+assert [r(0, 64, l, 0, 256) for l in (1, 2, 3)] == [1, 1, 1] and r(0, 64, 1, 1, 256) == 0
+assert r(1, 64, 3, 0, 2048) == 2 and r(1, 64, 3, 1, 2048) == 2 and r(1, 64, 2, 1, 2048) == 2 and r(1, 64, 1, 0, 2048) == 1
+assert r(1, 64, 1, 0, 16383) == 1 and r(1, 64, 1, 0, 16384) == 0 and r(0, 64, 1, 0, 8191) == 1 and r(0, 64, 1, 0, 8192) == 0
+assert r(2, 64, 1, 0, 256) == 0 and r(1, 32, 1, 0, 8) < 0 and r(1, 64, 4, 0, 8) < 0 and r(1, 64, 1, 0, 0) < 0 and r(1, 64, 1, 0, 1 << 32) < 0
+print("ok")
+""" % ROOT
+    env = {k: v for k, v in os.environ.items() if not k.startswith("CVAE_")}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_two_handles_do_not_share_state():
     """include/cvae.h: one handle per device / configuration, no global state."""
     a, b = cvlib.Handle(64, 4), cvlib.Handle(128, 2, precision="bf16")

@@ -18,6 +18,9 @@
 //     slab 0 AND its slab 1 are requested before the current item's epilogue (vmcnt retires loads and stores in issue order: a load
 //     consumed behind the epilogue's stores would wait for their write acknowledgements), so an item starts without a cold prologue
 //     and the epilogue's stores drain under the next item's MFMAs.
+// IMGL (round 5): an item's tiles are whole images in LDS — borders zeroed once, only the interiors staged (see the kernel).  S16 (round 5, opt-in through
+// CVAE_BIG_S16=1): the same kernel on v_mfma_f32_16x16x32_bf16, on which the power-limited chip holds a 15 % higher clock (profiles/r05_l_mfma_shape_probe.txt,
+// r05_m_big_s16.txt: level with the 32x32x16 form so far; see stage16).
 // Epilogues, both from channel-major accumulators (v_cvt_pk + two 16-byte buffer stores per tile, no transpose, invalid lanes as
 // out-of-range offsets): plain (input gradient), or bias (= the accumulators' initial value) + ONE BatchNorm partial per item — its MT
 // tiles summed in the lane before the cross-lane column sums (launch_bn_fwd_finalize(.., tilesPerPartial = MT)).
@@ -46,6 +49,7 @@ extern "C" int cvae_big_steps_read(long long* out) { return (int)hipMemcpyFromSy
 #endif
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 // Timing experiments (WRONG results, never shipped; profiles/experiments/variant.sh -DBIG_EXP=n): what the stage loop pays for each of its
 // parts.  bit 0: no barrier in front of a stage's last step;  bit 1: no slab writes;  bit 2: no slab requests;  bit 3: no tile requests / writes;
 // bit 4: no BatchNorm sums in the epilogue;  bit 5: no column sums / partial rows;  bit 6: no output stores;  bit 7: workgroups start staggered
@@ -63,7 +67,31 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t big_rsrc(const void* p, unsign
 }
 static constexpr unsigned BIG_OOB = 0x80000000u;
 
-template <int KCH, int NCH, int H, int NT, int MT, int KB, int EPI, bool TDB, bool IMGL>
+// S16: which of the wave's 32 pixels (row-major inside the 128-pixel tile) sits behind column c of pixel block jh of a 16x16x32 fragment.  A
+// ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+ 32): with k-block q = lane / 16 reading octet plane q & 1
+// (plane stride == 8 units mod 16) a group is conflict-free when lanes {0-3, 12-15} hold pixels at unit residues S u (S + 8) and lanes {4-11} the rest:
+// lanes 8-11 and 12-15 trade places.  8-pixel rows: a block is rows {0, 2} or {1, 3} of the wave's four (unit offsets 0..7 and 24..31 = residues 0..15).
+template <int H>
+__device__ __forceinline__ int s16_pix(int jh, int c) {
+    const int j = c < 8 ? c : (c < 12 ? c + 4 : c - 4);
+    if constexpr (Tile<H>::TW == 8) return ((j >> 3) * 2 + jh) * 8 + (j & 7);
+    else return 16 * jh + j;
+}
+// Sum x[k] (k = 0..15) over the 16 lanes of each DPP row, 45 instructions: lane L returns the total of element L & 15.  Fixed pairing, fixed order.
+__device__ __forceinline__ float row_colsum16(const float (&x)[16]) {
+    const int lane = threadIdx.x & 63;
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+    float r8[8], r4[4], r2[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r8[j] = (b3 ? x[j + 8] : x[j]) + dpp_mov<0x128>(b3 ? x[j] : x[j + 8]);            // partner i ^ 8 (row_ror:8)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r4[j] = (b2 ? r8[j + 4] : r8[j]) + dpp_mov<0x141>(b2 ? r8[j] : r8[j + 4]);        // partner 7 - i of the 8 (row_half_mirror: bit 2 flipped)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) r2[j] = (b1 ? r4[j + 2] : r4[j]) + dpp_mov<0x4E>(b1 ? r4[j] : r4[j + 2]);         // partner i ^ 2
+    return (b0 ? r2[1] : r2[0]) + dpp_mov<0xB1>(b0 ? r2[0] : r2[1]);                                                // partner i ^ 1
+}
+
+template <int KCH, int NCH, int H, int NT, int MT, int KB, int EPI, bool TDB, bool IMGL, bool S16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv5x5_bf16_big_kernel(ConvBf16Args a, int numGroups) {
     using T = Tile<H>;
     static_assert(EPI == EPI_PLAIN || EPI == EPI_BIAS_BNSTAT, "epilogues: plain (input gradient) or bias + BatchNorm partials (forward)");
@@ -85,11 +113,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);       // [tile][octet][halo pixel]; IMGL: [octet][image][halo pixel]
     constexpr int TBUFS = TDB ? 2 : 1;                         // TDB: the input tiles are double-buffered too (tile buffer = chunk parity)
     bf16x8* lds_w = lds_a + TBUFS * TILE_UNITS;                // [buffer][tap][kb][half][n]
+    constexpr int NSLAB = S16 ? 3 : 2;                         // slab buffers (S16: a ring of three, see stage16)
     // behind the slabs: 256 dump units (4 KB) for the staging stores of units that do not exist, then (forward) the [S | Q][wave][NT] rows of the
     // BatchNorm partials (they live from an item's epilogue until the next item's first stage barrier: not in the dump area) and [NCH] bias
-    [[maybe_unused]] float* red = reinterpret_cast<float*>(lds_w + 2 * W_UNITS + 256);
+    [[maybe_unused]] float* red = reinterpret_cast<float*>(lds_w + NSLAB * W_UNITS + 256);
     [[maybe_unused]] float* lds_bias = red + 2 * 4 * NT;
-    bf16x8* const lds_patch = lds_w + 2 * W_UNITS + 256 + (BN ? (2 * 4 * NT + NCH) / 4 : 0);              // [wave][32 rows][8 + 1] units: the epilogue's transposing patch
+    bf16x8* const lds_patch = lds_w + NSLAB * W_UNITS + 256 + (BN ? (2 * 4 * NT + NCH) / 4 : 0);              // [wave][32 rows][8 + 1] units: the epilogue's transposing patch
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     [[maybe_unused]] long long b0 = 0, b1 = 0, b2 = 0, tpro = 0, tstage = 0, tclose = 0, tepi = 0, nit = 0;
@@ -200,7 +229,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto store_w = [&](int i0, int i1, int buf) {                // units past the slab land in the dump slots behind the slabs (no branch around a store)
 #pragma unroll
         for (int i = i0; i < i1; ++i)
-            if (i < WPT) lds_w[(W_UNITS % 256 == 0 || tid + i * 256 < W_UNITS) ? buf * W_UNITS + tid + i * 256 : 2 * W_UNITS + tid] = wreg[i < WPT ? i : 0];
+            if (i < WPT) lds_w[(W_UNITS % 256 == 0 || tid + i * 256 < W_UNITS) ? buf * W_UNITS + tid + i * 256 : NSLAB * W_UNITS + tid] = wreg[i < WPT ? i : 0];
     };
     auto set_voff = [&](const Item& x) {
         if constexpr (IMGL) {                                  // interiors only: a unit is missing only when its image is (ragged last item)
@@ -222,7 +251,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (u < NU) {
             if constexpr (IMGL) {
                 const int cimg = (u * UPX) / (H * H);
-                const unsigned v = (NIMG == 1 || pimg0 + cimg < nv_req) ? irel0 : BIG_OOB;
+                const unsigned v = (NIMG == 1 || pimg0 < nv_req - cimg) ? irel0 : BIG_OOB;      // the unit's image number stays on the scalar side
                 breg[u] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v, tsoff[0] + (unsigned)(u * UPX * KCH * 2), 0));
             } else breg[u] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[u], tsoff[u / IPT], 0));
         }
@@ -234,7 +263,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 lds_a[tb * TILE_UNITS + clds + ilds0] = breg[u];
             } else {
                 const int tl = u / IPT, i = u % IPT, q = tid + i * 256;
-                lds_a[(NQ % 256 == 0 || q < NQ) ? (tb * MT + tl) * A_UNITS + (q % OCT) * PSP + q / OCT : TBUFS * TILE_UNITS + 2 * W_UNITS + tid] = breg[u];
+                lds_a[(NQ % 256 == 0 || q < NQ) ? (tb * MT + tl) * A_UNITS + (q % OCT) * PSP + q / OCT : TBUFS * TILE_UNITS + NSLAB * W_UNITS + tid] = breg[u];
             }
         }
     };
@@ -334,6 +363,129 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
 
+    // ---- S16 (round 5): the same tiles, slabs and staging on v_mfma_f32_16x16x32_bf16 — the chip holds a higher clock on that shape under its power
+    // limit (profiles/r05_l_mfma_shape_probe.txt: +14 % sustained).  k = 32 of one MFMA = TWO TAPS x the chunk's 16 channels: lane (c, q) of a
+    // fragment reads the unit of tap A (q < 2) or tap B (q >= 2), octet q & 1 — the LDS images stay as they are, only the lane -> address map changes.
+    // The wave tile is 2 MT pixel blocks (16 pixels: rows 16 jh .. + 15 of the wave's 32 in tile tl) x 2 NB channel blocks of 16; acc16[j][i], lane
+    // (c, q) = pixel c of block j, channels 16 i + 4 q .. + 3.  25 taps of a (chunk, 5 kernel rows) = 12.5 steps: a chunk PAIR is 25 steps — stage
+    // g = 5 h + r (h = chunk of the pair, r = kernel row) runs the steps whose first tap lies in its slab: three (taps 0|1, 2|3, 4|next slab's 0) when g
+    // is even, two (1|2, 3|4) when odd; the crossing step reads slab g + 1 and (r = 4) the next chunk's tiles, both visible behind the barrier that
+    // stands in front of every stage's last step anyway.
+    constexpr int NJ = S16 ? 2 * MT : 1, NI = S16 ? 2 * NB : 1;
+    [[maybe_unused]] f32x4 acc16[NJ][NI];
+    [[maybe_unused]] bf16x8 wf16[2][NI], xf16[2][NJ];          // two fragment sets, alternating per step
+    [[maybe_unused]] const int c16 = lane & 15, q4 = lane >> 4;
+    [[maybe_unused]] const bool hiq = q4 >= 2;
+    [[maybe_unused]] int xb16[2], wb16 = 0;
+    if constexpr (S16) {
+        static_assert(!S16 || (TDB && IMGL && KB == 1 && NCHUNK % 2 == 0 && NT % 64 == 0), "S16: image layout, double-buffered tiles, 16-channel chunks");
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {
+            const int mj = wave * 32 + s16_pix<H>(jh, c16), pi = mj / (T::TH * T::TW), pr = mj % (T::TH * T::TW);
+            xb16[jh] = (q4 & 1) * PSX + pi * T::HPI + (pr / T::TW) * T::HTW + (pr % T::TW);
+        }
+        wb16 = (q4 & 1) * NT + c16;
+    }
+    // Fragment reads = ONE lane pointer per KIND of tap pair + a compile-time offset (the ds_read's immediate): the lanes of tap B (q >= 2) sit a
+    // constant distance D behind tap A's — kind 0: the next column of the same kernel row (D = 1 unit; weights: 2 NT), kind 1: tap 4 of a row | tap 0 of
+    // the next row (D = HTW - 4), kind 2: tap (4, 4) of a chunk | tap (0, 0) of the next chunk in the other tile buffer (D = TILE_UNITS - 4 HTW - 4).
+    // (Per-step lane pointers with both taps' offsets folded in are 50 loop invariants: hoisted, spilled, and every reload inside the loop is followed
+    // by s_waitcnt vmcnt(0) — behind the slab and tile requests in flight: 5.1 k instead of 2.8 k cycles per stage.)
+    [[maybe_unused]] int xbk[3][2], wbh = 0;
+    if constexpr (S16) {
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {
+            xbk[0][jh] = xb16[jh] + (hiq ? 1 : 0);
+            xbk[1][jh] = xb16[jh] + (hiq ? T::HTW - 4 : 0);
+            xbk[2][jh] = xb16[jh] + (hiq ? TILE_UNITS - 4 * T::HTW - 4 : 0);
+        }
+        wbh = wb16 + (hiq ? 2 * NT : 0);
+    }
+    // weights of a tap pair (sA, sA + 1) inside ring slot `slot`
+    auto ldw16 = [&](int set, int sA, int slot) {
+        const bf16x8* wp = lds_w + wbh + slot * W_UNITS;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wf16[set][i] = wp[sA * 2 * NT + 16 * i];
+    };
+    // weights of the crossing pair: tap 4 of ring slot b0 | tap 0 of ring slot b1
+    auto ldw16x = [&](int set, int b0, int b1) {
+        const bf16x8* wp = lds_w + wb16 + (hiq ? b1 * W_UNITS : b0 * W_UNITS + 8 * NT);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wf16[set][i] = wp[16 * i];
+    };
+    // pixel fragments: kind of the pair, cA = tap A's compile-time unit offset (tile buffer, kernel row, column)
+    auto ldx16 = [&](int set, int kind, int cA) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int tl = j >> 1, toff = (tl * 128 / (H * H)) * (HW * HW) + ((tl * 128 % (H * H)) / H) * HW;
+            xf16[set][j] = (lds_a + xbk[kind][j & 1])[cA + toff];
+        }
+    };
+    // One stage on the 16x16x32 shape.  HC = chunk of the pair (= tile buffer), R = kernel row, P0 = fragment set of its first step; sb = ring slot of
+    // the stage's slab (THREE slab buffers: g in sb, g + 1 in sb + 1, and slab g + 2 — travelling in wreg — is written into sb + 2 during this stage).
+    //   step 0: fragments of step 1 (own slab) are read, nothing else;
+    //   step 1: BARRIER in front of it — the crossing step's fragments (THREE: tap 4 | tap 0 of slab g + 1, at R = 4 of the next chunk's tiles) or the next
+    //           stage's first fragments (two-step stage) lie behind it; then slab g + 2 goes from wreg into ring slot sb + 2 (its previous tenant g - 1 was
+    //           last read right behind the PREVIOUS stage's barrier: every wave is past that) and slab g + 3 (at wsoff) is requested;
+    //   step 2 (THREE): the next stage's first fragments.
+    //   Tile units of the next chunk: requested two per step at (R, step) = (0,1) (1,0) (1,1) (2,0), written two stages later at (2,1) (3,0) (3,1) (4,0) —
+    //   all in front of stage 4's barrier, behind which the crossing step reads them.
+    auto stage16 = [&](auto hc, auto rc, auto p0c, int sb, unsigned wsoff, const unsigned (&tsoff)[MT]) {
+        constexpr int HC = decltype(hc)::value, R = decltype(rc)::value, P0 = decltype(p0c)::value, TB = HC;
+        constexpr bool THREE = ((HC * KS + R) & 1) == 0;
+        constexpr int NSTP = THREE ? 3 : 2;
+        constexpr int RN = R == KS - 1 ? 0 : R + 1, TBN = R == KS - 1 ? TB ^ 1 : TB;
+        const int b0 = sb, b1 = sb == 2 ? 0 : sb + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+#pragma unroll
+        for (int i = 0; i < NSTP; ++i) {
+            const int set = (P0 + i) & 1;
+#ifdef BIG_STEPTIME
+            if (BT_ON) {
+                __builtin_amdgcn_sched_barrier(0);
+                const long long t = clock64();
+                const unsigned so = (steptime_on && tid == 0) ? (unsigned)(steptime_idx * 8) : BIG_OOB;
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)t, rs_steps, so, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)(t >> 32), rs_steps, so == BIG_OOB ? BIG_OOB : so + 4u, 0, 0);
+                ++steptime_idx;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+            // the NEXT step's taps: step 0 -> own slab (THREE: 2|3, else 3|4); step 1 -> behind the barrier: THREE: 4 | next slab's 0, else the next stage's
+            // first step (0|1 of slab g + 1); step 2 (THREE) -> the next stage's first step (1|2 of slab g + 1)
+            if (i == 0) { ldw16(set ^ 1, THREE ? 2 : 3, b0); ldx16(set ^ 1, 0, TB * TILE_UNITS + R * T::HTW + (THREE ? 2 : 3)); }
+            if (i == 1) {
+                if (!(BIG_EXP & 1)) __syncthreads();
+                if constexpr (THREE) { ldw16x(set ^ 1, b0, b1); ldx16(set ^ 1, R == KS - 1 ? 2 : 1, TB * TILE_UNITS + R * T::HTW + 4); }
+                else { ldw16(set ^ 1, 0, b1); ldx16(set ^ 1, 0, TBN * TILE_UNITS + RN * T::HTW); }
+                if (!(BIG_EXP & 2)) store_w(0, WPT, b2);
+                if (!(BIG_EXP & 4)) load_w(wsoff);
+            }
+            if (i == 2) { ldw16(set ^ 1, 1, b1); ldx16(set ^ 1, 0, TBN * TILE_UNITS + RN * T::HTW + 1); }
+            if (!(BIG_EXP & 8)) {
+                constexpr int RQ = R == 0 ? 0 : (R == 1 ? 1 : 3);             // first request slot of row R (rows 0..2), first write slot of row R + 2
+                if ((R == 0 && i == 1) || (R == 1 && i <= 1) || (R == 2 && i == 0)) { const int sl = RQ + (R == 1 ? i : 0); load_unit(2 * sl, tsoff); load_unit(2 * sl + 1, tsoff); }
+                if ((R == 2 && i == 1) || (R == 3 && i <= 1) || (R == 4 && i == 0)) {
+                    const int sl = (R == 2 ? 0 : (R == 3 ? 1 : 3)) + (R == 3 ? i : 0);
+                    store_unit(2 * sl, TB ^ 1); store_unit(2 * sl + 1, TB ^ 1);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                for (int ii = 0; ii < NI; ++ii)                // weights as the A operand: D[channel][pixel]
+                    acc16[j][ii] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf16[set][ii], xf16[set][j], acc16[j][ii], 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {                     // pinned: a fragment read per four MFMAs (LDS at half its rate), the step's writes / requests between
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x220, 2, 0);      // (one per gap stretches wreg's live range: 92 spills)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     // Forward: the finished item's per-wave rows [S | Q][wave][NT] -> ONE (sum, M2) partial per channel.  Deferred: a barrier of its own in the
     // epilogue waited for the slowest wave's store issue (8.5 k of the 16 k-cycle epilogue, profiles/r05_d_big_epilogue_ablation.txt); the rows are
     // combined behind the first stage barrier of the NEXT item instead (or behind one barrier at the very end), no branch: without a finished item
@@ -375,14 +527,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     store_input();
     store_w(0, WPT, 0);
     load_w(slab_soff(cur.n0, 1));
+    if constexpr (S16) {                                       // ring slots 0 and 1 filled, slab 2 on the way (stage 0 writes it into slot 2)
+        store_w(0, WPT, 1);
+        load_w(slab_soff(cur.n0, 2));
+        __syncthreads();
+        ldw16(0, 0, 0);
+        ldx16(0, 0, 0);
+    } else {
     __syncthreads();
     ldf(0, 0, 0, 0);
+    }
     BT(b1);
 #ifdef BIG_TIMING
     if (BT_ON) tpro = b1 - bt_entry;
 #endif
 
     int gst = 0;
+    [[maybe_unused]] int sb16 = 0;                             // S16: ring slot of the current stage's slab
 #ifdef BIG_STEPTIME
     steptime_first = true;
 #endif
@@ -390,6 +551,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         int itn = it + G, grpn, n0n;
         decode(itn, grpn, n0n);
         const bool have_next = itn < numItems && grpn < numGroups;
+        if constexpr (S16) {
+#pragma unroll
+            for (int ii = 0; ii < NI; ++ii) {
+                f32x4 bq4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (BN) bq4 = *reinterpret_cast<const f32x4*>(lds_bias + cur.n0 + 16 * ii + 4 * q4);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc16[j][ii] = bq4;
+            }
+        } else
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             f32x4 bq[4];
@@ -429,10 +599,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 BT(b2);
 #pragma unroll
                 for (int r = 0; r < KS; ++r) {
-                    const int s2 = cc * KS + r + 2;            // the slab requested in this stage: two stages ahead, across the item boundary
+                    const int s2 = cc * KS + r + (S16 ? 3 : 2);    // the slab requested in this stage: two (S16: three) stages ahead, across the item boundary
                     const bool own = s2 < NST;
                     const unsigned wsoff = slab_soff(own || !have_next ? cur.n0 : n0n, own ? s2 : (have_next ? s2 - NST : 0));
                     constexpr int P0v[2][5] = {{0, NSTEP & 1, 0, NSTEP & 1, 0}, {NSTEP & 1, 0, NSTEP & 1, 0, NSTEP & 1}};
+                    if constexpr (S16) {
+                        // fragment set of a stage's first step = parity of the steps before it in the pair (3, 2, 3, 2 ... steps per stage)
+                        constexpr int P16[2][5] = {{0, 1, 1, 0, 0}, {1, 1, 0, 0, 1}};
+                        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+                        if (h == 0) {
+                            if (r == 0) stage16(I0{}, std::integral_constant<int, 0>{}, std::integral_constant<int, P16[0][0]>{}, sb16, wsoff, ts);
+                            if (r == 1) stage16(I0{}, std::integral_constant<int, 1>{}, std::integral_constant<int, P16[0][1]>{}, sb16, wsoff, ts);
+                            if (r == 2) stage16(I0{}, std::integral_constant<int, 2>{}, std::integral_constant<int, P16[0][2]>{}, sb16, wsoff, ts);
+                            if (r == 3) stage16(I0{}, std::integral_constant<int, 3>{}, std::integral_constant<int, P16[0][3]>{}, sb16, wsoff, ts);
+                            if (r == 4) stage16(I0{}, std::integral_constant<int, 4>{}, std::integral_constant<int, P16[0][4]>{}, sb16, wsoff, ts);
+                        } else {
+                            if (r == 0) stage16(I1{}, std::integral_constant<int, 0>{}, std::integral_constant<int, P16[1][0]>{}, sb16, wsoff, ts);
+                            if (r == 1) stage16(I1{}, std::integral_constant<int, 1>{}, std::integral_constant<int, P16[1][1]>{}, sb16, wsoff, ts);
+                            if (r == 2) stage16(I1{}, std::integral_constant<int, 2>{}, std::integral_constant<int, P16[1][2]>{}, sb16, wsoff, ts);
+                            if (r == 3) stage16(I1{}, std::integral_constant<int, 3>{}, std::integral_constant<int, P16[1][3]>{}, sb16, wsoff, ts);
+                            if (r == 4) stage16(I1{}, std::integral_constant<int, 4>{}, std::integral_constant<int, P16[1][4]>{}, sb16, wsoff, ts);
+                        }
+                        sb16 = sb16 == 2 ? 0 : sb16 + 1;
+                    } else
                     if (h == 0) {
                         if (r == 0) stage(std::integral_constant<int, P0v[0][0]>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts);
                         if (r == 1) stage(std::integral_constant<int, P0v[0][1]>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts);
@@ -459,6 +648,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (BT_ON) { tstage += b3 - b2; tclose += b4 - b3; }
 #endif
             }
+            if constexpr (S16) {                               // a chunk pair is 25 steps: its last step left the next first fragments in set 1 — every pair starts from set 0
+#pragma unroll
+                for (int ii = 0; ii < NI; ++ii) wf16[0][ii] = wf16[1][ii];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) xf16[0][j] = xf16[1][j];
+            }
         }
         BT(b1);
 
@@ -477,6 +672,88 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // layout a lane stores 16 bytes of ITS pixel: 64 lines per instruction, and the 16-tile epilogue was bound by exactly that (9.5 k cycles for
         // 128 KB per CU, profiles/r05_b_big_timing_persistent.txt).  A wave's LDS operations execute in order: no wait between the patch's writes
         // and reads.  Forward: the BatchNorm sums of the pair's 2 x 16 channels per lane are taken from the same register copies.
+        if constexpr (S16) {
+            // 16x16 accumulator tiles: lane (c, q) holds channels 16 i + 4 q .. + 3 of pixel c of block j.  64 channels (four channel blocks = one 128-byte
+            // line per pixel) at a time, block by block, through the wave's patch [16 pixel rows][8 + 1 units]: the lane writes its 8 bytes of every
+            // channel block into row c (conflict-free ds_write_b64), reads back unit lane % 8 of rows lane / 8 and lane / 8 + 8, and 8 consecutive lanes
+            // store one pixel's whole line.  Forward: per-lane sums of the 16 (channel block, e) values over the wave's blocks, then row_colsum16 over
+            // the 16 pixel lanes of each DPP row: lane (c, q) ends with channel 64 hp + 16 (c >> 2) + 4 q + (c & 3) — 64 lanes, 64 channels.
+            constexpr int NPASS = NT / 64;
+            // the epilogue's lane tables are rebuilt here from an opaque copy of the lane id: as loop invariants they would be hoisted over the stage loop,
+            // where the register file has no room for them (spilled, and every reload inside the loop waits for vmcnt(0))
+            int lz = lane;
+            asm volatile("" : "+v"(lz));
+            const int cz = lz & 15, qz = lz >> 4;
+            char* const pw = reinterpret_cast<char*>(lds_patch + wave * (16 * 9)) + cz * 144 + 8 * qz;
+            const bf16x8* const pr = lds_patch + wave * (16 * 9) + (lz >> 3) * 9 + (lz & 7);
+            const unsigned pcol16 = (unsigned)(lz & 7) * 16u;
+            unsigned orow16[2][2];                             // byte offset (from the tile's first pixel) of the pixel rows lane / 8 and lane / 8 + 8 of block jh
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int mr = wave * 32 + s16_pix<H>(jh, (lz >> 3) + 8 * k), ir = mr / (T::TH * T::TW), rr = mr % (T::TH * T::TW);
+                    orow16[jh][k] = (unsigned)(((ir * H + rr / T::TW) * H + rr % T::TW) * NCH * 2);
+                }
+            if constexpr (BN) {
+                if (!allv) {
+#pragma unroll
+                    for (int tl = 0; tl < MT; ++tl)
+                        if (!validv[tl]) {
+#pragma unroll
+                            for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                                for (int ii = 0; ii < NI; ++ii) acc16[2 * tl + jh][ii] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                }
+            }
+#pragma unroll
+            for (int hp = 0; hp < NPASS; ++hp) {
+                [[maybe_unused]] float sv[16], qv[16];
+                if constexpr (BN) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) { sv[k] = 0.f; qv[k] = 0.f; }
+                }
+                bf16x8 rows[2];
+                unsigned rbase = BIG_OOB;
+                auto flush16 = [&](int jhp) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                        if (!(BIG_EXP & 64)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, rows[k]), rs_out, rbase == BIG_OOB ? BIG_OOB : rbase + orow16[jhp][k], 0, 0);
+                };
+#pragma unroll
+                for (int tl = 0; tl < MT; ++tl)
+#pragma unroll
+                    for (int jh = 0; jh < 2; ++jh) {
+                        const int j = 2 * tl + jh;
+#pragma unroll
+                        for (int il = 0; il < 4; ++il) {
+                            const int ii = hp * 4 + il;
+                            asm volatile("" : "+a"(acc16[j][ii]));      // one tile at a time out of the AGPRs (see the 32x32 epilogue)
+                            const f32x4 cv = acc16[j][ii];
+                            u32x2v pk;
+                            pk[0] = pack_bf16x2(cv[0], cv[1]); pk[1] = pack_bf16x2(cv[2], cv[3]);
+                            *reinterpret_cast<u32x2v*>(pw + 32 * il) = pk;
+                            if constexpr (BN && !(BIG_EXP & 16)) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { sv[il * 4 + e] += cv[e]; qv[il * 4 + e] = __builtin_fmaf(cv[e], cv[e], qv[il * 4 + e]); }
+                            }
+                        }
+                        asm volatile("" ::: "memory");
+                        if (j > 0) flush16(jh ^ 1);
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) rows[k] = pr[k * 8 * 9];
+                        rbase = validv[tl] ? ((unsigned)(cur.ibase[tl] / (KCH * 2)) * NCH + cur.n0 + hp * 64) * 2u + pcol16 : BIG_OOB;
+                        asm volatile("" ::: "memory");
+                    }
+                if constexpr (BN && !(BIG_EXP & 32)) {
+                    const float S = row_colsum16(sv), Q = row_colsum16(qv);
+                    const int ch = hp * 64 + 16 * (cz >> 2) + 4 * qz + (cz & 3);
+                    red[(0 * 4 + wave) * NT + ch] = S; red[(1 * 4 + wave) * NT + ch] = Q;
+                }
+                flush16(1);
+            }
+        } else {
         if constexpr (BN) {
             // ragged end only (wave-uniform, rare): the accumulators of tiles that do not exist hold the bias — zeroed, so that the sums below need no mask
             if (!allv) {
@@ -549,6 +826,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             flush_rows();                                      // the pair's last tile (behind the column sums: its patch reads have long landed)
         }
+        }
         if constexpr (BN) {                                    // the four waves' rows meet behind the NEXT barrier the workgroup passes anyway (bn_combine)
             pd_cnt = 0;
 #pragma unroll
@@ -580,7 +858,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 }
 
-template <int KCH, int NCH, int H, int NT, int MT, int KB, int EPI, bool IMGL = false>
+template <int KCH, int NCH, int H, int NT, int MT, int KB, int EPI, bool IMGL = false, bool S16 = false>
 static int run_big(const ConvBf16Args& a, hipStream_t st) {
     constexpr bool TDB = (MT == 4 || IMGL) && KB == 1;         // the 4 x 4 tile / the image layout leave LDS for a second set of input tiles
     using T = Tile<H>;
@@ -588,12 +866,12 @@ static int run_big(const ConvBf16Args& a, hipStream_t st) {
     constexpr int NY = NCH / NT;
     constexpr int NIMG = MT * 128 / (H * H), PAD = Bf16Geom<H, OCT>::PAD;
     constexpr int TILE_UNITS = IMGL ? OCT * (((NIMG * (H + 4) * (H + 4) + 15 - PAD) / 16) * 16 + PAD) : MT * OCT * Bf16Geom<H, OCT>::PSP;
-    constexpr int SMEM = ((TDB ? 2 : 1) * TILE_UNITS + 2 * 5 * KB * 2 * NT + 256 + 4 * 32 * 9) * 16 + (EPI == EPI_BIAS_BNSTAT ? (2 * 4 * NT + NCH) * 4 : 0);
+    constexpr int SMEM = ((TDB ? 2 : 1) * TILE_UNITS + (S16 ? 3 : 2) * 5 * KB * 2 * NT + 256 + (S16 ? 4 * 16 * 9 : 4 * 32 * 9)) * 16 + (EPI == EPI_BIAS_BNSTAT ? (2 * 4 * NT + NCH) * 4 : 0);
     static_assert(SMEM <= 160 * 1024, "LDS");
     // 32-bit byte offsets and buffer descriptors inside: larger tensors take the per-tile kernels (size_t addressing)
     if ((size_t)a.B * H * H * KCH * 2 >= (1ull << 31) || (size_t)a.B * H * H * NCH * 2 >= (1ull << 31)) return -100;
     if (g_conv_dry) return 0;
-    auto kern = conv5x5_bf16_big_kernel<KCH, NCH, H, NT, MT, KB, EPI, TDB, IMGL>;
+    auto kern = conv5x5_bf16_big_kernel<KCH, NCH, H, NT, MT, KB, EPI, TDB, IMGL, S16>;
     static DeviceOnce once;
     { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(kern), SMEM); if (rc) return rc; }
     const int numTiles = cdiv(a.B, T::IMGS) * T::TILES_PER_IMG, numGroups = cdiv(numTiles, MT);
@@ -617,6 +895,8 @@ static int run_big(const ConvBf16Args& a, hipStream_t st) {
 // bit 0 = E3 (64 -> 128), bit 1 = E4 (128 -> 256), both on the 4 x 4 tile.  Measured and not instantiated: E2 forward (32 -> 64) on the 8 x 2 tile —
 // eight 4-row tiles with their own halos are 98 KB of requests per 16-channel chunk and CU: 268-285 us against 219 us on the two-workgroup persistent
 // kernel (profiles/r05_e_kprof_conv_r4_vs_new.txt; it wants ONE image-high tile with one halo).
+// CVAE_BIG_S16 (experiment): the instantiations built on v_mfma_f32_16x16x32_bf16 (S16)
+static bool big_s16() { static const bool on = [] { const char* e = getenv("CVAE_BIG_S16"); return e && atoi(e) != 0; }(); return on; }
 bool conv_bf16_big_has(int layer, int width, bool dgrad, int mask) {
     if (width != 64 && width != 128) return false;
     if (dgrad) return (layer == 3 && (mask & 1)) || (layer == 2 && (mask & 2));
@@ -627,6 +907,7 @@ int conv_bf16_big_tiles(int layer, int width, bool dgrad) { (void)width; return 
 int launch_conv_bf16_big(int layer, int width, bool dgrad, int mask, const ConvBf16Args& a, hipStream_t st) {
     if (!conv_bf16_big_has(layer, width, dgrad, mask)) return -100;
     if (dgrad) {
+        if (width == 64 && layer == 3 && big_s16()) return run_big<256, 128, 8, 128, 4, 1, EPI_PLAIN, true, true>(a, st);
         if (width == 64 && layer == 3) return run_big<256, 128, 8, 128, 4, 1, EPI_PLAIN, BIG_IMGL>(a, st);
         if (width == 64 && layer == 2) return run_big<128, 64, 16, 64, 8, 1, EPI_PLAIN, BIG_IMGL>(a, st);
         if (width == 128 && layer == 3) return run_big<256, 128, 16, 128, 4, 1, EPI_PLAIN, BIG_IMGL>(a, st);
@@ -634,6 +915,7 @@ int launch_conv_bf16_big(int layer, int width, bool dgrad, int mask, const ConvB
     } else {
         if (width == 64 && layer == 1) return run_big<32, 64, 32, 64, 8, 1, EPI_BIAS_BNSTAT, true>(a, st);
         if (width == 64 && layer == 2) return run_big<64, 128, 16, 128, 4, 1, EPI_BIAS_BNSTAT, BIG_IMGL>(a, st);
+        if (width == 64 && layer == 3 && big_s16()) return run_big<128, 256, 8, 128, 4, 1, EPI_BIAS_BNSTAT, true, true>(a, st);
         if (width == 64 && layer == 3) return run_big<128, 256, 8, 128, 4, 1, EPI_BIAS_BNSTAT, BIG_IMGL>(a, st);
         if (width == 128 && layer == 2) return run_big<64, 128, 32, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);       // half an image per item: per-tile layout
         if (width == 128 && layer == 3) return run_big<128, 256, 16, 128, 4, 1, EPI_BIAS_BNSTAT, BIG_IMGL>(a, st);

@@ -346,20 +346,24 @@ def test_bf16x6_step_at_128x128_frames_meets_the_fp32_parity_bar():
     assert abs(float(losses["total_loss"].item()) - float(o["total_loss"].detach())) < 1e-4
 
 
-def test_big_tile_conv_kernels_every_instantiation_exact_on_their_stored_operands():
+@pytest.mark.parametrize("s16", ["0", "1"])
+def test_big_tile_conv_kernels_every_instantiation_exact_on_their_stored_operands(s16):
     """conv_bf16_big.hip (rounds 4-5: PERSISTENT workgroups on a 16-accumulator-tile wave tile, everything inside the MFMA stream) runs
     E3 / E4 forward and input gradient (and, behind its mask bit, E2 forward on an image-high item) by default.  At test batch sizes every item would get its own workgroup, so the item loop — next
     item's tiles and slabs requested across the epilogue, fragment sets and slab buffers carried over — would never run: a child process
     caps the grid at 8 workgroups (CVAE_BIG_MAXWG, read once per process) and runs the stored-operand test of this file — every conv
     output recomputed on the CPU from the bf16 operands the kernels consumed; B = 8, the ragged B = 5, and B = 37 (74 / 19 tiles: several
-    items per workgroup, uneven ends, partial groups, the forward kernels' four-tile BatchNorm partials)."""
+    items per workgroup, uneven ends, partial groups, the forward kernels' four-tile BatchNorm partials).  s16 = "1": the same with CVAE_BIG_S16=1 — E4's
+    two passes on the v_mfma_f32_16x16x32_bf16 form of the kernel (two taps per MFMA, three-slot slab ring, 16x16 accumulator tiles; an opt-in experiment,
+    profiles/r05_m_big_s16.txt) — plus the BatchNorm-partial geometry test below through that form."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CVAE_BF16_BIG="124", CVAE_BIG_MAXWG="8")
+    env = dict(os.environ, CVAE_BF16_BIG="124", CVAE_BIG_MAXWG="8", CVAE_BIG_S16=s16)
+    sel = "kernels_exact_on_their_stored_operands or two_pass_e1" + (" or (bn_partials_match and 64-5)" if s16 == "1" else "")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_bf16.py"), "-m", "gpu", "-q", "-x",
-                        "-k", "kernels_exact_on_their_stored_operands or two_pass_e1"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+                        "-k", sel], env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
 

@@ -40,10 +40,10 @@ enum { MODE_STD = 0, MODE_UP_FWD = 1, MODE_UP_DGRAD = 2 };
 #ifndef BF16_BIG_DEFAULT
 // CVAE_BF16_BIG: layers on the persistent 16-accumulator-tile kernel (conv_bf16_big.hip) — bit 2 = E4 input gradient, bit 3 = E3 input gradient, bit 4 = E3
 // forward, bit 5 = E4 forward, bit 6 = E2 forward at 64 x 64 (one BatchNorm partial per item of four / eight tiles); 0 = the two-workgroup kernels (A/B
-// runs).  Defaults from the un-profiled step on one box, masks alternating (profiles/r05_g_big_mask_sweep.txt, r05_k_big_image_layout.txt): 64 x 64 frames 44
-// (E4 both passes + E3 input gradient; E3 forward is 15-19 us faster as a kernel and the step no faster with it — the chip is at its power limit; E2 forward
-// loses as a kernel, 244 vs 205 us), 128 x 128 frames 60 (with the image layout E3's input gradient no longer spills on its 32-row item: +0.5 % on the step).
-#define BF16_BIG_DEFAULT 44
+// runs).  Defaults from the un-profiled step on one box, masks alternating (profiles/r05_g_big_mask_sweep.txt, r05_k_big_image_layout.txt): 60 at both frame
+// sizes since the image layout (E3 forward: 172 vs 187 us as a kernel, step +0.2 % in five alternations; before the image layout the step was 0.5 % SLOWER
+// with it — the chip is at its power limit; at 128 x 128 E3's input gradient no longer spills on its 32-row item: +0.5 %).  E2 forward loses as a kernel (244 vs 205 us).
+#define BF16_BIG_DEFAULT 60
 #endif
 #ifndef BF16_BIG_DEFAULT_W128
 #define BF16_BIG_DEFAULT_W128 60

@@ -1202,10 +1202,10 @@ __global__ __launch_bounds__(WT_NW * 64, 2) void conv5x5_wgrad_tr_kernel(WgradBf
 }
 
 template <int H>
-static int wgrad_bf16_splits(int B, int blocksPerSplit, int* tilesPerSplit, int* numTilesOut) {
+static int wgrad_bf16_splits(int B, int blocksPerSplit, int targetWgs, int* tilesPerSplit, int* numTilesOut) {
     using T = WtTile<H>;
     const int numTiles = cdiv(B, T::IMGS) * T::TPI;
-    int S = cdiv(512, blocksPerSplit);                // ~2 workgroups per CU
+    int S = cdiv(targetWgs, blocksPerSplit);
     if (S > numTiles) S = numTiles;
     if (S < 1) S = 1;
     const int tps = cdiv(numTiles, S);
@@ -1220,7 +1220,9 @@ static int run_wgrad_bf16(int B, const float* in, const float* dout, float* dw, 
     using T = WtTile<H>;
     int tps, numTiles;
     constexpr int COB = (CIN == 32 && COUT == 64) ? 2 : 1;              // E2: both output-channel halves in one workgroup
-    const int S = wgrad_bf16_splits<H>(B, (CIN / 32) * (COUT / (32 * COB)), &tps, &numTiles);
+    // split-K workgroups: two per CU for the 4-wave kernels (256 of them: E3 227 / E4 267 us instead of 197 / 202); ONE per CU for E2's 8-wave workgroups
+    // (195.6 instead of 207.1 us at B = 2048, and half the slab traffic: 52 instead of 105 MB written and re-read; profiles/r05_o_wgrad_split_count.txt)
+    const int S = wgrad_bf16_splits<H>(B, (CIN / 32) * (COUT / (32 * COB)), CIN == 32 ? 256 : 512, &tps, &numTiles);
     const int64_t n = (int64_t)25 * CIN * COUT, row = n + COUT;
     if (need) { *need = (int64_t)(S + 16) * row; return 0; }
     WgradBf16Args a{in, dout, ws, B, numTiles, tps};

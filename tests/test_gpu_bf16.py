@@ -515,8 +515,8 @@ def test_bf16_step_never_stores_y0_unless_a_block0_gamma_is_tiny(B, vec_bound, t
             assert gk[0] == 0 and rk[0] == 0          # gamma = 0, beta = 0: the channel's output is 0 everywhere and ReLU'(0) = 0 blocks its gradient
 
 
-@pytest.mark.parametrize("B", [8, 5, 37])      # 5, 37: ragged tile counts (the persistent D4 / MS-SSIM / E1 / conv loops end unevenly)
-def test_bf16_kernels_exact_on_their_stored_operands(B):
+@pytest.mark.parametrize("W,B", [(64, 8), (64, 5), (64, 37), (128, 5)])      # 5, 37: ragged tile counts (the persistent D4 / MS-SSIM / E1 / conv loops end unevenly);
+def test_bf16_kernels_exact_on_their_stored_operands(W, B):                       # 128 x 128: the other set of instantiations (every spatial size doubles)
     """Layout / indexing check of every bf16-mode contraction, independent of the bf16 rounding noise: after one
     bf16 step the workspace holds the bf16 activations and activation gradients the kernels actually consumed.
     Recomputing each layer's result on the CPU in fp32 from THOSE operands (weights rounded to bf16 as the packed
@@ -529,7 +529,7 @@ def test_bf16_kernels_exact_on_their_stored_operands(B):
     from critic_vae_amd.train import FusedTrainer
     from critic_vae_amd import layout as L
     dev = torch.device("cuda:0")
-    W = 64
+    m = W // 64
     vae = VariationalAutoencoder(width=W, max_batch=B, seed=0, precision="bf16").to(dev)
     tr = FusedTrainer(vae)
     x, pred, eps = (torch.from_numpy(v).to(dev) for v in synth.make_batch(1234, 0, B, W))
@@ -540,7 +540,7 @@ def test_bf16_kernels_exact_on_their_stored_operands(B):
     torch.cuda.synchronize()
     from ws_tools import recompute_d_y0
     # neither y0 nor block 0's dy is stored: both exist only inside the fused E1 weight-gradient kernel
-    d_y0 = recompute_d_y0(h, tr.ws, B, bf16_storage=True, x=x, theta=theta).view(torch.bfloat16)
+    d_y0 = recompute_d_y0(h, tr.ws, B, width=W, bf16_storage=True, x=x, theta=theta).view(torch.bfloat16)
     ws16 = tr.ws.view(torch.bfloat16)
 
     def act(name, c, s):            # stored bf16 NHWC tensor -> fp32 NCHW on the CPU
@@ -553,8 +553,8 @@ def test_bf16_kernels_exact_on_their_stored_operands(B):
     ref = L.native_to_ref(h.layout, theta.cpu())
     grd = L.native_to_ref(h.layout, tr.grads.cpu())
     bf = lambda t: t.to(torch.bfloat16).float()      # noqa: E731
-    enc = [(3, 32, 64), (32, 64, 32), (64, 128, 16), (128, 256, 8)]
-    dec = [(256, 128, 4), (128, 64, 8), (64, 32, 16), (32, 32, 32), (32, 3, 64)]
+    enc = [(3, 32, 64 * m), (32, 64, 32 * m), (64, 128, 16 * m), (128, 256, 8 * m)]
+    dec = [(256, 128, 4 * m), (128, 64, 8 * m), (64, 32, 16 * m), (32, 32, 32 * m), (32, 3, 64 * m)]
 
     def close(got, want, what, rel):
         scale = want.abs().max().item()
@@ -580,7 +580,7 @@ def test_bf16_kernels_exact_on_their_stored_operands(B):
             close(act(f"d_a{l - 1}", ci, s), da, f"d_a{l - 1}", 2.0 ** -8)
     # ---- decoder: D0 plain, D1..D3 behind a nearest-2x upsample (phase-collapsed in the kernels) ----
     for i, (ci, co, s) in enumerate(dec[:4]):
-        src = act("h", 256, 4) if i == 0 else act(f"o{i - 1}", ci, s // 2)
+        src = act("h", 256, 4 * m) if i == 0 else act(f"o{i - 1}", ci, s // 2)
         inp = src if i == 0 else F.interpolate(src, scale_factor=2, mode="nearest")
         wk, bk = f"decoder.model.{3 * i}.weight", f"decoder.model.{3 * i}.bias"
         o = torch.relu(F.conv2d(inp, bf(ref[wk]), ref[bk], padding=2))
@@ -593,18 +593,18 @@ def test_bf16_kernels_exact_on_their_stored_operands(B):
     # ---- decoder_input: [zcat | 1]^T . d_h ----
     off = h.lib.cvae_ws_offset(h.h, B, b"zcat")
     zcat = tr.ws[off:off + B * 33].view(B, 33).cpu()
-    dh = act("d_h", 256, 4)                                            # (B,256,4,4) = the reference's view(-1,256,4,4)
+    dh = act("d_h", 256, 4 * m)                                        # (B,256,4,4) = the reference's view(-1,256,4,4)
     dwd = bf(zcat).t() @ dh.reshape(B, -1)                             # (33, 4096) in (C,H,W) column order
     close(grd["decoder.decoder_input.weight"], dwd.t().contiguous(), "dW decoder_input", 2e-3)
     close(grd["decoder.decoder_input.bias"], dh.reshape(B, -1).sum(0), "db decoder_input", 2e-3)
     # ---- D4 (Upsample -> Conv(32->3) -> Tanh): forward on exact bf16 products; backward through G rounded to bf16 ----
-    o3 = act("o3", 32, 32)
+    o3 = act("o3", 32, 32 * m)
     up3 = F.interpolate(o3, scale_factor=2, mode="nearest")
     w4, b4 = ref["decoder.model.12.weight"], ref["decoder.model.12.bias"]
     # the forward kernel contracts the PHASE-COLLAPSED 3x3 weights (sums of the 5x5 taps that reach one source pixel from
     # one output phase), summed in fp32 and rounded to bf16 once: reproduce exactly that
     taps = {0: [[0, 1], [2, 3], [4]], 1: [[0], [1, 2], [3, 4]]}
-    pre = torch.empty(B, 3, 64, 64)
+    pre = torch.empty(B, 3, W, W)
     for py in (0, 1):
         for px in (0, 1):
             wc = torch.zeros(3, 32, 3, 3)
@@ -622,7 +622,7 @@ def test_bf16_kernels_exact_on_their_stored_operands(B):
     close(grd["decoder.model.12.bias"], db4, "db dec4", 1e-4)            # summed in fp32 from dOut itself
     d_up = F.conv_transpose2d(dout, bf(w4), padding=2)
     d_o3 = F.avg_pool2d(d_up, 2) * 4.0 * (o3 > 0).float()                # Upsample backward = 2x2 sum, then the ReLU mask
-    close(act("d_o3", 32, 32), d_o3, "d_o3", 2.0 ** -6)
+    close(act("d_o3", 32, 32 * m), d_o3, "d_o3", 2.0 ** -6)
 
 
 @pytest.mark.parametrize("B", [40, 1029])      # 40: two ragged 32-image groups, four / two K slices;  1029: the large-batch paths

@@ -38,12 +38,12 @@ enum { MODE_STD = 0, MODE_UP_FWD = 1, MODE_UP_DGRAD = 2 };
 #define BF16_MT 2          // 128-pixel tiles per workgroup of the plain bf16 kernels (1 = round-1 structure)
 #endif
 #ifndef BF16_BIG_DEFAULT
-// CVAE_BF16_BIG: layers on the persistent 16-accumulator-tile kernel (conv_bf16_big.hip) — bit 2 = E4 input gradient, bit 3 = E3 input gradient, bit 4 = E3
-// forward, bit 5 = E4 forward, bit 6 = E2 forward at 64 x 64 (one BatchNorm partial per item of four / eight tiles); 0 = the two-workgroup kernels (A/B
-// runs).  Defaults from the un-profiled step on one box, masks alternating (profiles/r05_g_big_mask_sweep.txt, r05_k_big_image_layout.txt): 60 at both frame
-// sizes since the image layout (E3 forward: 172 vs 187 us as a kernel, step +0.2 % in five alternations; before the image layout the step was 0.5 % SLOWER
-// with it — the chip is at its power limit; at 128 x 128 E3's input gradient no longer spills on its 32-row item: +0.5 %).  E2 forward loses as a kernel (244 vs 205 us).
-#define BF16_BIG_DEFAULT 60
+// CVAE_BF16_BIG: layers on the persistent big-tile kernel (conv_bf16_big.hip) — bit 2 = E4 input gradient, bit 3 = E3 input gradient, bit 4 = E3 forward,
+// bit 5 = E4 forward, bit 6 = E2 forward and bit 7 = E2 input gradient at 64 x 64 (image-high items on an 8 x 1 wave tile; one BatchNorm partial per item of
+// four / eight tiles); 0 = the two-workgroup / per-tile kernels (A/B runs).  Defaults from the un-profiled step on one box, masks alternating
+// (profiles/r05_g_big_mask_sweep.txt, r05_k_big_image_layout.txt, r05_r_e2_on_big_kernel.txt): every bit at 64 x 64 (252: E2 forward 196 vs 209 us, E2 input gradient
+// 192 vs 209 us, step +0.8 % over mask 60), 60 at 128 x 128 (E2's 64-row images have no whole-image item).
+#define BF16_BIG_DEFAULT 252
 #endif
 #ifndef BF16_BIG_DEFAULT_W128
 #define BF16_BIG_DEFAULT_W128 60
@@ -867,7 +867,7 @@ static int bf16_big_mask(int width) {
 static int try_persistent_bf16(int layer, int width, bool dgrad, const ConvBf16Args& a, hipStream_t st, int* family) {
     *family = 0;
     const int big = bf16_big_mask(width);
-    const int m = dgrad ? (big >> 2) & 3 : (big >> 4) & 7;        // bits 2 / 3: E4 / E3 input gradient; bits 4 / 5 / 6: E3 / E4 / E2 forward
+    const int m = dgrad ? ((big >> 2) & 3) | ((big >> 5) & 4) : (big >> 4) & 7;      // bits 2 / 3 / 7: E4 / E3 / E2 input gradient; bits 4 / 5 / 6: E3 / E4 / E2 forward
     if (m) { const int rc = launch_conv_bf16_big(layer, width, dgrad, m, a, st); if (rc != -100) { *family = 2; return rc; } }
     if (use_ps_kernel(layer, dgrad)) { const int rc = launch_conv_bf16_ps(layer, width, dgrad, a, st); if (rc != -100) { *family = 1; return rc; } }
     return 0;

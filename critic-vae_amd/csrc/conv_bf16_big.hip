@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int NB = NT / 32, KS = 5, KCB = 16 * KB, OCT = KCB / 8, NY = NCH / NT;
     constexpr int PSP = Bf16Geom<H, OCT>::PSP, A_UNITS = OCT * PSP, W_UNITS = KS * KB * 2 * NT;
     constexpr int NCHUNK = KCH / KCB, NST = NCHUNK * KS, NSTEP = KS * KB;
-    static_assert(KCH % KCB == 0 && NCH % NT == 0 && MT * NB == 16 && (KB == 1 || KB == 2), "tiling");
+    static_assert(KCH % KCB == 0 && NCH % NT == 0 && (MT * NB == 16 || (MT == 8 && NB == 1)) && (KB == 1 || KB == 2), "tiling");       // 8 x 1: a 32-channel layer (E2's input gradient) fills half the accumulators
     // IMGL (image layout, round 5): an item's MT tiles are NIMG WHOLE images, kept in LDS as ONE plane per octet of (H + 4) x (H + 4) halo images.
     // Every halo pixel of a whole image is zero padding: the planes are zeroed once per kernel and only the H x H interiors are ever staged —
     // 128 instead of 288 units per 8 x 8-image tile, 1024 instead of 2304 for a 32 x 32 image cut into eight 4-row tiles (the tiles of the
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // epilogue patch of this wave: [32 pixel rows][RU0 = 8 units of 8 channels + 1 pad] = the wave's pixels x 64 channels (two channel blocks: one
     // 128-byte line per pixel); lane (li, lh) writes units 4 nb' + 2 k + lh of row li, and reads back unit (lane % 8) of rows (lane / 8) + 8 k:
     // orow[k] = byte offset of that row's pixel from the tile's first pixel, pcol = of the unit
-    constexpr int HB = 2, NH = NB / HB, RU0 = HB * 4, PRS = RU0 + 1, PPI = 64 / RU0, PIT = 32 / PPI;
+    constexpr int HB = NB % 2 == 0 ? 2 : 1, NH = NB / HB, RU0 = HB * 4, PRS = RU0 + 1, PPI = 64 / RU0, PIT = 32 / PPI;     // HB = 1 (NB = 1): 64-byte rows, 16 pixels per store instruction
     static_assert(NB % HB == 0, "the epilogue walks the channel blocks in pairs");
     bf16x8* const patch = lds_patch + wave * (32 * PRS);
     bf16x8* const patch_w = patch + li * PRS + lh;
@@ -860,6 +860,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 template <int KCH, int NCH, int H, int NT, int MT, int KB, int EPI, bool IMGL = false, bool S16 = false>
 static int run_big(const ConvBf16Args& a, hipStream_t st) {
+    // (8 x 1 wave tile, E2's input gradient: 8 accumulator tiles = 256 registers would let TWO workgroups share a CU with single-buffered tiles — measured:
+    //  194.0 us against 192.1 for one workgroup with double-buffered tiles, step level; profiles/r05_r_e2_on_big_kernel.txt)
     constexpr bool TDB = (MT == 4 || IMGL) && KB == 1;         // the 4 x 4 tile / the image layout leave LDS for a second set of input tiles
     using T = Tile<H>;
     constexpr int OCT = 2 * KB;
@@ -890,16 +892,16 @@ static int run_big(const ConvBf16Args& a, hipStream_t st) {
     return 0;
 }
 
-// Which layers this file serves, by mask bit: input gradients — bit 0 = E4 (256 -> 128, 4 x 4 tile), bit 1 = E3 (128 -> 64, 8 x 2 tile, single-buffered
-// input tiles); forward (bias + ONE BatchNorm partial per item of conv_bf16_big_tiles(..) tiles — the kernel that ran tells launch_bn_fwd_finalize) —
-// bit 0 = E3 (64 -> 128), bit 1 = E4 (128 -> 256), both on the 4 x 4 tile.  Measured and not instantiated: E2 forward (32 -> 64) on the 8 x 2 tile —
-// eight 4-row tiles with their own halos are 98 KB of requests per 16-channel chunk and CU: 268-285 us against 219 us on the two-workgroup persistent
-// kernel (profiles/r05_e_kprof_conv_r4_vs_new.txt; it wants ONE image-high tile with one halo).
+// Which layers this file serves, by mask bit: input gradients — bit 0 = E4 (256 -> 128, 4 x 4 wave tile), bit 1 = E3 (128 -> 64, 8 x 2), bit 2 = E2 at 64 x 64 (64 -> 32:
+// an image-high item on an 8 x 1 wave tile, 9 fragment reads per 8 MFMAs where the per-tile kernel reads 12: 192 vs 209 us); forward (bias + ONE BatchNorm partial per
+// item of conv_bf16_big_tiles(..) tiles — the kernel that ran tells launch_bn_fwd_finalize) — bit 0 = E3 (64 -> 128), bit 1 = E4 (128 -> 256), both 4 x 4, bit 2 = E2 at
+// 64 x 64 (32 -> 64 as two 32-channel halves of an image-high item, 8 x 1: 196 vs 209 us on the two-workgroup persistent kernel; as ONE 8 x 2 item it lost, 244 us:
+// its 16-tile BatchNorm epilogue was half of a 10-stage item, profiles/r05_k_big_image_layout.txt).
 // CVAE_BIG_S16 (experiment): the instantiations built on v_mfma_f32_16x16x32_bf16 (S16)
 static bool big_s16() { static const bool on = [] { const char* e = getenv("CVAE_BIG_S16"); return e && atoi(e) != 0; }(); return on; }
 bool conv_bf16_big_has(int layer, int width, bool dgrad, int mask) {
     if (width != 64 && width != 128) return false;
-    if (dgrad) return (layer == 3 && (mask & 1)) || (layer == 2 && (mask & 2));
+    if (dgrad) return (layer == 3 && (mask & 1)) || (layer == 2 && (mask & 2)) || (layer == 1 && width == 64 && (mask & 4));
     return (layer == 2 && (mask & 1)) || (layer == 3 && (mask & 2)) || (layer == 1 && width == 64 && (mask & 4));
 }
 int conv_bf16_big_tiles(int layer, int width, bool dgrad) { (void)width; return ((dgrad && layer == 2) || (!dgrad && layer == 1)) ? 8 : 4; }
@@ -910,10 +912,11 @@ int launch_conv_bf16_big(int layer, int width, bool dgrad, int mask, const ConvB
         if (width == 64 && layer == 3 && big_s16()) return run_big<256, 128, 8, 128, 4, 1, EPI_PLAIN, true, true>(a, st);
         if (width == 64 && layer == 3) return run_big<256, 128, 8, 128, 4, 1, EPI_PLAIN, BIG_IMGL>(a, st);
         if (width == 64 && layer == 2) return run_big<128, 64, 16, 64, 8, 1, EPI_PLAIN, BIG_IMGL>(a, st);
+        if (width == 64 && layer == 1) return run_big<64, 32, 32, 32, 8, 1, EPI_PLAIN, true>(a, st);        // E2: image-high item, 8 x 1 wave tile
         if (width == 128 && layer == 3) return run_big<256, 128, 16, 128, 4, 1, EPI_PLAIN, BIG_IMGL>(a, st);
         if (width == 128 && layer == 2) return run_big<128, 64, 32, 64, 8, 1, EPI_PLAIN, BIG_IMGL>(a, st);
     } else {
-        if (width == 64 && layer == 1) return run_big<32, 64, 32, 64, 8, 1, EPI_BIAS_BNSTAT, true>(a, st);
+        if (width == 64 && layer == 1) return run_big<32, 64, 32, 32, 8, 1, EPI_BIAS_BNSTAT, true>(a, st);      // 8 x 1 (two channel halves per image); 8 x 2: 244 us
         if (width == 64 && layer == 2) return run_big<64, 128, 16, 128, 4, 1, EPI_BIAS_BNSTAT, BIG_IMGL>(a, st);
         if (width == 64 && layer == 3 && big_s16()) return run_big<128, 256, 8, 128, 4, 1, EPI_BIAS_BNSTAT, true, true>(a, st);
         if (width == 64 && layer == 3) return run_big<128, 256, 8, 128, 4, 1, EPI_BIAS_BNSTAT, BIG_IMGL>(a, st);

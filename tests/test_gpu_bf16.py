@@ -360,7 +360,7 @@ def test_big_tile_conv_kernels_every_instantiation_exact_on_their_stored_operand
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CVAE_BF16_BIG="124", CVAE_BIG_MAXWG="8", CVAE_BIG_S16=s16)
+    env = dict(os.environ, CVAE_BF16_BIG="252", CVAE_BIG_MAXWG="8", CVAE_BIG_S16=s16)
     sel = "kernels_exact_on_their_stored_operands or two_pass_e1" + (" or (bn_partials_match and 64-5)" if s16 == "1" else "")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_bf16.py"), "-m", "gpu", "-q", "-x",
                         "-k", sel], env=env, capture_output=True, text=True, timeout=900, cwd=root)
@@ -373,7 +373,7 @@ def test_big_tile_bn_partials_match_the_per_tile_kernels(W, B, tmp_path):
     """The persistent big-tile forward kernels emit ONE BatchNorm partial per item of four 128-pixel tiles, and launch_bn_fwd_finalize derives the
     pixel count of every partial from the tile geometry: a quarter of an image (tiles per image >= 4: E3 at 128 x 128), two whole images (two tiles
     per image: E4 at 128 x 128, E3 at 64 x 64), four half-filled... (8 x 8 images: E4 at 64 x 64), with ragged ends at odd batch sizes.  Two child
-    processes (the switch is read once per process) run the same bf16 forward with the big-tile kernels (CVAE_BF16_BIG=124: all five) and with
+    processes (the switch is read once per process) run the same bf16 forward with the big-tile kernels (CVAE_BF16_BIG=252: all six) and with
     the per-tile / two-workgroup kernels (0): the running statistics — sums over ALL pixels, merged from differently grouped partials — must agree
     to fp32 summation noise, the outputs to bf16 noise.  A wrong count or a wrong partial row would be off by whole percents."""
     import os
@@ -381,13 +381,13 @@ def test_big_tile_bn_partials_match_the_per_tile_kernels(W, B, tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for mask in ("124", "0"):
+    for mask in ("252", "0"):
         out = str(tmp_path / f"bn_{mask}.npz")
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "bn_geom_worker.py"), str(W), str(B), out],
                            env=dict(os.environ, CVAE_BF16_BIG=mask), capture_output=True, text=True, timeout=300, cwd=root)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         res[mask] = np.load(out)
-    a, b = res["124"], res["0"]
+    a, b = res["252"], res["0"]
     for bi in (1, 5, 9, 13):
         for k in (f"rm{bi}", f"rv{bi}"):
             scale = max(float(np.abs(b[k]).max()), 1e-6)

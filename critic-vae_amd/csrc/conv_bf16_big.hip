@@ -56,6 +56,9 @@ typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 #ifndef BIG_EXP
 #define BIG_EXP 0
 #endif
+#ifndef BIG_ALLC
+#define BIG_ALLC true      // false (A/B builds): E2's input gradient requests its tiles chunk by chunk like the others
+#endif
 #ifndef BIG_IMGL
 #define BIG_IMGL true      // false (A/B builds): the per-tile halo layout for the instantiations that existed before the image layout
 #endif
@@ -91,7 +94,7 @@ __device__ __forceinline__ float row_colsum16(const float (&x)[16]) {
     return (b0 ? r2[1] : r2[0]) + dpp_mov<0xB1>(b0 ? r2[0] : r2[1]);                                                // partner i ^ 1
 }
 
-template <int KCH, int NCH, int H, int NT, int MT, int KB, int EPI, bool TDB, bool IMGL, bool S16 = false>
+template <int KCH, int NCH, int H, int NT, int MT, int KB, int EPI, bool TDB, bool IMGL, bool S16 = false, bool ALLC = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv5x5_bf16_big_kernel(ConvBf16Args a, int numGroups) {
     using T = Tile<H>;
     static_assert(EPI == EPI_PLAIN || EPI == EPI_BIAS_BNSTAT, "epilogues: plain (input gradient) or bias + BatchNorm partials (forward)");
@@ -276,6 +279,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int u = 0; u < NU; ++u) store_unit(u, 0);
     };
 
+    // ALLC (round 5, E2's input gradient: KCH = 64, one 128-byte line per pixel): the 16-channel chunks take 32 bytes of every pixel's line, the item walks all its
+    // pixels once per chunk, and HBM moves whole lines (profiles/experiments/partial_line_probe.hip) — chunk by chunk each line was fetched 2.4 times.  All NCHUNK
+    // chunks of the NEXT item are therefore requested together, in the item's last chunk: chunk 0 goes to LDS as before, chunks 1.. wait in registers (hreg: the 8 x 1
+    // wave tile leaves 290 of them unused) and are written into the tile buffer that has just become free, one chunk later each.
+    static_assert(!ALLC || (TDB && IMGL && !S16 && NCHUNK <= 4 && NU <= 8), "ALLC: image layout, double-buffered tiles, at most four chunks");
+    [[maybe_unused]] bf16x8 hreg[ALLC ? (NCHUNK - 1) * NU : 1];
+    [[maybe_unused]] auto load_unit_to = [&](bf16x8& dst, int uu, unsigned soff) {
+        const int cimg = (uu * UPX) / (H * H);
+        const unsigned v = (NIMG == 1 || pimg0 < nv_req - cimg) ? irel0 : BIG_OOB;
+        dst = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v, soff + (unsigned)(uu * UPX * KCH * 2), 0));
+    };
+    [[maybe_unused]] auto store_unit_from = [&](const bf16x8& src, int uu, int tb) {
+        const int clds = ((uu * UPX) / (H * H)) * (HW * HW) + (((uu * UPX) % (H * H)) / H) * HW;
+        lds_a[tb * TILE_UNITS + clds + ilds0] = src;
+    };
     f32x16 acc[MT][NB];
     bf16x8 wf[2][NB], xf[2][MT];                               // two fragment sets, alternating per step (they live across stages)
     auto ldf = [&](int set, int i, int r, int buf, int tb = 0) {   // fragments of step i of a stage (kernel row r, slab buffer buf, tile buffer tb)
@@ -311,7 +329,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const __amdgpu_buffer_rsrc_t rs_steps = big_rsrc(big_steps, (unsigned)sizeof(big_steps));
 #endif
     static_assert(!TDB || (KB == 1 && NU <= 12), "the unit schedule of the double-buffered tiles: 6 slots of two units");
-    auto stage = [&](auto p0c, auto rc, auto tbc, int gst, unsigned wsoff, const unsigned (&tsoff)[MT]) {
+    auto stage = [&](auto p0c, auto rc, auto tbc, int gst, unsigned wsoff, const unsigned (&tsoff)[MT], [[maybe_unused]] int ci = 0) {
         constexpr int P0 = decltype(p0c)::value, R = decltype(rc)::value, TB = decltype(tbc)::value;       // TB: tile buffer of this chunk (TDB)
         constexpr int RN = R == KS - 1 ? 0 : R + 1;
         const int buf = gst & 1;
@@ -338,7 +356,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             } else ldf(set ^ 1, i + 1, R, buf, TB);
             if (i < WN && !(BIG_EXP & 2)) store_w(WU * i, WU * (i + 1), buf ^ 1);
             if (i == WN && !(BIG_EXP & 4)) load_w(wsoff);
-            if constexpr (TDB) {
+            if constexpr (ALLC) {
+                // ci = this chunk's index in the item (a constant after unrolling).  Last chunk: the next item's NCHUNK x NU units are requested four per step in rows
+                // 0..3 (chunk 0 first: it is written below, in this chunk); other chunks: no request, chunk ci + 1 leaves hreg for the free tile buffer.
+                if (ci == NCHUNK - 1 && R <= 3 && (i == 3 || i == 4) && !(BIG_EXP & 8)) {
+                    const int sl = R * 2 + (i - 3);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int u = 4 * sl + q, k = u / NU, uu = u % NU;
+                        if (u < NCHUNK * NU) { if (k == 0) load_unit_to(breg[uu], uu, tsoff[0]); else load_unit_to(hreg[(k - 1) * NU + uu], uu, tsoff[0] + (unsigned)(k * KCB * 2)); }
+                    }
+                }
+                if ((((R == 2 || R == 3) && (i == 3 || i == 4)) || (R == 4 && (i == 2 || i == 3))) && !(BIG_EXP & 8)) {
+                    const int sl = R == 4 ? 4 + (i - 2) : (R - 2) * 2 + (i - 3);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int uu = 2 * sl + q;
+                        if (uu < NU) { if (ci == NCHUNK - 1) store_unit_from(breg[uu], uu, TB ^ 1); else store_unit_from(hreg[(ci < NCHUNK - 1 ? ci : 0) * NU + uu], uu, TB ^ 1); }
+                    }
+                }
+            } else if constexpr (TDB) {
                 // the tile stream, two units per step (the 12 requests of a chunk in ONE step held the wave at the texture unit for 800 cycles, and
                 // their 12 LDS writes + a second barrier closed every chunk: 1.7 k of a 16.4 k-cycle chunk, profiles/r05_f_big_steptime.txt)
                 if (R <= 2 && (i == 3 || i == 4) && !(BIG_EXP & 8)) { const int sl = R * 2 + (i - 3); load_unit(2 * sl, tsoff); load_unit(2 * sl + 1, tsoff); }
@@ -523,6 +560,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int tl = 0; tl < MT; ++tl) ts[tl] = (unsigned)cur.ibase[tl];
         load_w(slab_soff(cur.n0, 0));
         load_input(ts);
+        if constexpr (ALLC) {
+#pragma unroll
+            for (int k = 1; k < NCHUNK; ++k)
+#pragma unroll
+                for (int uu = 0; uu < NU; ++uu) load_unit_to(hreg[(k - 1) * NU + uu], uu, ts[0] + (unsigned)(k * KCB * 2));
+        }
     }
     store_input();
     store_w(0, WPT, 0);
@@ -577,6 +620,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // Two chunks per trip (the fragment sets alternate per step, a chunk has KS x NSTEP steps), kernel rows unrolled.  Slab st + 1 is
         // travelling in wreg when stage st starts (requested by stage st - 1, by the previous item's last stage, or by the prologue).
         static_assert(NCHUNK % 2 == 0, "chunks are walked in pairs");
+        constexpr int PAIR_UNROLL = ALLC ? NCHUNK / 2 : 1;     // ALLC: the chunk index is a constant in every stage
+#pragma unroll PAIR_UNROLL
         for (int cp = 0; cp < NCHUNK; cp += 2) {
 #ifdef BIG_STEPTIME
             steptime_on = BT_ON && blockIdx.x == 0 && steptime_first && cp == (NCHUNK >= 4 ? 2 : 0);
@@ -623,17 +668,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         sb16 = sb16 == 2 ? 0 : sb16 + 1;
                     } else
                     if (h == 0) {
-                        if (r == 0) stage(std::integral_constant<int, P0v[0][0]>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts);
-                        if (r == 1) stage(std::integral_constant<int, P0v[0][1]>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts);
-                        if (r == 2) stage(std::integral_constant<int, P0v[0][2]>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts);
-                        if (r == 3) stage(std::integral_constant<int, P0v[0][3]>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts);
-                        if (r == 4) stage(std::integral_constant<int, P0v[0][4]>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts);
+                        if (r == 0) stage(std::integral_constant<int, P0v[0][0]>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts, cc);
+                        if (r == 1) stage(std::integral_constant<int, P0v[0][1]>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts, cc);
+                        if (r == 2) stage(std::integral_constant<int, P0v[0][2]>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts, cc);
+                        if (r == 3) stage(std::integral_constant<int, P0v[0][3]>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts, cc);
+                        if (r == 4) stage(std::integral_constant<int, P0v[0][4]>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts, cc);
                     } else {
-                        if (r == 0) stage(std::integral_constant<int, P0v[1][0]>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts);
-                        if (r == 1) stage(std::integral_constant<int, P0v[1][1]>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts);
-                        if (r == 2) stage(std::integral_constant<int, P0v[1][2]>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts);
-                        if (r == 3) stage(std::integral_constant<int, P0v[1][3]>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts);
-                        if (r == 4) stage(std::integral_constant<int, P0v[1][4]>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts);
+                        if (r == 0) stage(std::integral_constant<int, P0v[1][0]>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts, cc);
+                        if (r == 1) stage(std::integral_constant<int, P0v[1][1]>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts, cc);
+                        if (r == 2) stage(std::integral_constant<int, P0v[1][2]>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts, cc);
+                        if (r == 3) stage(std::integral_constant<int, P0v[1][3]>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts, cc);
+                        if (r == 4) stage(std::integral_constant<int, P0v[1][4]>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts, cc);
                     }
                     ++gst;
                     if (BN && h == 0 && r == 0 && cp == 0) bn_combine();      // behind stage 0's barrier: the previous item's rows are complete
@@ -858,7 +903,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 }
 
-template <int KCH, int NCH, int H, int NT, int MT, int KB, int EPI, bool IMGL = false, bool S16 = false>
+template <int KCH, int NCH, int H, int NT, int MT, int KB, int EPI, bool IMGL = false, bool S16 = false, bool ALLC = false>
 static int run_big(const ConvBf16Args& a, hipStream_t st) {
     // (8 x 1 wave tile, E2's input gradient: 8 accumulator tiles = 256 registers would let TWO workgroups share a CU with single-buffered tiles — measured:
     //  194.0 us against 192.1 for one workgroup with double-buffered tiles, step level; profiles/r05_r_e2_on_big_kernel.txt)
@@ -873,7 +918,7 @@ static int run_big(const ConvBf16Args& a, hipStream_t st) {
     // 32-bit byte offsets and buffer descriptors inside: larger tensors take the per-tile kernels (size_t addressing)
     if ((size_t)a.B * H * H * KCH * 2 >= (1ull << 31) || (size_t)a.B * H * H * NCH * 2 >= (1ull << 31)) return -100;
     if (g_conv_dry) return 0;
-    auto kern = conv5x5_bf16_big_kernel<KCH, NCH, H, NT, MT, KB, EPI, TDB, IMGL, S16>;
+    auto kern = conv5x5_bf16_big_kernel<KCH, NCH, H, NT, MT, KB, EPI, TDB, IMGL, S16, ALLC>;
     static DeviceOnce once;
     { int rc = cvae_grant_lds(once, reinterpret_cast<const void*>(kern), SMEM); if (rc) return rc; }
     const int numTiles = cdiv(a.B, T::IMGS) * T::TILES_PER_IMG, numGroups = cdiv(numTiles, MT);
@@ -912,7 +957,7 @@ int launch_conv_bf16_big(int layer, int width, bool dgrad, int mask, const ConvB
         if (width == 64 && layer == 3 && big_s16()) return run_big<256, 128, 8, 128, 4, 1, EPI_PLAIN, true, true>(a, st);
         if (width == 64 && layer == 3) return run_big<256, 128, 8, 128, 4, 1, EPI_PLAIN, BIG_IMGL>(a, st);
         if (width == 64 && layer == 2) return run_big<128, 64, 16, 64, 8, 1, EPI_PLAIN, BIG_IMGL>(a, st);
-        if (width == 64 && layer == 1) return run_big<64, 32, 32, 32, 8, 1, EPI_PLAIN, true>(a, st);        // E2: image-high item, 8 x 1 wave tile
+        if (width == 64 && layer == 1) return run_big<64, 32, 32, 32, 8, 1, EPI_PLAIN, true, false, BIG_ALLC>(a, st);      // E2: image-high item, 8 x 1 wave tile, whole lines fetched once
         if (width == 128 && layer == 3) return run_big<256, 128, 16, 128, 4, 1, EPI_PLAIN, BIG_IMGL>(a, st);
         if (width == 128 && layer == 2) return run_big<128, 64, 32, 64, 8, 1, EPI_PLAIN, BIG_IMGL>(a, st);
     } else {

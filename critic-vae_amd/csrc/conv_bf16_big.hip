@@ -56,6 +56,12 @@ typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 #ifndef BIG_EXP
 #define BIG_EXP 0
 #endif
+#ifndef BIG_ALLC4
+#define BIG_ALLC4 false    // experiment builds: the same for E4's input gradient (4 lines per pixel, groups of four chunks)
+#endif
+#ifndef BIG_ALLC3
+#define BIG_ALLC3 false    // ... and E3's (2 lines per pixel)
+#endif
 #ifndef BIG_ALLC
 #define BIG_ALLC true      // false (A/B builds): E2's input gradient requests its tiles chunk by chunk like the others
 #endif
@@ -283,8 +289,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // pixels once per chunk, and HBM moves whole lines (profiles/experiments/partial_line_probe.hip) — chunk by chunk each line was fetched 2.4 times.  All NCHUNK
     // chunks of the NEXT item are therefore requested together, in the item's last chunk: chunk 0 goes to LDS as before, chunks 1.. wait in registers (hreg: the 8 x 1
     // wave tile leaves 290 of them unused) and are written into the tile buffer that has just become free, one chunk later each.
-    static_assert(!ALLC || (TDB && IMGL && !S16 && NCHUNK <= 4 && NU <= 8), "ALLC: image layout, double-buffered tiles, at most four chunks");
-    [[maybe_unused]] bf16x8 hreg[ALLC ? (NCHUNK - 1) * NU : 1];
+    // More than four chunks (KCH > 64: several lines per pixel): the same in GROUPS of four chunks = one line — the group's last chunk requests the next group.
+    static_assert(!ALLC || (TDB && IMGL && !S16 && NCHUNK % 4 == 0 && NU <= 8), "ALLC: image layout, double-buffered tiles, chunks in groups of four");
+    [[maybe_unused]] bf16x8 hreg[ALLC ? 3 * NU : 1];
     [[maybe_unused]] auto load_unit_to = [&](bf16x8& dst, int uu, unsigned soff) {
         const int cimg = (uu * UPX) / (H * H);
         const unsigned v = (NIMG == 1 || pimg0 < nv_req - cimg) ? irel0 : BIG_OOB;
@@ -357,14 +364,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (i < WN && !(BIG_EXP & 2)) store_w(WU * i, WU * (i + 1), buf ^ 1);
             if (i == WN && !(BIG_EXP & 4)) load_w(wsoff);
             if constexpr (ALLC) {
-                // ci = this chunk's index in the item (a constant after unrolling).  Last chunk: the next item's NCHUNK x NU units are requested four per step in rows
-                // 0..3 (chunk 0 first: it is written below, in this chunk); other chunks: no request, chunk ci + 1 leaves hreg for the free tile buffer.
-                if (ci == NCHUNK - 1 && R <= 3 && (i == 3 || i == 4) && !(BIG_EXP & 8)) {
+                // ci = this chunk's index in its group of four (a constant: the group loop is unrolled).  Last chunk of a group: the next group's 4 x NU units (the
+                // next item's first group behind the item's last chunk) are requested four per step in rows 0..3 (its first chunk first: that one is written below, in
+                // this chunk); other chunks: no request, chunk ci + 1 of the group leaves hreg for the free tile buffer.
+                if (ci == 3 && R <= 3 && (i == 3 || i == 4) && !(BIG_EXP & 8)) {
                     const int sl = R * 2 + (i - 3);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int u = 4 * sl + q, k = u / NU, uu = u % NU;
-                        if (u < NCHUNK * NU) { if (k == 0) load_unit_to(breg[uu], uu, tsoff[0]); else load_unit_to(hreg[(k - 1) * NU + uu], uu, tsoff[0] + (unsigned)(k * KCB * 2)); }
+                        if (u < 4 * NU) { if (k == 0) load_unit_to(breg[uu], uu, tsoff[0]); else load_unit_to(hreg[(k - 1) * NU + uu], uu, tsoff[0] + (unsigned)(k * KCB * 2)); }
                     }
                 }
                 if ((((R == 2 || R == 3) && (i == 3 || i == 4)) || (R == 4 && (i == 2 || i == 3))) && !(BIG_EXP & 8)) {
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const int uu = 2 * sl + q;
-                        if (uu < NU) { if (ci == NCHUNK - 1) store_unit_from(breg[uu], uu, TB ^ 1); else store_unit_from(hreg[(ci < NCHUNK - 1 ? ci : 0) * NU + uu], uu, TB ^ 1); }
+                        if (uu < NU) { if (ci == 3) store_unit_from(breg[uu], uu, TB ^ 1); else store_unit_from(hreg[(ci < 3 ? ci : 0) * NU + uu], uu, TB ^ 1); }
                     }
                 }
             } else if constexpr (TDB) {
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         load_input(ts);
         if constexpr (ALLC) {
 #pragma unroll
-            for (int k = 1; k < NCHUNK; ++k)
+            for (int k = 1; k < 4; ++k)
 #pragma unroll
                 for (int uu = 0; uu < NU; ++uu) load_unit_to(hreg[(k - 1) * NU + uu], uu, ts[0] + (unsigned)(k * KCB * 2));
         }
@@ -620,9 +628,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // Two chunks per trip (the fragment sets alternate per step, a chunk has KS x NSTEP steps), kernel rows unrolled.  Slab st + 1 is
         // travelling in wreg when stage st starts (requested by stage st - 1, by the previous item's last stage, or by the prologue).
         static_assert(NCHUNK % 2 == 0, "chunks are walked in pairs");
-        constexpr int PAIR_UNROLL = ALLC ? NCHUNK / 2 : 1;     // ALLC: the chunk index is a constant in every stage
-#pragma unroll PAIR_UNROLL
-        for (int cp = 0; cp < NCHUNK; cp += 2) {
+        constexpr int GP = ALLC ? 2 : 1;                       // ALLC: a trip is a GROUP of four chunks (two pairs), so that the chunk's index in its group is a constant
+        for (int cq = 0; cq < NCHUNK; cq += 2 * GP) {
+#pragma unroll
+        for (int g2 = 0; g2 < GP; ++g2) {
+            const int cp = cq + 2 * g2;
 #ifdef BIG_STEPTIME
             steptime_on = BT_ON && blockIdx.x == 0 && steptime_first && cp == (NCHUNK >= 4 ? 2 : 0);
             steptime_idx = 0;
@@ -668,17 +678,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         sb16 = sb16 == 2 ? 0 : sb16 + 1;
                     } else
                     if (h == 0) {
-                        if (r == 0) stage(std::integral_constant<int, P0v[0][0]>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts, cc);
-                        if (r == 1) stage(std::integral_constant<int, P0v[0][1]>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts, cc);
-                        if (r == 2) stage(std::integral_constant<int, P0v[0][2]>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts, cc);
-                        if (r == 3) stage(std::integral_constant<int, P0v[0][3]>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts, cc);
-                        if (r == 4) stage(std::integral_constant<int, P0v[0][4]>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts, cc);
+                        if (r == 0) stage(std::integral_constant<int, P0v[0][0]>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts, 2 * g2 + h);
+                        if (r == 1) stage(std::integral_constant<int, P0v[0][1]>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts, 2 * g2 + h);
+                        if (r == 2) stage(std::integral_constant<int, P0v[0][2]>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts, 2 * g2 + h);
+                        if (r == 3) stage(std::integral_constant<int, P0v[0][3]>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts, 2 * g2 + h);
+                        if (r == 4) stage(std::integral_constant<int, P0v[0][4]>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{}, gst, wsoff, ts, 2 * g2 + h);
                     } else {
-                        if (r == 0) stage(std::integral_constant<int, P0v[1][0]>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts, cc);
-                        if (r == 1) stage(std::integral_constant<int, P0v[1][1]>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts, cc);
-                        if (r == 2) stage(std::integral_constant<int, P0v[1][2]>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts, cc);
-                        if (r == 3) stage(std::integral_constant<int, P0v[1][3]>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts, cc);
-                        if (r == 4) stage(std::integral_constant<int, P0v[1][4]>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts, cc);
+                        if (r == 0) stage(std::integral_constant<int, P0v[1][0]>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts, 2 * g2 + h);
+                        if (r == 1) stage(std::integral_constant<int, P0v[1][1]>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts, 2 * g2 + h);
+                        if (r == 2) stage(std::integral_constant<int, P0v[1][2]>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts, 2 * g2 + h);
+                        if (r == 3) stage(std::integral_constant<int, P0v[1][3]>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts, 2 * g2 + h);
+                        if (r == 4) stage(std::integral_constant<int, P0v[1][4]>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{}, gst, wsoff, ts, 2 * g2 + h);
                     }
                     ++gst;
                     if (BN && h == 0 && r == 0 && cp == 0) bn_combine();      // behind stage 0's barrier: the previous item's rows are complete
@@ -699,6 +709,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) xf16[0][j] = xf16[1][j];
             }
+        }
         }
         BT(b1);
 
@@ -955,8 +966,8 @@ int launch_conv_bf16_big(int layer, int width, bool dgrad, int mask, const ConvB
     if (!conv_bf16_big_has(layer, width, dgrad, mask)) return -100;
     if (dgrad) {
         if (width == 64 && layer == 3 && big_s16()) return run_big<256, 128, 8, 128, 4, 1, EPI_PLAIN, true, true>(a, st);
-        if (width == 64 && layer == 3) return run_big<256, 128, 8, 128, 4, 1, EPI_PLAIN, BIG_IMGL>(a, st);
-        if (width == 64 && layer == 2) return run_big<128, 64, 16, 64, 8, 1, EPI_PLAIN, BIG_IMGL>(a, st);
+        if (width == 64 && layer == 3) return run_big<256, 128, 8, 128, 4, 1, EPI_PLAIN, BIG_IMGL, false, BIG_ALLC4>(a, st);
+        if (width == 64 && layer == 2) return run_big<128, 64, 16, 64, 8, 1, EPI_PLAIN, BIG_IMGL, false, BIG_ALLC3>(a, st);
         if (width == 64 && layer == 1) return run_big<64, 32, 32, 32, 8, 1, EPI_PLAIN, true, false, BIG_ALLC>(a, st);      // E2: image-high item, 8 x 1 wave tile, whole lines fetched once
         if (width == 128 && layer == 3) return run_big<256, 128, 16, 128, 4, 1, EPI_PLAIN, BIG_IMGL>(a, st);
         if (width == 128 && layer == 2) return run_big<128, 64, 32, 64, 8, 1, EPI_PLAIN, BIG_IMGL>(a, st);

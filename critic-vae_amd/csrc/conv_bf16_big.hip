@@ -56,6 +56,10 @@ typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 #ifndef BIG_EXP
 #define BIG_EXP 0
 #endif
+#ifndef BIG_ST_AUX
+#define BIG_ST_AUX (BN ? 0 : 2)      // cache policy of the output stores: nt (2) for the input gradients — the written lines do not push the input lines the next chunks re-read out of
+                                      // L2 (counter fetch of E3's input gradient 260 -> 234 MB, E2's 318 -> 299; kernels -1 %; profiles/r05_r_e2_on_big_kernel.txt); forward outputs stay cached
+#endif
 #ifndef BIG_ALLC4
 #define BIG_ALLC4 false    // experiment builds: the same for E4's input gradient (4 lines per pixel, groups of four chunks)
 #endif
@@ -837,7 +841,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             auto flush_rows = [&]() {
 #pragma unroll
                 for (int k = 0; k < PIT; ++k)
-                    if (!(BIG_EXP & 64)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, rows[k]), rs_out, rbase == BIG_OOB ? BIG_OOB : rbase + orow[k], 0, 0);
+                    if (!(BIG_EXP & 64)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, rows[k]), rs_out, rbase == BIG_OOB ? BIG_OOB : rbase + orow[k], 0, BIG_ST_AUX);
             };
 #pragma unroll
             for (int tl = 0; tl < MT; ++tl) {

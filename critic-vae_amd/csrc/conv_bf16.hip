@@ -42,11 +42,11 @@ enum { MODE_STD = 0, MODE_UP_FWD = 1, MODE_UP_DGRAD = 2 };
 // bit 5 = E4 forward, bit 6 = E2 forward and bit 7 = E2 input gradient at 64 x 64 (image-high items on an 8 x 1 wave tile; one BatchNorm partial per item of
 // four / eight tiles); 0 = the two-workgroup / per-tile kernels (A/B runs).  Defaults from the un-profiled step on one box, masks alternating
 // (profiles/r05_g_big_mask_sweep.txt, r05_k_big_image_layout.txt, r05_r_e2_on_big_kernel.txt): every bit at 64 x 64 (252: E2 forward 196 vs 209 us, E2 input gradient
-// 192 vs 209 us, step +0.8 % over mask 60), 60 at 128 x 128 (E2's 64-row images have no whole-image item).
+// 192 vs 209 us, step +0.8 % over mask 60) and at 128 x 128 (E2's 64-row images as 16-row strips with real halo rows: input gradient 379 vs 415 us, forward 424 vs 431, step +0.9 %).
 #define BF16_BIG_DEFAULT 252
 #endif
 #ifndef BF16_BIG_DEFAULT_W128
-#define BF16_BIG_DEFAULT_W128 60
+#define BF16_BIG_DEFAULT_W128 252
 #endif
 #ifndef BF16_WDMA
 #define BF16_WDMA 0        // 1 (experiment, round 3): weight slabs travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) into a double

@@ -117,9 +117,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // Every halo pixel of a whole image is zero padding: the planes are zeroed once per kernel and only the H x H interiors are ever staged —
     // 128 instead of 288 units per 8 x 8-image tile, 1024 instead of 2304 for a 32 x 32 image cut into eight 4-row tiles (the tiles of the
     // per-tile layout carry a halo each: 98 KB of requests per 16-channel chunk, which is what kept E2 off this kernel).
+    // STRIP (64-row images, E2 at 128 x 128 frames): an image does not fit, so the item is a full-width STRIP of SR rows (its MT tiles, TILES_X side by side) with two real
+    // halo rows above and below — staged with the interior (out-of-range offsets = zeros at the image's top / bottom edge) — and the two zero columns left and right.
     constexpr int HW = H + 4, NIMG = MT * 128 / (H * H);
-    static_assert(!IMGL || (NIMG >= 1 && NIMG * H * H == MT * 128 && T::TW == H && T::HTW == HW), "image layout: the item's tiles are whole images");
-    constexpr int PSPI = ((NIMG * HW * HW + 15 - Bf16Geom<H, OCT>::PAD) / 16) * 16 + Bf16Geom<H, OCT>::PAD;      // plane stride, == 16 / OCT (mod 16) like PSP
+    constexpr bool STRIP = IMGL && T::TW != H;
+    constexpr int SR = STRIP ? MT * 128 / H : 0;
+    static_assert(!IMGL || STRIP || (NIMG >= 1 && NIMG * H * H == MT * 128 && T::TW == H && T::HTW == HW), "image layout: the item's tiles are whole images");
+    static_assert(!STRIP || (H % SR == 0 && MT % T::TILES_X == 0 && T::TH * (MT / T::TILES_X) == SR && T::IMGS == 1 && !S16 && !ALLC && 256 / OCT == 2 * H), "strip layout");
+    constexpr int PLPX = STRIP ? (SR + 4) * HW : NIMG * HW * HW;          // halo pixels of one octet plane
+    constexpr int PSPI = ((PLPX + 15 - Bf16Geom<H, OCT>::PAD) / 16) * 16 + Bf16Geom<H, OCT>::PAD;      // plane stride, == 16 / OCT (mod 16) like PSP
     constexpr int PSX = IMGL ? PSPI : PSP;                     // octet-plane stride of the layout in use
     constexpr int TILE_UNITS = IMGL ? OCT * PSPI : MT * A_UNITS;       // one tile buffer
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- per-thread tables that do not depend on the item ----
     const int m = wave * 32 + lane_pix<H, true>(li);           // pixel (of the 128 of a tile) behind MFMA column li of this wave
     const int pimg = m / (T::TH * T::TW), prem = m % (T::TH * T::TW);
-    const int aPix = pimg * T::HPI + (prem / T::TW) * T::HTW + (prem % T::TW);
+    const int aPix = STRIP ? (prem / T::TW) * HW + (prem % T::TW) : pimg * T::HPI + (prem / T::TW) * T::HTW + (prem % T::TW);
     // epilogue patch of this wave: [32 pixel rows][RU0 = 8 units of 8 channels + 1 pad] = the wave's pixels x 64 channels (two channel blocks: one
     // 128-byte line per pixel); lane (li, lh) writes units 4 nb' + 2 k + lh of row li, and reads back unit (lane % 8) of rows (lane / 8) + 8 k:
     // orow[k] = byte offset of that row's pixel from the tile's first pixel, pcol = of the unit
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     // staged 16-byte units per thread and tile buffer: per tile IPT units of its halo image (tables shared by the tiles), or (IMGL) the item's
     // NU units of image interiors
-    constexpr int NQ = IMGL ? NIMG * H * H * OCT : T::HP * OCT, IPT = (NQ + 255) / 256;
+    constexpr int NQ = STRIP ? (SR + 4) * H * OCT : (IMGL ? NIMG * H * H * OCT : T::HP * OCT), IPT = (NQ + 255) / 256;
     constexpr int NU = IMGL ? IPT : MT * IPT;                  // units a thread stages per tile buffer
     static_assert(NU <= 32 && (!IMGL || NQ % 256 == 0), "staged units");
     constexpr int IPTT = IMGL ? 1 : IPT;
@@ -189,7 +195,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     static_assert(!IMGL || (UPX % H == 0 && (H * H) % UPX == 0) || UPX % (H * H) == 0, "a unit step is whole rows of one image, or whole images");
     [[maybe_unused]] unsigned irel0 = 0;
     [[maybe_unused]] int ilds0 = 0, pimg0 = 0;
-    if constexpr (IMGL) {
+    [[maybe_unused]] bool top_req = false, bot_req = false;     // STRIP: the item being requested touches the image's top / bottom edge (its halo rows there are padding)
+    if constexpr (STRIP) {                                     // unit u = strip rows 2 u, 2 u + 1 (row 0 = two rows above the strip's first), interior columns
+        const int oct = tid % OCT, px = tid / OCT, row0 = px / H, x = px % H;
+        irel0 = (unsigned)((((row0 - 2) * H + x) * KCH + oct * 8) * 2 + (2 * H + 2) * KCH * 2);
+        ilds0 = oct * PSPI + row0 * HW + x + 2;
+    } else if constexpr (IMGL) {
         const int oct = tid % OCT, px = tid / OCT, img = px / (H * H), rem = px - img * (H * H), y = rem / H, x = rem % H;
         irel0 = (unsigned)((px * KCH + oct * 8) * 2 + (2 * H + 2) * KCH * 2);     // + IBIAS (the input descriptor starts that far in front of the tensor)
         ilds0 = oct * PSPI + img * (HW * HW) + (y + 2) * HW + x + 2;
@@ -245,7 +256,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (i < WPT) lds_w[(W_UNITS % 256 == 0 || tid + i * 256 < W_UNITS) ? buf * W_UNITS + tid + i * 256 : NSLAB * W_UNITS + tid] = wreg[i < WPT ? i : 0];
     };
     auto set_voff = [&](const Item& x) {
-        if constexpr (IMGL) {                                  // interiors only: a unit is missing only when its image is (ragged last item)
+        if constexpr (STRIP) {
+            top_req = x.ty0[0] == 0; bot_req = x.ty0[0] + SR == H;
+        } else if constexpr (IMGL) {                           // interiors only: a unit is missing only when its image is (ragged last item)
             nv_req = a.B - x.img0[0];
         } else {
 #pragma unroll
@@ -262,7 +275,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // and where it goes (units that do not exist land in the dump slots behind the slabs: no branch around a store)
     auto load_unit = [&](int u, const unsigned (&tsoff)[MT]) {
         if (u < NU) {
-            if constexpr (IMGL) {
+            if constexpr (STRIP) {
+                const unsigned v = ((u == 0 && top_req) || (u == NU - 1 && bot_req)) ? BIG_OOB : irel0;
+                breg[u] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v, tsoff[0] + (unsigned)(u * UPX * KCH * 2), 0));
+            } else if constexpr (IMGL) {
                 const int cimg = (u * UPX) / (H * H);
                 const unsigned v = (NIMG == 1 || pimg0 < nv_req - cimg) ? irel0 : BIG_OOB;      // the unit's image number stays on the scalar side
                 breg[u] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v, tsoff[0] + (unsigned)(u * UPX * KCH * 2), 0));
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto store_unit = [&](int u, int tb) {
         if (u < NU) {
             if constexpr (IMGL) {
-                const int clds = ((u * UPX) / (H * H)) * (HW * HW) + (((u * UPX) % (H * H)) / H) * HW;
+                const int clds = STRIP ? (u * UPX / H) * HW : ((u * UPX) / (H * H)) * (HW * HW) + (((u * UPX) % (H * H)) / H) * HW;
                 lds_a[tb * TILE_UNITS + clds + ilds0] = breg[u];
             } else {
                 const int tl = u / IPT, i = u % IPT, q = tid + i * 256;
@@ -309,14 +325,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     bf16x8 wf[2][NB], xf[2][MT];                               // two fragment sets, alternating per step (they live across stages)
     auto ldf = [&](int set, int i, int r, int buf, int tb = 0) {   // fragments of step i of a stage (kernel row r, slab buffer buf, tile buffer tb)
         const int s = i / KB, kb = i % KB;
-        const bf16x8* ap = lds_a + (TDB ? tb : 0) * TILE_UNITS + lh * PSX + aPix + r * T::HTW;
+        const bf16x8* ap = lds_a + (TDB ? tb : 0) * TILE_UNITS + lh * PSX + aPix + r * (STRIP ? HW : T::HTW);
         const bf16x8* bp = lds_w + buf * W_UNITS + lh * NT + li;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) wf[set][nb] = bp[((s * KB + kb) * 2) * NT + nb * 32];
 #pragma unroll
         for (int tl = 0; tl < MT; ++tl) {                      // IMGL: tile tl = 128 consecutive pixels of the item's images, its first one at halo pixel toff
             constexpr int TPX = 128;
-            const int toff = IMGL ? (tl * TPX / (H * H)) * (HW * HW) + ((tl * TPX % (H * H)) / H) * HW : tl * A_UNITS;
+            const int toff = STRIP ? (tl / T::TILES_X) * T::TH * HW + (tl % T::TILES_X) * T::TW
+                                   : (IMGL ? (tl * TPX / (H * H)) * (HW * HW) + ((tl * TPX % (H * H)) / H) * HW : tl * A_UNITS);
             xf[set][tl] = ap[toff + (kb * 2) * PSX + s];
         }
     };
@@ -927,7 +944,8 @@ static int run_big(const ConvBf16Args& a, hipStream_t st) {
     constexpr int OCT = 2 * KB;
     constexpr int NY = NCH / NT;
     constexpr int NIMG = MT * 128 / (H * H), PAD = Bf16Geom<H, OCT>::PAD;
-    constexpr int TILE_UNITS = IMGL ? OCT * (((NIMG * (H + 4) * (H + 4) + 15 - PAD) / 16) * 16 + PAD) : MT * OCT * Bf16Geom<H, OCT>::PSP;
+    constexpr int PLPX = (IMGL && T::TW != H) ? (MT * 128 / H + 4) * (H + 4) : NIMG * (H + 4) * (H + 4);      // strip layout: SR + 4 rows of H + 4
+    constexpr int TILE_UNITS = IMGL ? OCT * (((PLPX + 15 - PAD) / 16) * 16 + PAD) : MT * OCT * Bf16Geom<H, OCT>::PSP;
     constexpr int SMEM = ((TDB ? 2 : 1) * TILE_UNITS + (S16 ? 3 : 2) * 5 * KB * 2 * NT + 256 + (S16 ? 4 * 16 * 9 : 4 * 32 * 9)) * 16 + (EPI == EPI_BIAS_BNSTAT ? (2 * 4 * NT + NCH) * 4 : 0);
     static_assert(SMEM <= 160 * 1024, "LDS");
     // 32-bit byte offsets and buffer descriptors inside: larger tensors take the per-tile kernels (size_t addressing)
@@ -961,8 +979,8 @@ static int run_big(const ConvBf16Args& a, hipStream_t st) {
 static bool big_s16() { static const bool on = [] { const char* e = getenv("CVAE_BIG_S16"); return e && atoi(e) != 0; }(); return on; }
 bool conv_bf16_big_has(int layer, int width, bool dgrad, int mask) {
     if (width != 64 && width != 128) return false;
-    if (dgrad) return (layer == 3 && (mask & 1)) || (layer == 2 && (mask & 2)) || (layer == 1 && width == 64 && (mask & 4));
-    return (layer == 2 && (mask & 1)) || (layer == 3 && (mask & 2)) || (layer == 1 && width == 64 && (mask & 4));
+    if (dgrad) return (layer == 3 && (mask & 1)) || (layer == 2 && (mask & 2)) || (layer == 1 && (mask & 4));
+    return (layer == 2 && (mask & 1)) || (layer == 3 && (mask & 2)) || (layer == 1 && (mask & 4));
 }
 int conv_bf16_big_tiles(int layer, int width, bool dgrad) { (void)width; return ((dgrad && layer == 2) || (!dgrad && layer == 1)) ? 8 : 4; }
 // returns -100 when the layer has no instantiation (or the tensors are too large for its 32-bit offsets)
@@ -975,6 +993,7 @@ int launch_conv_bf16_big(int layer, int width, bool dgrad, int mask, const ConvB
         if (width == 64 && layer == 1) return run_big<64, 32, 32, 32, 8, 1, EPI_PLAIN, true, false, BIG_ALLC>(a, st);      // E2: image-high item, 8 x 1 wave tile, whole lines fetched once
         if (width == 128 && layer == 3) return run_big<256, 128, 16, 128, 4, 1, EPI_PLAIN, BIG_IMGL>(a, st);
         if (width == 128 && layer == 2) return run_big<128, 64, 32, 64, 8, 1, EPI_PLAIN, BIG_IMGL>(a, st);
+        if (width == 128 && layer == 1) return run_big<64, 32, 64, 32, 8, 1, EPI_PLAIN, true>(a, st);       // 16-row strips of the 64-row image, 8 x 1
     } else {
         if (width == 64 && layer == 1) return run_big<32, 64, 32, 32, 8, 1, EPI_BIAS_BNSTAT, true>(a, st);      // 8 x 1 (two channel halves per image); 8 x 2: 244 us
         if (width == 64 && layer == 2) return run_big<64, 128, 16, 128, 4, 1, EPI_BIAS_BNSTAT, BIG_IMGL>(a, st);
@@ -982,6 +1001,7 @@ int launch_conv_bf16_big(int layer, int width, bool dgrad, int mask, const ConvB
         if (width == 64 && layer == 3) return run_big<128, 256, 8, 128, 4, 1, EPI_BIAS_BNSTAT, BIG_IMGL>(a, st);
         if (width == 128 && layer == 2) return run_big<64, 128, 32, 128, 4, 1, EPI_BIAS_BNSTAT>(a, st);       // half an image per item: per-tile layout
         if (width == 128 && layer == 3) return run_big<128, 256, 16, 128, 4, 1, EPI_BIAS_BNSTAT, BIG_IMGL>(a, st);
+        if (width == 128 && layer == 1) return run_big<32, 64, 64, 32, 8, 1, EPI_BIAS_BNSTAT, true>(a, st);
     }
     return -100;
 }
